@@ -1,0 +1,744 @@
+/* daala_oracle.c - CPU restatement of the Daala transform + PVQ hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (daala_amd/, include/) may
+ * include, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, as the checker for the HIP path.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-exactly against
+ * the real reference compiled from /root/reference (oracle/_ref, built by
+ * oracle/Makefile) in tests/test_oracle_vs_ref.py, against golden vectors
+ * generated from that build (tests/golden/, tools/gen_golden.py) and - for the
+ * transforms - against the reference's own self-test `dcttest`
+ * (src/dct.c:2192-3951; stdout md5 eaace07761b6fd646b83285dfbdbc5c2).
+ *
+ * Exception (documented in DESIGN.md): orc_gain_compand with beta != 1 calls
+ * the host libm pow(), exactly like the reference does; its value is therefore
+ * "the reference on this libm", not an independent restatement of pow.
+ *
+ * Plain C99, no FMA contraction (-ffp-contract=off in oracle/Makefile) so double
+ * arithmetic evaluates left to right like the gcc -O2 reference build.
+ * od_coeff == int32_t (reference src/filter.h:31).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "gen_lift_oracle.h"
+#include "coding_order_tables.h"
+
+typedef int32_t coeff;
+
+/* ------------------------------------------------------------------------ */
+/* A6/A7: 1-D and separable 2-D reversible DCT (reference src/dct.c:137-149,
+   :335-347, :774-788, :2028-2042).  Forward: N column transforms into the rows
+   of a scratch, then N column transforms of the scratch into rows of y.
+   Inverse: rows of y into columns of the scratch, rows of scratch into columns
+   of x.  The order is observable because of rounding. */
+typedef void (*fdct1d_fn)(int32_t *y, const int32_t *x, int xs);
+typedef void (*idct1d_fn)(int32_t *x, int xs, const int32_t *y);
+
+static fdct1d_fn fdct_1d_of(int n) {
+  return n == 4 ? orc_fdct4_1d : n == 8 ? orc_fdct8_1d
+       : n == 16 ? orc_fdct16_1d : orc_fdct32_1d;
+}
+static idct1d_fn idct_1d_of(int n) {
+  return n == 4 ? orc_idct4_1d : n == 8 ? orc_idct8_1d
+       : n == 16 ? orc_idct16_1d : orc_idct32_1d;
+}
+
+void orc_fdct_1d(int n, coeff *y, const coeff *x, int xstride) {
+  fdct_1d_of(n)(y, x, xstride);
+}
+void orc_idct_1d(int n, coeff *x, int xstride, const coeff *y) {
+  idct_1d_of(n)(x, xstride, y);
+}
+
+void orc_fdct_2d(int n, coeff *y, int ystride, const coeff *x, int xstride) {
+  coeff z[32*32];
+  fdct1d_fn f = fdct_1d_of(n);
+  int i;
+  for (i = 0; i < n; i++) f(z + n*i, x + i, xstride);
+  for (i = 0; i < n; i++) f(y + ystride*i, z + i, n);
+}
+
+void orc_idct_2d(int n, coeff *x, int xstride, const coeff *y, int ystride) {
+  coeff z[32*32];
+  idct1d_fn f = idct_1d_of(n);
+  int i;
+  for (i = 0; i < n; i++) f(z + i, n, y + ystride*i);
+  for (i = 0; i < n; i++) f(x + i, xstride, z + n*i);
+}
+
+/* ------------------------------------------------------------------------ */
+/* A8: 2x2 Haar kernel (reference src/tf.h:34-45) and the multi-level 2-D Haar
+   used for lossless frames (src/dct.c:1960-2026). */
+static void haar_kernel(coeff *ll, coeff *lh, coeff *hl, coeff *hh) {
+  coeff a = *ll, b = *lh, c = *hl, d = *hh, m;
+  a += c;
+  d -= b;
+  m = (a - d) >> 1;
+  b = m - b;
+  c = m - c;
+  a -= b;
+  d += c;
+  *ll = a; *lh = b; *hl = c; *hh = d;
+}
+
+void orc_haar(coeff *y, int ystride, const coeff *x, int xstride, int ln) {
+  coeff tmp[32*32];
+  int n = 1 << ln, i, j, level;
+  for (i = 0; i < n; i++)
+    for (j = 0; j < n; j++) tmp[i*n + j] = x[i*xstride + j];
+  for (level = 0; level < ln; level++) {
+    int np = n >> level >> 1;
+    for (i = 0; i < np; i++) {
+      for (j = 0; j < np; j++) {
+        coeff a = tmp[2*i*n + 2*j], b = tmp[(2*i + 1)*n + 2*j];
+        coeff c = tmp[2*i*n + 2*j + 1], d = tmp[(2*i + 1)*n + 2*j + 1];
+        haar_kernel(&a, &b, &c, &d);
+        tmp[i*n + j] = a;
+        y[i*ystride + j + np] = b;
+        y[(i + np)*ystride + j] = c;
+        y[(i + np)*ystride + j + np] = d;
+      }
+    }
+  }
+  y[0] = tmp[0];
+}
+
+void orc_haar_inv(coeff *x, int xstride, const coeff *y, int ystride, int ln) {
+  int i, j, level;
+  x[0] = y[0];
+  for (level = ln - 1; level >= 0; level--) {
+    int np = 1 << (ln - 1 - level);
+    for (i = np - 1; i >= 0; i--) {
+      for (j = np - 1; j >= 0; j--) {
+        coeff a = x[i*xstride + j], b = y[i*ystride + j + np];
+        coeff c = y[(i + np)*ystride + j], d = y[(i + np)*ystride + j + np];
+        haar_kernel(&a, &b, &c, &d);
+        x[2*i*xstride + 2*j] = a;
+        x[(2*i + 1)*xstride + 2*j] = b;
+        x[2*i*xstride + 2*j + 1] = c;
+        x[(2*i + 1)*xstride + 2*j + 1] = d;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* A3: 4-point lapping pre/post filter (reference src/filter.c:174-249, params
+   85,75,-15,33 at :164-167).  In/out may alias.  The forward scale uses a floor
+   shift plus "+1 if positive"; the inverse undoes it with C truncating
+   division. */
+void orc_pre_filter4(coeff *y, const coeff *x) {
+  int d3 = x[0] - x[3];
+  int d2 = x[1] - x[2];
+  int s1 = x[1] - (d2 >> 1);
+  int s0 = x[0] - (d3 >> 1);
+  d2 = d2*85 >> 6;
+  if (d2 > 0) d2++;
+  d3 = d3*75 >> 6;
+  if (d3 > 0) d3++;
+  d3 += (d2*-15 + 32) >> 6;
+  d2 += (d3*33 + 32) >> 6;
+  s0 += d3 >> 1;
+  s1 += d2 >> 1;
+  y[0] = s0;
+  y[1] = s1;
+  y[2] = s1 - d2;
+  y[3] = s0 - d3;
+}
+
+void orc_post_filter4(coeff *x, const coeff *y) {
+  int d3 = y[0] - y[3];
+  int d2 = y[1] - y[2];
+  int s1 = y[1] - (d2 >> 1);
+  int s0 = y[0] - (d3 >> 1);
+  d2 -= (d3*33 + 32) >> 6;
+  d3 -= (d2*-15 + 32) >> 6;
+  d3 = d3*64/75;
+  d2 = d2*64/85;
+  s0 += d3 >> 1;
+  s1 += d2 >> 1;
+  x[0] = s0;
+  x[1] = s1;
+  x[2] = s1 - d2;
+  x[3] = s0 - d3;
+}
+
+static void filt4_col(coeff *c, int stride, int inv) {
+  coeff t[4];
+  int k;
+  for (k = 0; k < 4; k++) t[k] = c[k*stride];
+  if (inv) orc_post_filter4(t, t); else orc_pre_filter4(t, t);
+  for (k = 0; k < 4; k++) c[k*stride] = t[k];
+}
+
+/* A4: lapping across every superblock boundary of a plane (reference
+   src/filter.c:1556-1586 pre, :1588-1646 post).  Pre: all horizontal boundaries
+   (vertical taps) first, then all vertical boundaries; post: the reverse.
+   sb = superblock size in this plane (32 >> dec). */
+void orc_prefilter_frame_sbs(coeff *c, int stride, int nhsb, int nvsb, int dec) {
+  int sb = 32 >> dec, w = nhsb*sb, h = nvsb*sb, s, i;
+  for (s = 1; s < nvsb; s++)
+    for (i = 0; i < w; i++) filt4_col(c + (s*sb - 2)*stride + i, stride, 0);
+  for (s = 1; s < nhsb; s++)
+    for (i = 0; i < h; i++) {
+      coeff *p = c + i*stride + s*sb - 2;
+      orc_pre_filter4(p, p);
+    }
+}
+
+void orc_postfilter_frame_sbs(coeff *c, int stride, int nhsb, int nvsb, int dec) {
+  int sb = 32 >> dec, w = nhsb*sb, h = nvsb*sb, s, i;
+  for (s = 1; s < nhsb; s++)
+    for (i = 0; i < h; i++) {
+      coeff *p = c + i*stride + s*sb - 2;
+      orc_post_filter4(p, p);
+    }
+  for (s = 1; s < nvsb; s++)
+    for (i = 0; i < w; i++) filt4_col(c + (s*sb - 2)*stride + i, stride, 1);
+}
+
+/* A5: lapping on the internal cross of an n x n block about to be split
+   (reference src/filter.c:1486-1510 pre, :1512-1554 post; always the 4-point
+   filter since OD_FILT_SIZE()==0, src/filter.h:99).  `hfilter` gates the taps
+   across the horizontal centre line, `vfilter` those across the vertical one. */
+void orc_prefilter_split(coeff *c, int stride, int n, int hfilter, int vfilter) {
+  int i;
+  if (hfilter)
+    for (i = 0; i < n; i++) filt4_col(c + (n/2 - 2)*stride + i, stride, 0);
+  if (vfilter)
+    for (i = 0; i < n; i++) {
+      coeff *p = c + i*stride + n/2 - 2;
+      orc_pre_filter4(p, p);
+    }
+}
+
+void orc_postfilter_split(coeff *c, int stride, int n, int hfilter, int vfilter) {
+  int i;
+  if (vfilter)
+    for (i = 0; i < n; i++) {
+      coeff *p = c + i*stride + n/2 - 2;
+      orc_post_filter4(p, p);
+    }
+  if (hfilter)
+    for (i = 0; i < n; i++) filt4_col(c + (n/2 - 2)*stride + i, stride, 1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* A1/A2: pixel <-> coefficient domain (reference src/state.c:1209-1232 and
+   :1274-1300, 8-bit references: xstride 1). */
+void orc_ref_buf_to_coeff(coeff *dst, int dstride, const uint8_t *src,
+ int sstride, int w, int h, int coeff_shift) {
+  int x, y;
+  for (y = 0; y < h; y++)
+    for (x = 0; x < w; x++)
+      dst[y*dstride + x] = (src[y*sstride + x] - 128)*(1 << coeff_shift);
+}
+
+void orc_coeff_to_ref_buf(uint8_t *dst, int dstride, const coeff *src,
+ int sstride, int w, int h, int coeff_shift) {
+  int x, y;
+  for (y = 0; y < h; y++)
+    for (x = 0; x < w; x++) {
+      int v = ((src[y*sstride + x] + (1 << coeff_shift >> 1)) >> coeff_shift) + 128;
+      dst[y*dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* A11: raster <-> coding (band) order (reference src/partition.c:144-194).
+   dst has n*n entries; for n==32 only entries 0..511 are written/read. */
+static const uint16_t *coding_table(int n, int *ncoded) {
+  switch (n) {
+    case 4: *ncoded = CODING_NCODED_4; return CODING_TO_RASTER_4;
+    case 8: *ncoded = CODING_NCODED_8; return CODING_TO_RASTER_8;
+    case 16: *ncoded = CODING_NCODED_16; return CODING_TO_RASTER_16;
+    default: *ncoded = CODING_NCODED_32; return CODING_TO_RASTER_32;
+  }
+}
+
+void orc_raster_to_coding_order(coeff *dst, int n, const coeff *src, int stride) {
+  int nc, i;
+  const uint16_t *t = coding_table(n, &nc);
+  for (i = 0; i < nc; i++) dst[i] = src[(t[i]/n)*stride + t[i]%n];
+}
+
+void orc_coding_order_to_raster(coeff *dst, int stride, const coeff *src, int n) {
+  int nc, i;
+  const uint16_t *t = coding_table(n, &nc);
+  for (i = 0; i < nc; i++) dst[(t[i]/n)*stride + t[i]%n] = src[i];
+}
+
+/* Band boundaries in coding order (reference src/partition.c:77-91): returns the
+   number of bands of an n x n block and fills off[0..nb]. */
+int orc_band_offsets(int n, int *off) {
+  static const int all[] = {1, 16, 24, 32, 64, 96, 128, 256, 384, 512};
+  int nb = n == 4 ? 1 : n == 8 ? 4 : n == 16 ? 7 : 9, i;
+  for (i = 0; i <= nb; i++) off[i] = all[i];
+  return nb;
+}
+
+/* ------------------------------------------------------------------------ */
+/* A9: TF resampling (reference src/tf.c:38-108, :112-170) and the CfL luma
+   resample built on it (src/intra.c:72-109). */
+void orc_tf_up_h_lp(coeff *dst, int dstride, const coeff *src, int sstride,
+ int dx, int n) {
+  int x, y;
+  for (y = 0; y < n; y++)
+    for (x = 0; x < n >> 1; x++) {
+      coeff ll = src[y*sstride + x], lh = src[y*sstride + x + dx];
+      int sw = x & 1;
+      lh = ll - lh;
+      ll -= LIFT_HALF(lh);
+      dst[y*dstride + 2*x + sw] = ll;
+      dst[y*dstride + 2*x + 1 - sw] = lh;
+    }
+}
+
+void orc_tf_up_v_lp(coeff *dst, int dstride, const coeff *src, int sstride,
+ int dy, int n) {
+  int x, y;
+  for (y = 0; y < n >> 1; y++) {
+    int sw = y & 1;
+    for (x = 0; x < n; x++) {
+      coeff ll = src[y*sstride + x], hl = src[(y + dy)*sstride + x];
+      hl = ll - hl;
+      ll -= LIFT_HALF(hl);
+      dst[(2*y + sw)*dstride + x] = ll;
+      dst[(2*y + 1 - sw)*dstride + x] = hl;
+    }
+  }
+}
+
+/* Shared body of od_tf_up_hv_lp (count = n/2, offsets dx,dy) and od_tf_up_hv
+   (count = n, offsets n,n): note the lh/hl swap into the Haar kernel. */
+static void tf_up_hv_core(coeff *dst, int dstride, const coeff *src, int sstride,
+ int dx, int dy, int cnt) {
+  int x, y;
+  for (y = 0; y < cnt; y++) {
+    int vs = y & 1;
+    for (x = 0; x < cnt; x++) {
+      coeff ll = src[y*sstride + x], lh = src[y*sstride + x + dx];
+      coeff hl = src[(y + dy)*sstride + x], hh = src[(y + dy)*sstride + x + dx];
+      int hs = x & 1;
+      haar_kernel(&ll, &hl, &lh, &hh);
+      dst[(2*y + vs)*dstride + 2*x + hs] = ll;
+      dst[(2*y + vs)*dstride + 2*x + 1 - hs] = lh;
+      dst[(2*y + 1 - vs)*dstride + 2*x + hs] = hl;
+      dst[(2*y + 1 - vs)*dstride + 2*x + 1 - hs] = hh;
+    }
+  }
+}
+
+void orc_tf_up_hv_lp(coeff *dst, int dstride, const coeff *src, int sstride,
+ int dx, int dy, int n) {
+  tf_up_hv_core(dst, dstride, src, sstride, dx, dy, n >> 1);
+}
+
+void orc_tf_up_hv(coeff *dst, int dstride, const coeff *src, int sstride, int n) {
+  tf_up_hv_core(dst, dstride, src, sstride, n, n, n);
+}
+
+void orc_tf_down_hv(coeff *dst, int dstride, const coeff *src, int sstride, int n) {
+  int x, y;
+  n >>= 1;
+  for (y = 0; y < n; y++) {
+    int vs = y & 1;
+    for (x = 0; x < n; x++) {
+      int hs = x & 1;
+      coeff ll = src[(2*y + vs)*sstride + 2*x + hs];
+      coeff lh = src[(2*y + vs)*sstride + 2*x + 1 - hs];
+      coeff hl = src[(2*y + 1 - vs)*sstride + 2*x + hs];
+      coeff hh = src[(2*y + 1 - vs)*sstride + 2*x + 1 - hs];
+      haar_kernel(&ll, &lh, &hl, &hh);
+      dst[y*dstride + x] = ll;
+      dst[y*dstride + x + n] = lh;
+      dst[(y + n)*dstride + x] = hl;
+      dst[(y + n)*dstride + x + n] = hh;
+    }
+  }
+}
+
+/* CfL scaling of the 4x4 predictor, indexed [column][row] by the reference
+   (src/intra.c:65-70, :85-86); the table is symmetric so it reads the same. */
+static const int16_t CFL_SCALE4[4][4] = {
+  {128, 128, 100, 36}, {128, 80, 71, 35}, {100, 71, 35, 31}, {36, 35, 31, 18}};
+
+void orc_resample_luma_coeffs(coeff *pred, int pstride, const coeff *luma,
+ int lstride, int xdec, int ydec, int bs, int chroma_bs) {
+  int n = 4 << bs, x, y;
+  if (chroma_bs == 0 && (xdec || ydec)) {
+    if (xdec && ydec) {
+      orc_tf_up_hv_lp(pred, pstride, luma, lstride, n, n, n);
+      for (y = 0; y < 4; y++)
+        for (x = 0; x < 4; x++)
+          pred[y*pstride + x] = (CFL_SCALE4[x][y]*pred[y*pstride + x] + 64) >> 7;
+    }
+    else if (xdec) orc_tf_up_h_lp(pred, pstride, luma, lstride, n, n);
+    else orc_tf_up_v_lp(pred, pstride, luma, lstride, n, n);
+  }
+  else {
+    for (y = 0; y < n; y++)
+      for (x = 0; x < n; x++) pred[y*pstride + x] = luma[y*lstride + x];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* A10: keyframe luma H/V predictor (reference src/intra.c:37-61).  bsize is the
+   per-8x8... per-4x4-addressed block-size map accessor of the reference
+   (OD_BLOCK_SIZE4x4: bsize[(by>>1)*bstride + (bx>>1)], src/block_size.h). */
+void orc_hv_intra_pred(coeff *pred, const coeff *d, int w, int bx, int by,
+ const unsigned char *bsize, int bstride, int bs) {
+  int n = 4 << bs, i;
+  int top = by > 0 && bsize[((by - 1) >> 1)*bstride + (bx >> 1)] == bs;
+  int left = bx > 0 && bsize[(by >> 1)*bstride + ((bx - 1) >> 1)] == bs;
+  const coeff *t = d + (by << 2)*w + (bx << 2);
+  double g1 = 0, g2 = 0;
+  if (top) for (i = 1; i < 4; i++) g1 += t[-n*w + i]*(double)t[-n*w + i];
+  if (left) for (i = 1; i < 4; i++) g2 += t[-n + i*w]*(double)t[-n + i*w];
+  if (top) for (i = 4; i < n; i++) pred[i] = t[-n*w + i];
+  if (left) for (i = 4; i < n; i++) pred[i*n] = t[-n + i*w];
+  if (g1 > g2) {
+    if (top) for (i = 1; i < 4; i++) pred[i] = t[-n*w + i];
+  }
+  else if (left) for (i = 1; i < 4; i++) pred[i*n] = t[-n + i*w];
+}
+
+/* ------------------------------------------------------------------------ */
+/* Forward path of one plane with KNOWN block sizes: pixel->coeff (A1), frame
+   lapping (A4), then per superblock the recursion of od_compute_dcts
+   (reference src/encode.c:1286-1343): split lapping (A5) down to the coded
+   block size, fDCT (A6), and on keyframes the Haar merge of the four child DCs
+   at every split.  bsize: luma block-size map, 1 byte per 8x8 luma area,
+   values 0..3 (src/state.h:207-224), addressed without border here.
+   c: w x h work plane (ends up lapped), d: w x h coefficient plane. */
+static void compute_dcts_rec(coeff *c, coeff *d, int w, const unsigned char *bsize,
+ int bstride, int bx, int by, int bsi, int dec, int pic_w, int pic_h,
+ int keyframe) {
+  int obs = bsize[((by << bsi) >> 1)*bstride + ((bx << bsi) >> 1)];
+  int bs = obs > dec ? obs : dec;
+  if (bs == bsi) {
+    int n, bo;
+    bs -= dec;
+    n = 4 << bs;
+    bo = (by*n)*w + bx*n;
+    orc_fdct_2d(n, d + bo, w, c + bo, w);
+  }
+  else {
+    int n, bo, hf, vf, ln;
+    coeff x0, x1, x2, x3;
+    bs = bsi - dec;
+    n = 4 << bs;
+    bo = (by*n)*w + bx*n;
+    /* Quirk kept literally: plane-sample extents against the LUMA picture size,
+       and the x-extent test gates the horizontal-centre-line filter
+       (reference src/encode.c:1318-1320). */
+    hf = (bx + 1)*n <= pic_w;
+    vf = (by + 1)*n <= pic_h;
+    orc_prefilter_split(c + bo, w, n, hf, vf);
+    bsi--;
+    bx <<= 1;
+    by <<= 1;
+    compute_dcts_rec(c, d, w, bsize, bstride, bx, by, bsi, dec, pic_w, pic_h, keyframe);
+    compute_dcts_rec(c, d, w, bsize, bstride, bx + 1, by, bsi, dec, pic_w, pic_h, keyframe);
+    compute_dcts_rec(c, d, w, bsize, bstride, bx, by + 1, bsi, dec, pic_w, pic_h, keyframe);
+    compute_dcts_rec(c, d, w, bsize, bstride, bx + 1, by + 1, bsi, dec, pic_w, pic_h, keyframe);
+    if (keyframe) {
+      ln = bsi - dec + 2;
+      x0 = d[(by << ln)*w + (bx << ln)];
+      x1 = d[(by << ln)*w + ((bx + 1) << ln)];
+      x2 = d[((by + 1) << ln)*w + (bx << ln)];
+      x3 = d[((by + 1) << ln)*w + ((bx + 1) << ln)];
+      haar_kernel(&x0, &x2, &x1, &x3);
+      d[(by << ln)*w + (bx << ln)] = x0;
+      d[(by << ln)*w + ((bx + 1) << ln)] = x1;
+      d[((by + 1) << ln)*w + (bx << ln)] = x2;
+      d[((by + 1) << ln)*w + ((bx + 1) << ln)] = x3;
+    }
+  }
+}
+
+void orc_forward_plane(coeff *c, coeff *d, const uint8_t *pix, int pstride,
+ int nhsb, int nvsb, int dec, const unsigned char *bsize, int bstride,
+ int pic_w, int pic_h, int keyframe) {
+  int w = (nhsb*32) >> dec, h = (nvsb*32) >> dec, sbx, sby;
+  orc_ref_buf_to_coeff(c, w, pix, pstride, w, h, 4);
+  orc_prefilter_frame_sbs(c, w, nhsb, nvsb, dec);
+  for (sby = 0; sby < nvsb; sby++)
+    for (sbx = 0; sbx < nhsb; sbx++)
+      compute_dcts_rec(c, d, w, bsize, bstride, sbx, sby, 3, dec, pic_w, pic_h,
+       keyframe);
+}
+
+/* Forward PYRAMID of one plane for block-size RDO: level L (0..3 <-> block size
+   4<<L in this plane... see DESIGN.md) holds the fDCT of every block of that
+   size, computed from the frame-lapped plane plus the split lapping of all its
+   ancestors - exactly the input the reference's RDO recursion hands to
+   od_block_encode at that level (src/encode.c:1554-1592; c is restored from
+   c_orig between the no-split trial and the split).  lev[k] are w x h planes,
+   k = 0 for the superblock-sized transform, k = 1 its four children, ...
+   nlev = 4 for luma (32,16,8,4), 3 for 4:2:0 chroma (16,8,4). */
+static void pyramid_rec(coeff *c, coeff **lev, int w, int x0, int y0, int n,
+ int k, int nlev, int bx, int by, int pic_w, int pic_h) {
+  int bo = y0*w + x0;
+  orc_fdct_2d(n, lev[k] + bo, w, c + bo, w);
+  if (k + 1 < nlev) {
+    int hf = (bx + 1)*n <= pic_w, vf = (by + 1)*n <= pic_h, h = n/2;
+    orc_prefilter_split(c + bo, w, n, hf, vf);
+    pyramid_rec(c, lev, w, x0, y0, h, k + 1, nlev, 2*bx, 2*by, pic_w, pic_h);
+    pyramid_rec(c, lev, w, x0 + h, y0, h, k + 1, nlev, 2*bx + 1, 2*by, pic_w, pic_h);
+    pyramid_rec(c, lev, w, x0, y0 + h, h, k + 1, nlev, 2*bx, 2*by + 1, pic_w, pic_h);
+    pyramid_rec(c, lev, w, x0 + h, y0 + h, h, k + 1, nlev, 2*bx + 1, 2*by + 1, pic_w, pic_h);
+  }
+}
+
+void orc_forward_pyramid_plane(coeff *c, coeff **lev, int nlev,
+ const uint8_t *pix, int pstride, int nhsb, int nvsb, int dec, int pic_w,
+ int pic_h) {
+  int sb = 32 >> dec, w = nhsb*sb, h = nvsb*sb, sbx, sby;
+  orc_ref_buf_to_coeff(c, w, pix, pstride, w, h, 4);
+  orc_prefilter_frame_sbs(c, w, nhsb, nvsb, dec);
+  for (sby = 0; sby < nvsb; sby++)
+    for (sbx = 0; sbx < nhsb; sbx++)
+      pyramid_rec(c, lev, w, sbx*sb, sby*sb, sb, 0, nlev, sbx, sby, pic_w, pic_h);
+}
+
+/* Inverse path of one plane with known block sizes (reference decoder order,
+   src/decode.c:767-868 + :1037 + :1154): per superblock, iDCT (A7) of every
+   coded block into c then the split post-filters on the way back up; after all
+   superblocks the frame post-filter (A4) and the clamp to 8 bit (A2).
+   Does NOT undo the keyframe Haar-of-DCs: that belongs to the DC decoding
+   (od_decode_haar_dc_*), i.e. d must hold final DCT coefficients. */
+static void inverse_rec(coeff *c, const coeff *d, int w, const unsigned char *bsize,
+ int bstride, int bx, int by, int bsi, int dec, int pic_w, int pic_h) {
+  int obs = bsize[((by << bsi) >> 1)*bstride + ((bx << bsi) >> 1)];
+  int bs = obs > dec ? obs : dec;
+  if (bs == bsi) {
+    int n = 4 << (bs - dec), bo = (by*n)*w + bx*n;
+    orc_idct_2d(n, c + bo, w, d + bo, w);
+  }
+  else {
+    int n = 4 << (bsi - dec), bo = (by*n)*w + bx*n;
+    int hf = (bx + 1)*n <= pic_w, vf = (by + 1)*n <= pic_h;
+    inverse_rec(c, d, w, bsize, bstride, 2*bx, 2*by, bsi - 1, dec, pic_w, pic_h);
+    inverse_rec(c, d, w, bsize, bstride, 2*bx + 1, 2*by, bsi - 1, dec, pic_w, pic_h);
+    inverse_rec(c, d, w, bsize, bstride, 2*bx, 2*by + 1, bsi - 1, dec, pic_w, pic_h);
+    inverse_rec(c, d, w, bsize, bstride, 2*bx + 1, 2*by + 1, bsi - 1, dec, pic_w, pic_h);
+    orc_postfilter_split(c + bo, w, n, hf, vf);
+  }
+}
+
+void orc_inverse_plane(uint8_t *pix, int pstride, coeff *c, const coeff *d,
+ int nhsb, int nvsb, int dec, const unsigned char *bsize, int bstride,
+ int pic_w, int pic_h) {
+  int w = (nhsb*32) >> dec, h = (nvsb*32) >> dec, sbx, sby;
+  for (sby = 0; sby < nvsb; sby++)
+    for (sbx = 0; sbx < nhsb; sbx++)
+      inverse_rec(c, d, w, bsize, bstride, sbx, sby, 3, dec, pic_w, pic_h);
+  orc_postfilter_frame_sbs(c, w, nhsb, nvsb, dec);
+  orc_coeff_to_ref_buf(pix, pstride, c, w, w, h, 4);
+}
+
+/* ------------------------------------------------------------------------ */
+/* PVQ math (all double, sequential evaluation order kept). */
+#define QM_SCALE_1 (1./32767)          /* OD_QM_SCALE_1, reference src/pvq.h:57-59 */
+#define QM_INV_SCALE_1 (1./4096)       /* OD_QM_INV_SCALE_1 */
+#define COMPAND_SCALE 4096.            /* OD_COMPAND_SCALE = 256 << 4, src/pvq.h:68 */
+#define PVQ_LAMBDA .147                /* OD_PVQ_LAMBDA, src/pvq.h:49 */
+
+/* A13: reference src/pvq.c:422-425 and :456-468. */
+double orc_gain_compand(double g, int q0, double beta) {
+  if (beta == 1) return g/q0;
+  return COMPAND_SCALE*pow(g*(1./COMPAND_SCALE), 1./beta)/q0;
+}
+
+double orc_pvq_compute_gain(const coeff *x, int n, int q0, double *g, double beta,
+ const int16_t *qm) {
+  double acc = 0;
+  int i;
+  for (i = 0; i < n; i++)
+    acc += x[i]*(double)x[i]*qm[i]*QM_SCALE_1*qm[i]*QM_SCALE_1;
+  *g = sqrt(acc);
+  return orc_gain_compand(*g, q0, beta);
+}
+
+/* A17 helper: reference src/pvq.c:434-443. */
+double orc_gain_expand(double cg, int q0, double beta) {
+  if (beta == 1) return cg*q0;
+  if (beta == 1.5) {
+    cg *= q0*(1./COMPAND_SCALE);
+    return COMPAND_SCALE*cg*sqrt(cg);
+  }
+  return COMPAND_SCALE*pow(cg*q0*(1./COMPAND_SCALE), beta);
+}
+
+/* A18: reference src/pvq.c:476-535. */
+int orc_pvq_compute_max_theta(double qcg, double beta) {
+  int ts = (int)floor(.5 + qcg*M_PI/(2*beta));
+  if (qcg < 1.4) ts = 1;
+  return ts;
+}
+
+double orc_pvq_compute_theta(int t, int max_theta) {
+  if (max_theta != 0) return (t < max_theta - 1 ? t : max_theta - 1)*.5*M_PI/max_theta;
+  return 0;
+}
+
+int orc_pvq_compute_k(double qcg, int itheta, double theta, int noref, int n,
+ double beta, int nodesync) {
+  int k;
+  if (noref) {
+    if (qcg == 0) return 0;
+    if (n == 15 && qcg == 1 && beta > 1.25) return 1;
+    k = (int)floor(.5 + (qcg - .2)*sqrt((n + 3)/2)/beta);   /* integer (n+3)/2 */
+    return k > 1 ? k : 1;
+  }
+  if (itheta == 0) return 0;
+  if (nodesync) k = (int)floor(.5 + (itheta - .2)*sqrt((n + 2)/2));
+  else k = (int)floor(.5 + (qcg*sin(theta) - .2)*sqrt((n + 2)/2)/beta);
+  return k > 1 ? k : 1;
+}
+
+/* A14: reference src/pvq.c:364-413. */
+int orc_compute_householder(double *r, int n, double gr, int *sign) {
+  int m = 0, i, s;
+  double maxr = 0;
+  for (i = 0; i < n; i++)
+    if (fabs(r[i]) > maxr) { maxr = fabs(r[i]); m = i; }
+  s = r[m] > 0 ? 1 : -1;
+  r[m] += gr*s;
+  *sign = s;
+  return m;
+}
+
+void orc_apply_householder(double *x, const double *r, int n) {
+  double l2r = 0, proj = 0, proj_1;
+  int i;
+  for (i = 0; i < n; i++) l2r += r[i]*r[i];
+  for (i = 0; i < n; i++) proj += r[i]*x[i];
+  proj_1 = proj*2./(1e-100 + l2r);
+  for (i = 0; i < n; i++) x[i] -= r[i]*proj_1;
+}
+
+/* A15: PVQ codeword search (reference src/pvq_encoder.c:83-225).  The first 16
+   reciprocal square roots are the reference's 6-digit literals (:84-88). */
+static double rsqrt_small(int i) {
+  static const double t[16] = {
+    1.000000, 0.707107, 0.577350, 0.500000, 0.447214, 0.408248, 0.377964,
+    0.353553, 0.333333, 0.316228, 0.301511, 0.288675, 0.277350, 0.267261,
+    0.258199, 0.250000};
+  return i <= 16 ? t[i - 1] : 1./sqrt(i);
+}
+
+double orc_pvq_search_rdo_double(const double *xcoeff, int n, int k, coeff *yp,
+ double g2) {
+  double x[1024], xx = 0, xy = 0, yy = 0, norm_1, lambda, delta_rate;
+  int i = 0, j, rdo_pulses;
+  for (j = 0; j < n; j++) {
+    x[j] = fabs(xcoeff[j]);
+    xx += x[j]*x[j];
+  }
+  norm_1 = 1./sqrt(1e-30 + xx);
+  lambda = PVQ_LAMBDA/(1e-30 + g2);
+  if (k > 2) {
+    double l1 = 0, l1_inv;
+    for (j = 0; j < n; j++) l1 += x[j];
+    l1_inv = 1./(l1 > 1e-100 ? l1 : 1e-100);
+    for (j = 0; j < n; j++) {
+      int p = (int)floor(k*x[j]*l1_inv);
+      yp[j] = p > 0 ? p : 0;
+      xy += x[j]*yp[j];
+      yy += yp[j]*yp[j];
+      i += yp[j];
+    }
+  }
+  else for (j = 0; j < n; j++) yp[j] = 0;
+  rdo_pulses = 1 + k/4;
+  delta_rate = 3./n;
+  for (; i < k - rdo_pulses; i++) {
+    int pos = 0;
+    double best_xy = -10, best_yy = 1;
+    for (j = 0; j < n; j++) {
+      double txy = xy + x[j], tyy = yy + 2*yp[j] + 1;
+      txy *= txy;
+      if (j == 0 || txy*best_yy > best_xy*tyy) {
+        best_xy = txy;
+        best_yy = tyy;
+        pos = j;
+      }
+    }
+    xy = xy + x[pos];
+    yy = yy + 2*yp[pos] + 1;
+    yp[pos]++;
+  }
+  for (; i < k; i++) {
+    int pos = 0;
+    double best_cost = -1e5;
+    for (j = 0; j < n; j++) {
+      double txy = xy + x[j];
+      double rs = rsqrt_small((int)(yy + 2*yp[j] + 1));
+      txy = 2*txy*norm_1*rs - lambda*j*delta_rate;
+      if (j == 0 || txy > best_cost) {
+        best_cost = txy;
+        pos = j;
+      }
+    }
+    xy = xy + x[pos];
+    yy = yy + 2*yp[pos] + 1;
+    yp[pos]++;
+  }
+  for (j = 0; j < n; j++) if (xcoeff[j] < 0) yp[j] = -yp[j];
+  return xy/(1e-100 + sqrt(xx*yy));
+}
+
+/* A17: reference src/pvq.c:552-585. */
+void orc_pvq_synthesis_partial(coeff *xcoeff, const coeff *yp, const double *r,
+ int n, int noref, double g, double theta, int m, int s, const int16_t *qm_inv) {
+  int i, yy = 0, nn = n - (!noref);
+  double scale;
+  for (i = 0; i < nn; i++) yy += yp[i]*(int32_t)yp[i];
+  scale = yy == 0 ? 0 : g/sqrt(yy);
+  if (noref) {
+    for (i = 0; i < n; i++)
+      xcoeff[i] = (coeff)floor(.5 + (yp[i]*scale)*(qm_inv[i]*QM_INV_SCALE_1));
+  }
+  else {
+    double x[1024];
+    scale *= sin(theta);
+    for (i = 0; i < m; i++) x[i] = yp[i]*scale;
+    x[m] = -s*g*cos(theta);
+    for (i = m; i < nn; i++) x[i + 1] = yp[i]*scale;
+    orc_apply_householder(x, r, n);
+    for (i = 0; i < n; i++)
+      xcoeff[i] = (coeff)floor(.5 + (x[i]*(qm_inv[i]*QM_INV_SCALE_1)));
+  }
+}
+
+/* A16 (state-free part): the no-reference candidate loop of pvq_theta
+   (reference src/pvq_encoder.c:452-481) WITHOUT the rate term: for every gain
+   candidate i in [max(1,floor(cg)), ceil(cg)] the pulse count, codeword, cosine
+   distance and distortion.  The host adds lambda*od_pvq_rate() (adaptive
+   entropy state) and takes the argmin.  At most 2 candidates exist.
+   Returns the candidate count; y is [2][n]. */
+int orc_pvq_noref_candidates(const coeff *x0, int n, int q0, double beta,
+ const int16_t *qm, int nodesync, double *cg_out, double *g_out, int *qg, int *k,
+ double *cos_dist, double *dist, coeff *y) {
+  double x1[1024], g, cg;
+  int i, nc = 0;
+  cg = orc_pvq_compute_gain(x0, n, q0, &g, beta, qm);
+  *cg_out = cg;
+  *g_out = g;
+  for (i = 0; i < n; i++) x1[i] = x0[i]*qm[i]*QM_SCALE_1;   /* int*int first */
+  i = (int)floor(cg);
+  if (i < 1) i = 1;
+  for (; i <= ceil(cg) && nc < 2; i++, nc++) {
+    double qcg = i;
+    k[nc] = orc_pvq_compute_k(qcg, -1, -1, 1, n, beta, nodesync);
+    cos_dist[nc] = orc_pvq_search_rdo_double(x1, n, k[nc], y + nc*n, qcg*cg);
+    dist[nc] = 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist[nc]);
+    qg[nc] = i;
+  }
+  return nc;
+}
