@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Daala transform + PVQ hot path.
+
+One "step" = one pass of the device hot path over one batch of synthetic input
+already resident in HBM: BASELINE.json configs[1], 30 intra frames of 1920x1080
+4:2:0 (padded to 1920x1088) per GPU:
+
+  1. forward pyramid of all planes (A1 u8->coeff, A4 frame lapping, A5 split
+     lapping, A6 fDCT of every block of every size)       [block-size RDO input]
+  2. no-reference PVQ candidates (A13 gain, A18 K, A15 codeword search, distortion)
+     for every band of every block of every pyramid level of every plane
+  3. forward with known block sizes (od_compute_dcts) of all planes
+  4. inverse (A7 iDCT, split + frame post-filters, A2 clamp) of all planes
+
+The serial entropy coder / RDO argmin stay on the host and are NOT part of the
+step (out of scope); `value` is therefore hot-path Mpixels/s,
+not bitstream Mpixels/s.  Launch: python bench.py --gpus N --steps K --warmup W
+(N > 1 under torch.distributed.run, one rank per GPU, independent frames per rank,
+no data-path collective: "weak" scaling).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+PIC_W, PIC_H, FW, FH = 1920, 1080, 1920, 1088
+FRAMES = 30
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+BAND_OFF = {0: [1, 16], 1: [1, 16, 24, 32, 64], 2: [1, 16, 24, 32, 64, 96, 128, 256],
+            3: [1, 16, 24, 32, 64, 96, 128, 256, 384, 512]}
+
+
+def level_params(prm, tag, pli, bs, xdec):
+    q0 = int(prm['quantizer_' + tag][pli])
+    pq = prm['pvq_qm_q4_' + tag][pli]
+    off = BAND_OFF[bs]
+    nb = len(off) - 1
+    q = [max(1, q0*int(pq[bs*(bs + 1) + (b + 1) - (b + 1)//3]) >> 4) for b in range(nb)]
+    masking = tag.endswith('m1')
+    beta = [1.5 if (masking and pli == 0 and bs > 0) else 1.0]*nb
+    n = 4 << bs
+    base = bs*2048 + xdec*1024
+    return q, beta, np.ascontiguousarray(prm['qm_' + tag][base:base + n*n])
+
+
+def make_frames(count, seed0):
+    from testlib import synth_plane
+    base = [synth_plane(FW, FH, seed0), synth_plane(FW//2, FH//2, seed0, 1),
+            synth_plane(FW//2, FH//2, seed0 + 1, 1)]
+    frames = []
+    for f in range(count):
+        frames.append([np.ascontiguousarray(np.roll(p, (3*f, 5*f), axis=(0, 1))) for p in base])
+    return frames
+
+
+def cpu_port_baseline(frames, bmaps, prm, tag, nframes):
+    """Oracle (our C restatement) doing the same per-frame work as one device step,
+    single thread.  Checker code used as a reported baseline only."""
+    from testlib import oracle
+    o = oracle()
+    o.orc_bench_frame.restype = ctypes.c_long
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    qm = np.ascontiguousarray(prm['qm_' + tag])
+    q0 = (ctypes.c_int*3)(*[int(v) for v in prm['quantizer_' + tag]])
+    pq = np.ascontiguousarray(prm['pvq_qm_q4_' + tag]).ravel()
+    t0 = time.perf_counter()
+    for f in range(nframes):
+        planes = (U8P*3)(*[p.ctypes.data_as(U8P) for p in frames[f]])
+        o.orc_bench_frame(planes, FW, FH, PIC_W, PIC_H, bmaps[f].ctypes.data_as(U8P),
+                          qm.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), q0,
+                          pq.ctypes.data_as(U8P), 1 if tag.endswith('m1') else 0)
+    dt = time.perf_counter() - t0
+    return nframes*PIC_W*PIC_H/dt/1e6, dt
+
+
+def cpu_reference_encoder(frames, nframes):
+    """The real reference encoder (oracle/_ref, built from /root/reference in the
+    dev container; the .so travels to the GPU box) on the same content, -v 20,
+    complexity 7, masking on: whole bitstream encode, 1 thread."""
+    so = os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so')
+    if not os.path.exists(so):
+        return None
+    lib = ctypes.CDLL(so)
+    lib.probe_encode_frames.restype = ctypes.c_long
+    buf = np.concatenate([np.concatenate([frames[f][0][:PIC_H, :PIC_W].ravel(),
+                                          frames[f][1][:PIC_H//2, :PIC_W//2].ravel(),
+                                          frames[f][2][:PIC_H//2, :PIC_W//2].ravel()])
+                          for f in range(nframes)])
+    fnv = ctypes.c_uint()
+    sec = ctypes.c_double()
+    nbytes = lib.probe_encode_frames(PIC_W, PIC_H, nframes, 20, 7, 1, 1,
+                                     buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                     ctypes.byref(fnv), ctypes.byref(sec), None, 0)
+    if nbytes <= 0:
+        return None
+    return {'value': round(nframes*PIC_W*PIC_H/sec.value/1e6, 4), 'unit': 'Mpixels/s',
+            'cores': 1, 'frames': nframes, 'packet_bytes': int(nbytes),
+            'what': 'full reference encoder incl. entropy coding + RDO (oracle/_ref)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    import daala_amd.binding as b
+    from testlib import random_bsize_map
+    lib = b.load()                     # no fallback: raises if the HIP library is missing
+    if lib.od_hip_device_count() <= local_rank:
+        raise SystemExit('HIP device %d not available' % local_rank)
+
+    prm = np.load(os.path.join(ROOT, 'tests', 'golden', 'encoder_params.npz'))
+    tag = 'q20_m1'
+    frames = make_frames(FRAMES, seed0=1 + rank)
+    bmaps = [random_bsize_map(FW//32, FH//32, 1000*rank + f) for f in range(FRAMES)]
+    ctx = b.DaalaHip(PIC_W, PIC_H, FW, FH, nplanes=3, xdec=(0, 1, 1), nslots=FRAMES,
+                     device=local_rank)
+    for f in range(FRAMES):
+        ctx.upload_planes(f, frames[f])
+        ctx.set_bsize(f, bmaps[f])
+    lvl = []
+    for pli in range(3):
+        for level in range(ctx.nlevels(pli)):
+            n = (32 >> ctx.xdec[pli]) >> level
+            bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+            lvl.append((pli, level) + level_params(prm, tag, pli, bs, ctx.xdec[pli]))
+
+    def step():
+        ctx.forward_pyramid(0, FRAMES)
+        for pli, level, q, beta, qm in lvl:
+            ctx.pvq_noref_search(pli, level, qm, q, beta, 0, FRAMES)
+        ctx.forward_known(0, FRAMES, keyframe=1)
+        ctx.inverse(0, FRAMES)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    ctx.timing_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time (HIP events on the context's own stream)
+    s_y, s_c = FW*FH, (FW//2)*(FH//2)
+    alg_bytes = {        # ALGORITHMIC bytes per launch (SURVEY.md 8d x units per launch)
+        'k_forward_pyramid_luma': FRAMES*s_y*17,
+        'k_forward_pyramid_chroma': FRAMES*s_c*13,
+        'k_forward_known_luma': FRAMES*s_y*5,
+        'k_forward_known_chroma': FRAMES*s_c*5,
+        'k_inverse_sb_luma': FRAMES*s_y*5,          # inverse+postfilter+clamp is 5 B/sample
+        'k_inverse_sb_chroma': FRAMES*s_c*5,        #   in total; split over two kernels here
+        'k_postfilter_clamp_luma': FRAMES*s_y*5,
+        'k_postfilter_clamp_chroma': FRAMES*s_c*5,
+    }
+    kernels = {}
+    for name in list(alg_bytes) + ['k_pvq_noref_level']:
+        n, ms = ctx.timing_get(name)
+        if n:
+            kernels[name] = {'launches': n, 'avg_ms': ms/n}
+            if name in alg_bytes:
+                kernels[name]['GBps'] = alg_bytes[name]/(ms/n*1e-3)/1e9
+    if rank == 0:
+        px = world*FRAMES*PIC_W*PIC_H*args.steps
+        value = px/elapsed/1e6
+        # dominant HBM-bound (transform) kernel by device time
+        hb = {k: v for k, v in kernels.items() if k in alg_bytes}
+        dom = max(hb, key=lambda k: hb[k]['avg_ms']*hb[k]['launches'])
+        ach = hb[dom]['GBps']
+        line = {
+            'metric': 'encode Mpixels/s (intra hot path: lapping+DCT pyramid, PVQ no-ref '
+                      'search, known-size forward, inverse; bit-exact vs oracle)',
+            'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed/args.steps*1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int32+f64', 'data': 'synthetic',
+            'config': {'workload': '1920x1080 4:2:0 synthetic, 30 intra frames per GPU '
+                                   '(BASELINE configs[1]), q=20, activity masking on, '
+                                   'random valid block-size maps',
+                       'frames_per_gpu': FRAMES, 'parallelism': 'independent frames per GPU'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 2),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 5),
+                         'traffic': None},
+            'kernels': {k: {kk: round(vv, 4) if isinstance(vv, float) else vv
+                            for kk, vv in v.items()} for k, v in kernels.items()},
+        }
+        if 'k_pvq_noref_level' in kernels:
+            # band vectors searched per second (each band = up to 2 gain candidates)
+            nb = {0: 1, 1: 4, 2: 7, 3: 9}
+            bands = 0
+            for pli, level, q, beta, qm in lvl:
+                n = (32 >> ctx.xdec[pli]) >> level
+                bands += ctx.pvq_nblocks(pli, level)*nb[{4: 0, 8: 1, 16: 2, 32: 3}[n]]
+            tot_ms = kernels['k_pvq_noref_level']['avg_ms']*kernels['k_pvq_noref_level']['launches']
+            line['pvq'] = {'bands_per_s': round(bands*FRAMES*args.steps/(tot_ms*1e-3), 1),
+                           'bands_per_frame': bands,
+                           'share_of_device_time': round(
+                               tot_ms/sum(v['avg_ms']*v['launches'] for v in kernels.values()), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            nf = 3
+            v, dt = cpu_port_baseline(frames, bmaps, prm, tag, nf)
+            line['cpu_baseline'] = {'value': round(v, 4), 'unit': 'Mpixels/s', 'cores': 1,
+                                    'kind': 'port',
+                                    'sample': '%d of the 30 1080p frames, same per-frame work as '
+                                              'the device step, oracle C code, %.1f s' % (nf, dt)}
+            refenc = cpu_reference_encoder(frames, 3)
+            if refenc:
+                line['cpu_reference_encoder'] = refenc
+        print(json.dumps(line))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,307 @@
+"""ctypes binding of include/daala_hip.h.
+
+Names follow the reference's (od_bin_fdct8x8, od_pre_filter4,
+od_resample_luma_coeffs, ...) so that parity tests read like the reference's own
+tests.  Every call goes to the HIP library; if it is missing or no device is
+usable the call raises - nothing here computes on the CPU."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+I32P = ctypes.POINTER(ctypes.c_int32)
+I16P = ctypes.POINTER(ctypes.c_int16)
+U8P = ctypes.POINTER(ctypes.c_uint8)
+F64P = ctypes.POINTER(ctypes.c_double)
+c_int = ctypes.c_int
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class Geometry(ctypes.Structure):
+    _fields_ = [('pic_width', c_int), ('pic_height', c_int), ('frame_width', c_int),
+                ('frame_height', c_int), ('nplanes', c_int), ('xdec', c_int*4),
+                ('nslots', c_int)]
+
+
+class PvqBand(ctypes.Structure):
+    _fields_ = [('cg', ctypes.c_double), ('g', ctypes.c_double),
+                ('cos_dist', ctypes.c_double*2), ('dist', ctypes.c_double*2),
+                ('qg', ctypes.c_int32*2), ('k', ctypes.c_int32*2),
+                ('ncand', ctypes.c_int32), ('pad', ctypes.c_int32)]
+
+
+PVQ_BAND_DTYPE = np.dtype([('cg', 'f8'), ('g', 'f8'), ('cos_dist', 'f8', 2), ('dist', 'f8', 2),
+                           ('qg', 'i4', 2), ('k', 'i4', 2), ('ncand', 'i4'), ('pad', 'i4')])
+
+
+def lib_path():
+    return os.path.join(_HERE, 'libdaala_hip.so')
+
+
+_lib = None
+
+
+def load():
+    """Load libdaala_hip.so; raises HipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HipError('%s not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                       'or `make -C daala_amd/csrc` (there is no CPU fallback)' % path)
+    lib = ctypes.CDLL(path)
+    lib.od_hip_last_error.restype = ctypes.c_char_p
+    lib.od_hip_version.restype = ctypes.c_char_p
+    lib.od_hip_ctx_create.restype = ctypes.c_void_p
+    lib.od_hip_ctx_create.argtypes = [c_int, ctypes.POINTER(Geometry)]
+    lib.od_hip_ctx_destroy.argtypes = [ctypes.c_void_p]
+    for name in ('od_hip_bin_fdct4x4', 'od_hip_bin_fdct8x8', 'od_hip_bin_fdct16x16',
+                 'od_hip_bin_fdct32x32', 'od_hip_bin_idct4x4', 'od_hip_bin_idct8x8',
+                 'od_hip_bin_idct16x16', 'od_hip_bin_idct32x32'):
+        f = getattr(lib, name)
+        f.restype = None
+        f.argtypes = [I32P, c_int, I32P, c_int]
+    lib.od_hip_fdct_blocks.argtypes = [c_int, I32P, I32P, c_int]
+    lib.od_hip_idct_blocks.argtypes = [c_int, I32P, I32P, c_int]
+    lib.od_hip_haar_blocks.argtypes = [c_int, c_int, I32P, I32P, c_int]
+    lib.od_hip_filter4_vectors.argtypes = [c_int, I32P, I32P, c_int]
+    lib.od_hip_resample_luma_420.argtypes = [I32P, I32P, ctypes.c_size_t, c_int, I32P, c_int,
+                                             c_int, c_int]
+    vp = ctypes.c_void_p
+    lib.od_hip_upload_planes.argtypes = [vp, c_int, ctypes.POINTER(U8P), ctypes.POINTER(c_int)]
+    lib.od_hip_forward_pyramid.argtypes = [vp, c_int, c_int]
+    lib.od_hip_set_bsize.argtypes = [vp, c_int, U8P, c_int]
+    lib.od_hip_forward_known.argtypes = [vp, c_int, c_int, c_int]
+    lib.od_hip_inverse.argtypes = [vp, c_int, c_int]
+    lib.od_hip_download_level.argtypes = [vp, c_int, c_int, c_int, I32P]
+    lib.od_hip_download_coeffs.argtypes = [vp, c_int, c_int, I32P]
+    lib.od_hip_upload_coeffs.argtypes = [vp, c_int, c_int, I32P]
+    lib.od_hip_download_recon.argtypes = [vp, c_int, c_int, U8P]
+    lib.od_hip_band_offsets.argtypes = [c_int, ctypes.POINTER(c_int)]
+    lib.od_hip_pvq_noref_search.argtypes = [vp, c_int, c_int, c_int, c_int, I16P, I32P, F64P]
+    lib.od_hip_pvq_nblocks.argtypes = [vp, c_int, c_int]
+    lib.od_hip_pvq_download.argtypes = [vp, c_int, c_int, c_int, ctypes.c_void_p, I32P]
+    lib.od_hip_pvq_search_vectors.argtypes = [c_int, c_int, F64P, I32P, F64P, I32P, F64P]
+    lib.od_hip_pvq_synthesis_noref.argtypes = [c_int, c_int, I32P, F64P, I16P, I32P]
+    lib.od_hip_sync.argtypes = [vp]
+    lib.od_hip_timing_reset.argtypes = [vp]
+    lib.od_hip_timing_get.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(c_int), F64P]
+    _lib = lib
+    return lib
+
+
+def _p32(a):
+    return a.ctypes.data_as(I32P)
+
+
+def _chk(rc):
+    if rc < 0:
+        raise HipError('daala_hip error %d: %s' % (rc, load().od_hip_last_error().decode()))
+    return rc
+
+
+def _c32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# -- section 1/2 of the header: stand-alone pieces --------------------------------
+def od_bin_fdct_blocks(bs, blocks):
+    """blocks: [nblocks, n, n] int32 -> forward transform of each (od_bin_fdctNxN)."""
+    x = _c32(blocks)
+    y = np.empty_like(x)
+    _chk(load().od_hip_fdct_blocks(bs, _p32(y), _p32(x), x.shape[0]))
+    return y
+
+
+def od_bin_idct_blocks(bs, blocks):
+    y = _c32(blocks)
+    x = np.empty_like(y)
+    _chk(load().od_hip_idct_blocks(bs, _p32(x), _p32(y), y.shape[0]))
+    return x
+
+
+def od_haar_blocks(bs, blocks, inverse=False):
+    x = _c32(blocks)
+    y = np.empty_like(x)
+    _chk(load().od_hip_haar_blocks(bs, int(inverse), _p32(y), _p32(x), x.shape[0]))
+    return y
+
+
+def od_pre_filter4(vectors):
+    x = _c32(vectors)
+    y = np.empty_like(x)
+    _chk(load().od_hip_filter4_vectors(0, _p32(y), _p32(x), x.shape[0]))
+    return y
+
+
+def od_post_filter4(vectors):
+    x = _c32(vectors)
+    y = np.empty_like(x)
+    _chk(load().od_hip_filter4_vectors(1, _p32(y), _p32(x), x.shape[0]))
+    return y
+
+
+def od_resample_luma_coeffs_420(luma, lstride, offsets, bs, chroma_bs):
+    luma = _c32(luma).ravel()
+    off = np.ascontiguousarray(offsets, dtype=np.int32)
+    n = 4 << bs
+    pred = np.empty((len(off), n, n), np.int32)
+    _chk(load().od_hip_resample_luma_420(_p32(pred), _p32(luma), luma.size, lstride, _p32(off),
+                                         len(off), bs, chroma_bs))
+    return pred
+
+
+def vtable_call(name, out, ostride, inp, istride):
+    """Call one of the od_dct_func_2d drop-ins on (possibly aliasing) host arrays."""
+    getattr(load(), name)(_p32(out), ostride, _p32(inp), istride)
+
+
+def pvq_search_vectors(x, k, g2):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    nvec, n = x.shape
+    k = np.ascontiguousarray(k, dtype=np.int32)
+    g2 = np.ascontiguousarray(g2, dtype=np.float64)
+    y = np.empty((nvec, n), np.int32)
+    cd = np.empty(nvec, np.float64)
+    _chk(load().od_hip_pvq_search_vectors(n, nvec, x.ctypes.data_as(F64P), _p32(k),
+                                          g2.ctypes.data_as(F64P), _p32(y),
+                                          cd.ctypes.data_as(F64P)))
+    return y, cd
+
+
+def pvq_synthesis_noref(y, g, qm_inv):
+    y = _c32(y)
+    nvec, n = y.shape
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    qm_inv = np.ascontiguousarray(qm_inv, dtype=np.int16)
+    out = np.empty_like(y)
+    _chk(load().od_hip_pvq_synthesis_noref(n, nvec, _p32(y), g.ctypes.data_as(F64P),
+                                           qm_inv.ctypes.data_as(I16P), _p32(out)))
+    return out
+
+
+def band_offsets(bs):
+    off = (c_int*11)()
+    nb = _chk(load().od_hip_band_offsets(bs, off))
+    return [off[i] for i in range(nb + 1)]
+
+
+# -- section 3/4: device-resident frame pipeline ------------------------------------
+class DaalaHip(object):
+    """One od_hip_ctx: the HBM-resident buffers of `nslots` frames."""
+
+    def __init__(self, pic_width, pic_height, frame_width=None, frame_height=None, nplanes=3,
+                 xdec=(0, 1, 1), nslots=1, device=0):
+        self.lib = load()
+        fw = frame_width or (pic_width + 31)//32*32
+        fh = frame_height or (pic_height + 31)//32*32
+        g = Geometry()
+        g.pic_width, g.pic_height, g.frame_width, g.frame_height = pic_width, pic_height, fw, fh
+        g.nplanes, g.nslots = nplanes, nslots
+        for i in range(nplanes):
+            g.xdec[i] = xdec[i]
+        self.geo = g
+        self.nplanes = nplanes
+        self.xdec = tuple(xdec[:nplanes])
+        self.fw, self.fh, self.nslots = fw, fh, nslots
+        self.ctx = self.lib.od_hip_ctx_create(device, ctypes.byref(g))
+        if not self.ctx:
+            raise HipError('od_hip_ctx_create failed: %s' % self.lib.od_hip_last_error().decode())
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.od_hip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def plane_shape(self, pli):
+        return (self.fh >> self.xdec[pli], self.fw >> self.xdec[pli])
+
+    def nlevels(self, pli):
+        return 4 - self.xdec[pli]
+
+    def upload_planes(self, slot, planes):
+        planes = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+        for pli, p in enumerate(planes):
+            assert p.shape == self.plane_shape(pli), (p.shape, self.plane_shape(pli))
+        ptrs = (U8P*len(planes))(*[p.ctypes.data_as(U8P) for p in planes])
+        strides = (c_int*len(planes))(*[p.shape[1] for p in planes])
+        _chk(self.lib.od_hip_upload_planes(self.ctx, slot, ptrs, strides))
+
+    def set_bsize(self, slot, bsize):
+        b = np.ascontiguousarray(bsize, dtype=np.uint8)
+        assert b.shape == (self.fh//8, self.fw//8)
+        _chk(self.lib.od_hip_set_bsize(self.ctx, slot, b.ctypes.data_as(U8P), b.shape[1]))
+
+    def forward_pyramid(self, slot0=0, nslots=None):
+        _chk(self.lib.od_hip_forward_pyramid(self.ctx, slot0, nslots or self.nslots - slot0))
+
+    def forward_known(self, slot0=0, nslots=None, keyframe=1):
+        _chk(self.lib.od_hip_forward_known(self.ctx, slot0, nslots or self.nslots - slot0,
+                                           keyframe))
+
+    def inverse(self, slot0=0, nslots=None):
+        _chk(self.lib.od_hip_inverse(self.ctx, slot0, nslots or self.nslots - slot0))
+
+    def download_level(self, slot, pli, level):
+        out = np.empty(self.plane_shape(pli), np.int32)
+        _chk(self.lib.od_hip_download_level(self.ctx, slot, pli, level, _p32(out)))
+        return out
+
+    def download_coeffs(self, slot, pli):
+        out = np.empty(self.plane_shape(pli), np.int32)
+        _chk(self.lib.od_hip_download_coeffs(self.ctx, slot, pli, _p32(out)))
+        return out
+
+    def upload_coeffs(self, slot, pli, d):
+        d = _c32(d)
+        assert d.shape == self.plane_shape(pli)
+        _chk(self.lib.od_hip_upload_coeffs(self.ctx, slot, pli, _p32(d)))
+
+    def download_recon(self, slot, pli):
+        out = np.empty(self.plane_shape(pli), np.uint8)
+        _chk(self.lib.od_hip_download_recon(self.ctx, slot, pli, out.ctypes.data_as(U8P)))
+        return out
+
+    def pvq_noref_search(self, pli, level, qm, q, beta, slot0=0, nslots=None):
+        qm = np.ascontiguousarray(qm, dtype=np.int16)
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        _chk(self.lib.od_hip_pvq_noref_search(self.ctx, slot0, nslots or self.nslots - slot0,
+                                              pli, level, qm.ctypes.data_as(I16P), _p32(q),
+                                              beta.ctypes.data_as(F64P)))
+
+    def pvq_nblocks(self, pli, level):
+        return _chk(self.lib.od_hip_pvq_nblocks(self.ctx, pli, level))
+
+    def pvq_download(self, slot, pli, level):
+        nblk = self.pvq_nblocks(pli, level)
+        n = (32 >> self.xdec[pli]) >> level
+        bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+        nb = len(band_offsets(bs)) - 1
+        ncoded = min(n*n, 512)
+        bands = np.zeros((nblk, nb), PVQ_BAND_DTYPE)
+        y = np.zeros((nblk, 2, ncoded), np.int32)
+        _chk(self.lib.od_hip_pvq_download(self.ctx, slot, pli, level,
+                                          bands.ctypes.data_as(ctypes.c_void_p), _p32(y)))
+        return bands, y
+
+    def sync(self):
+        _chk(self.lib.od_hip_sync(self.ctx))
+
+    def timing_reset(self):
+        _chk(self.lib.od_hip_timing_reset(self.ctx))
+
+    def timing_get(self, kernel):
+        n = c_int()
+        ms = ctypes.c_double()
+        _chk(self.lib.od_hip_timing_get(self.ctx, kernel.encode(), ctypes.byref(n),
+                                        ctypes.byref(ms)))
+        return n.value, ms.value

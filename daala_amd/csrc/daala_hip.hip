@@ -1,0 +1,746 @@
+// C-ABI implementation of include/daala_hip.h (gfx950 only).
+// Host-side plumbing: device buffers, launches, timing events.  No CPU fallback:
+// every compute entry point fails with OD_HIP_ENODEV when HIP is unusable.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/daala_hip.h"
+#include "coding_order_tables.h"
+#include "pvq_kernels.hpp"
+#include "xform_kernels.hpp"
+
+static_assert(sizeof(PvqBandRec) == sizeof(od_hip_pvq_band), "record layout");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess) {
+  g_err = what;
+  if (e != hipSuccess) {
+    g_err += ": ";
+    g_err += hipGetErrorString(e);
+  }
+  return code;
+}
+
+#define HIPCHK(expr)                                         \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return fail(OD_HIP_ENODEV, #expr, e_); \
+  } while (0)
+
+int ensure_device() {
+  static int state = 0;     // 0 unknown, 1 ok, -1 none
+  if (state == 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    state = (e == hipSuccess && n > 0) ? 1 : -1;
+  }
+  if (state < 0) return fail(OD_HIP_ENODEV, "no HIP device available");
+  return 0;
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    HIPCHK(hipMalloc(&p, bytes));
+    cap = bytes;
+    return 0;
+  }
+};
+
+// Scratch for the host-pointer entry points (sections 1, 2 of the header).
+DevBuf g_in, g_out, g_aux0, g_aux1, g_aux2;
+
+template <int N, bool INV>
+int launch_dct_blocks(int32_t *out, const int32_t *in, int nblocks, hipStream_t s) {
+  constexpr int BPW = 256/N;
+  int grid = (nblocks + BPW - 1)/BPW;
+  hipLaunchKernelGGL((k_dct_blocks<N, INV>), dim3(grid), dim3(256), 0, s, out, in, nblocks);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int dct_blocks_dev(int bs, bool inv, int32_t *out, const int32_t *in, int nblocks,
+                   hipStream_t s) {
+  switch (bs*2 + (inv ? 1 : 0)) {
+    case 0: return launch_dct_blocks<4, false>(out, in, nblocks, s);
+    case 1: return launch_dct_blocks<4, true>(out, in, nblocks, s);
+    case 2: return launch_dct_blocks<8, false>(out, in, nblocks, s);
+    case 3: return launch_dct_blocks<8, true>(out, in, nblocks, s);
+    case 4: return launch_dct_blocks<16, false>(out, in, nblocks, s);
+    case 5: return launch_dct_blocks<16, true>(out, in, nblocks, s);
+    case 6: return launch_dct_blocks<32, false>(out, in, nblocks, s);
+    case 7: return launch_dct_blocks<32, true>(out, in, nblocks, s);
+  }
+  return fail(OD_HIP_EINVAL, "block size out of range");
+}
+
+int dct_blocks_host(int bs, bool inv, od_coeff *out, const od_coeff *in, int nblocks) {
+  if (!out || !in) return fail(OD_HIP_EFAULT, "null pointer");
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblocks < 0) return fail(OD_HIP_EINVAL, "bad bs/nblocks");
+  if (int rc = ensure_device()) return rc;
+  if (nblocks == 0) return 0;
+  size_t n = 4u << bs, bytes = (size_t)nblocks*n*n*sizeof(int32_t);
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_out.reserve(bytes)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
+  if (int rc = dct_blocks_dev(bs, inv, (int32_t *)g_out.p, (const int32_t *)g_in.p, nblocks, 0))
+    return rc;
+  HIPCHK(hipMemcpy(out, g_out.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// vtable-signature single block: gather the strided block, run, scatter.
+void dct_one(int bs, bool inv, od_coeff *out, int ostride, const od_coeff *in, int istride) {
+  int n = 4 << bs;
+  od_coeff tmp[32*32];
+  for (int i = 0; i < n; i++) memcpy(tmp + i*n, in + (size_t)i*istride, n*sizeof(od_coeff));
+  int rc = dct_blocks_host(bs, inv, tmp, tmp, 1);
+  if (rc != 0) {
+    fprintf(stderr, "daala_hip: fatal: %s\n", g_err.c_str());
+    abort();
+  }
+  for (int i = 0; i < n; i++) memcpy(out + (size_t)i*ostride, tmp + i*n, n*sizeof(od_coeff));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+struct od_hip_ctx {
+  od_hip_geometry geo;
+  int device;
+  hipStream_t stream;
+  int nhsb, nvsb;
+  int pw[OD_HIP_NPLANES_MAX], ph[OD_HIP_NPLANES_MAX], nlev[OD_HIP_NPLANES_MAX];
+  size_t psz[OD_HIP_NPLANES_MAX];            // samples per plane
+  uint8_t *pix[OD_HIP_NPLANES_MAX];          // [slot][h][w]
+  int32_t *lev[OD_HIP_NPLANES_MAX];          // [slot][level][h][w]
+  int32_t *d[OD_HIP_NPLANES_MAX];            // [slot][h][w]
+  int32_t *c[OD_HIP_NPLANES_MAX];            // [slot][h][w]
+  uint8_t *rec[OD_HIP_NPLANES_MAX];          // [slot][h][w]
+  uint8_t *bsize;                            // [slot][nvsb*4][nhsb*4]
+  size_t bsize_sz;
+  uint16_t *tab[OD_HIP_NBSIZES];             // coding tables on device
+  int16_t *qm_dev;                           // scratch QM (1024 int16)
+  // PVQ results per (plane, level)
+  PvqBandRec *pvq_bands[OD_HIP_NPLANES_MAX][4];
+  int32_t *pvq_y[OD_HIP_NPLANES_MAX][4];
+  // timing
+  struct Span { hipEvent_t a, b; };
+  std::map<std::string, std::vector<Span>> spans;
+  std::vector<hipEvent_t> pool;
+  bool timing = false;
+};
+
+namespace {
+
+hipEvent_t get_event(od_hip_ctx *ctx) {
+  if (!ctx->pool.empty()) {
+    hipEvent_t e = ctx->pool.back();
+    ctx->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct Timed {
+  od_hip_ctx *ctx;
+  const char *name;
+  hipEvent_t a = nullptr;
+  Timed(od_hip_ctx *c, const char *n) : ctx(c), name(n) {
+    if (ctx->timing) {
+      a = get_event(ctx);
+      if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~Timed() {
+    if (a) {
+      hipEvent_t b = get_event(ctx);
+      if (b) {
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->spans[name].push_back({a, b});
+      }
+    }
+  }
+};
+
+int check_slots(od_hip_ctx *ctx, int slot0, int nslots) {
+  if (!ctx) return fail(OD_HIP_EFAULT, "null context");
+  if (slot0 < 0 || nslots < 1 || slot0 + nslots > ctx->geo.nslots)
+    return fail(OD_HIP_EINVAL, "slot range out of bounds");
+  HIPCHK(hipSetDevice(ctx->device));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *od_hip_last_error(void) { return g_err.c_str(); }
+
+const char *od_hip_version(void) { return "daala_hip 0.1 (gfx950)"; }
+
+int od_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void od_hip_bin_fdct4x4(od_coeff *y, int ys, const od_coeff *x, int xs) { dct_one(0, false, y, ys, x, xs); }
+void od_hip_bin_fdct8x8(od_coeff *y, int ys, const od_coeff *x, int xs) { dct_one(1, false, y, ys, x, xs); }
+void od_hip_bin_fdct16x16(od_coeff *y, int ys, const od_coeff *x, int xs) { dct_one(2, false, y, ys, x, xs); }
+void od_hip_bin_fdct32x32(od_coeff *y, int ys, const od_coeff *x, int xs) { dct_one(3, false, y, ys, x, xs); }
+void od_hip_bin_idct4x4(od_coeff *x, int xs, const od_coeff *y, int ys) { dct_one(0, true, x, xs, y, ys); }
+void od_hip_bin_idct8x8(od_coeff *x, int xs, const od_coeff *y, int ys) { dct_one(1, true, x, xs, y, ys); }
+void od_hip_bin_idct16x16(od_coeff *x, int xs, const od_coeff *y, int ys) { dct_one(2, true, x, xs, y, ys); }
+void od_hip_bin_idct32x32(od_coeff *x, int xs, const od_coeff *y, int ys) { dct_one(3, true, x, xs, y, ys); }
+
+int od_hip_vtbl_fill(od_dct_func_2d fdct_2d[OD_HIP_NBSIZES + 1],
+                     od_dct_func_2d idct_2d[OD_HIP_NBSIZES + 1]) {
+  if (!fdct_2d || !idct_2d) return fail(OD_HIP_EFAULT, "null vtable");
+  if (int rc = ensure_device()) return rc;
+  fdct_2d[0] = od_hip_bin_fdct4x4;
+  fdct_2d[1] = od_hip_bin_fdct8x8;
+  fdct_2d[2] = od_hip_bin_fdct16x16;
+  fdct_2d[3] = od_hip_bin_fdct32x32;
+  idct_2d[0] = od_hip_bin_idct4x4;
+  idct_2d[1] = od_hip_bin_idct8x8;
+  idct_2d[2] = od_hip_bin_idct16x16;
+  idct_2d[3] = od_hip_bin_idct32x32;
+  return 0;
+}
+
+int od_hip_fdct_blocks(int bs, od_coeff *out, const od_coeff *in, int nblocks) {
+  return dct_blocks_host(bs, false, out, in, nblocks);
+}
+
+int od_hip_idct_blocks(int bs, od_coeff *out, const od_coeff *in, int nblocks) {
+  return dct_blocks_host(bs, true, out, in, nblocks);
+}
+
+int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in, int nblocks) {
+  if (!out || !in) return fail(OD_HIP_EFAULT, "null pointer");
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblocks < 0) return fail(OD_HIP_EINVAL, "bad bs/nblocks");
+  if (int rc = ensure_device()) return rc;
+  if (nblocks == 0) return 0;
+  size_t n = 4u << bs, bytes = (size_t)nblocks*n*n*sizeof(int32_t);
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_out.reserve(bytes)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
+  dim3 grid((nblocks + 63)/64), blk(64);
+  int32_t *o = (int32_t *)g_out.p;
+  const int32_t *i = (const int32_t *)g_in.p;
+  switch (bs) {
+    case 0: hipLaunchKernelGGL(k_haar_blocks<2>, grid, blk, 0, 0, o, i, nblocks, inverse); break;
+    case 1: hipLaunchKernelGGL(k_haar_blocks<3>, grid, blk, 0, 0, o, i, nblocks, inverse); break;
+    case 2: hipLaunchKernelGGL(k_haar_blocks<4>, grid, blk, 0, 0, o, i, nblocks, inverse); break;
+    default: hipLaunchKernelGGL(k_haar_blocks<5>, grid, blk, 0, 0, o, i, nblocks, inverse); break;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_filter4_vectors(int inverse, od_coeff *out, const od_coeff *in, int nvec) {
+  if (!out || !in) return fail(OD_HIP_EFAULT, "null pointer");
+  if (nvec < 0) return fail(OD_HIP_EINVAL, "bad nvec");
+  if (int rc = ensure_device()) return rc;
+  if (nvec == 0) return 0;
+  size_t bytes = (size_t)nvec*4*sizeof(int32_t);
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_out.reserve(bytes)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_filter4_vectors, dim3((nvec + 255)/256), dim3(256), 0, 0,
+                     (int32_t *)g_out.p, (const int32_t *)g_in.p, nvec, inverse);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_resample_luma_420(od_coeff *pred, const od_coeff *luma, size_t luma_len,
+                             int lstride, const int32_t *luma_off, int nblk, int bs,
+                             int chroma_bs) {
+  if (!pred || !luma || !luma_off) return fail(OD_HIP_EFAULT, "null pointer");
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblk < 0 || (chroma_bs == 0 && bs != 0))
+    return fail(OD_HIP_EINVAL, "bad block size");
+  if (int rc = ensure_device()) return rc;
+  if (nblk == 0) return 0;
+  size_t n = 4u << bs, obytes = (size_t)nblk*n*n*sizeof(int32_t);
+  if (int rc = g_in.reserve(luma_len*sizeof(int32_t))) return rc;
+  if (int rc = g_out.reserve(obytes)) return rc;
+  if (int rc = g_aux0.reserve((size_t)nblk*sizeof(int32_t))) return rc;
+  HIPCHK(hipMemcpy(g_in.p, luma, luma_len*sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, luma_off, (size_t)nblk*sizeof(int32_t), hipMemcpyHostToDevice));
+  long total = (long)nblk*n*n;
+  hipLaunchKernelGGL(k_resample_luma_420, dim3((total + 255)/256), dim3(256), 0, 0,
+                     (int32_t *)g_out.p, (const int32_t *)g_in.p, lstride,
+                     (const int32_t *)g_aux0.p, nblk, bs, chroma_bs);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(pred, g_out.p, obytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
+  if (!geo) { fail(OD_HIP_EFAULT, "null geometry"); return nullptr; }
+  if (ensure_device()) return nullptr;
+  if (geo->frame_width <= 0 || geo->frame_height <= 0 || geo->frame_width%32 ||
+      geo->frame_height%32 || geo->pic_width > geo->frame_width ||
+      geo->pic_height > geo->frame_height || geo->pic_width <= 0 || geo->pic_height <= 0 ||
+      geo->nplanes < 1 || geo->nplanes > 3 || geo->nslots < 1) {
+    fail(OD_HIP_EINVAL, "invalid geometry");
+    return nullptr;
+  }
+  for (int p = 0; p < geo->nplanes; p++) {
+    if (geo->xdec[p] < 0 || geo->xdec[p] > 1 || (p == 0 && geo->xdec[p] != 0)) {
+      fail(OD_HIP_EINVAL, "unsupported decimation");
+      return nullptr;
+    }
+  }
+  if (hipSetDevice(device) != hipSuccess) { fail(OD_HIP_ENODEV, "hipSetDevice failed"); return nullptr; }
+  od_hip_ctx *ctx = new od_hip_ctx();
+  ctx->geo = *geo;
+  ctx->device = device;
+  ctx->nhsb = geo->frame_width/32;
+  ctx->nvsb = geo->frame_height/32;
+  memset(ctx->pix, 0, sizeof(ctx->pix));
+  memset(ctx->lev, 0, sizeof(ctx->lev));
+  memset(ctx->d, 0, sizeof(ctx->d));
+  memset(ctx->c, 0, sizeof(ctx->c));
+  memset(ctx->rec, 0, sizeof(ctx->rec));
+  memset(ctx->pvq_bands, 0, sizeof(ctx->pvq_bands));
+  memset(ctx->pvq_y, 0, sizeof(ctx->pvq_y));
+  memset(ctx->tab, 0, sizeof(ctx->tab));
+  ctx->bsize = nullptr;
+  ctx->qm_dev = nullptr;
+  bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+  size_t ns = geo->nslots;
+  for (int p = 0; ok && p < geo->nplanes; p++) {
+    int dec = geo->xdec[p];
+    ctx->pw[p] = geo->frame_width >> dec;
+    ctx->ph[p] = geo->frame_height >> dec;
+    ctx->nlev[p] = 4 - dec;
+    ctx->psz[p] = (size_t)ctx->pw[p]*ctx->ph[p];
+    ok = ok && hipMalloc((void **)&ctx->pix[p], ns*ctx->psz[p]) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->lev[p], ns*ctx->nlev[p]*ctx->psz[p]*4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d[p], ns*ctx->psz[p]*4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->c[p], ns*ctx->psz[p]*4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->rec[p], ns*ctx->psz[p]) == hipSuccess;
+  }
+  ctx->bsize_sz = (size_t)ctx->nhsb*4*ctx->nvsb*4;
+  ok = ok && hipMalloc((void **)&ctx->bsize, ns*ctx->bsize_sz) == hipSuccess;
+  ok = ok && hipMemset(ctx->bsize, 3, ns*ctx->bsize_sz) == hipSuccess;
+  ok = ok && hipMalloc((void **)&ctx->qm_dev, 4*1024*sizeof(int16_t)) == hipSuccess;
+  const uint16_t *tabs[4] = {CODING_TO_RASTER_4, CODING_TO_RASTER_8, CODING_TO_RASTER_16,
+                             CODING_TO_RASTER_32};
+  const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
+  for (int b = 0; ok && b < 4; b++) {
+    ok = ok && hipMalloc((void **)&ctx->tab[b], tabn[b]*sizeof(uint16_t)) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->tab[b], tabs[b], tabn[b]*sizeof(uint16_t),
+                         hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok) {
+    fail(OD_HIP_ENODEV, "device allocation failed");
+    od_hip_ctx_destroy(ctx);
+    return nullptr;
+  }
+  return ctx;
+}
+
+void od_hip_ctx_destroy(od_hip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int p = 0; p < OD_HIP_NPLANES_MAX; p++) {
+    if (ctx->pix[p]) (void)hipFree(ctx->pix[p]);
+    if (ctx->lev[p]) (void)hipFree(ctx->lev[p]);
+    if (ctx->d[p]) (void)hipFree(ctx->d[p]);
+    if (ctx->c[p]) (void)hipFree(ctx->c[p]);
+    if (ctx->rec[p]) (void)hipFree(ctx->rec[p]);
+    for (int l = 0; l < 4; l++) {
+      if (ctx->pvq_bands[p][l]) (void)hipFree(ctx->pvq_bands[p][l]);
+      if (ctx->pvq_y[p][l]) (void)hipFree(ctx->pvq_y[p][l]);
+    }
+  }
+  for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
+  if (ctx->bsize) (void)hipFree(ctx->bsize);
+  if (ctx->qm_dev) (void)hipFree(ctx->qm_dev);
+  for (auto &kv : ctx->spans) for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (auto e : ctx->pool) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int od_hip_upload_planes(od_hip_ctx *ctx, int slot, const unsigned char *const planes[],
+                         const int ystride[]) {
+  if (int rc = check_slots(ctx, slot, 1)) return rc;
+  if (!planes || !ystride) return fail(OD_HIP_EFAULT, "null pointer");
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    if (!planes[p] || ystride[p] < ctx->pw[p]) return fail(OD_HIP_EINVAL, "bad plane");
+    HIPCHK(hipMemcpy2DAsync(ctx->pix[p] + (size_t)slot*ctx->psz[p], ctx->pw[p], planes[p],
+                            ystride[p], ctx->pw[p], ctx->ph[p], hipMemcpyHostToDevice,
+                            ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int od_hip_set_bsize(od_hip_ctx *ctx, int slot, const unsigned char *bsize, int bstride) {
+  if (int rc = check_slots(ctx, slot, 1)) return rc;
+  if (!bsize || bstride < ctx->nhsb*4) return fail(OD_HIP_EINVAL, "bad bsize map");
+  // validate: values 0..3 and quadtree consistency, so the kernels' per-block
+  // top-left-cell test is exact
+  int bw = ctx->nhsb*4, bh = ctx->nvsb*4;
+  for (int y = 0; y < bh; y++) {
+    for (int x = 0; x < bw; x++) {
+      int v = bsize[(size_t)y*bstride + x];
+      if (v > 3) return fail(OD_HIP_EINVAL, "bsize value out of range");
+      if (v >= 2) {
+        int m = (v == 3) ? 4 : 2;
+        int v0 = bsize[(size_t)(y/m*m)*bstride + (x/m*m)];
+        if (v0 != v) return fail(OD_HIP_EINVAL, "bsize map is not quadtree-consistent");
+      }
+    }
+  }
+  for (int y = 0; y < bh; y += 2) for (int x = 0; x < bw; x += 2) {
+    // a 16x16 area is either all 2 (or part of a 3) or all < 2
+    int hi = 0, lo = 0;
+    for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
+      if (bsize[(size_t)(y + j)*bstride + x + i] >= 2) hi++; else lo++;
+    }
+    if (hi && lo) return fail(OD_HIP_EINVAL, "bsize map is not quadtree-consistent");
+  }
+  for (int y = 0; y < bh; y += 4) for (int x = 0; x < bw; x += 4) {
+    int hi = 0, lo = 0;
+    for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
+      if (bsize[(size_t)(y + j)*bstride + x + i] == 3) hi++; else lo++;
+    }
+    if (hi && lo) return fail(OD_HIP_EINVAL, "bsize map is not quadtree-consistent");
+  }
+  HIPCHK(hipMemcpy2DAsync(ctx->bsize + (size_t)slot*ctx->bsize_sz, bw, bsize, bstride, bw, bh,
+                          hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+static FwdArgs fwd_args(od_hip_ctx *ctx, int p, int slot0, bool known, int keyframe) {
+  FwdArgs a;
+  a.pix = ctx->pix[p] + (size_t)slot0*ctx->psz[p];
+  a.pix_fstride = ctx->psz[p];
+  a.pstride = ctx->pw[p];
+  if (known) {
+    a.out = ctx->d[p] + (size_t)slot0*ctx->psz[p];
+    a.out_lstride = 0;
+    a.out_fstride = ctx->psz[p];
+  }
+  else {
+    a.out = ctx->lev[p] + (size_t)slot0*ctx->nlev[p]*ctx->psz[p];
+    a.out_lstride = ctx->psz[p];
+    a.out_fstride = (size_t)ctx->nlev[p]*ctx->psz[p];
+  }
+  a.bsize = ctx->bsize + (size_t)slot0*ctx->bsize_sz;
+  a.bsize_fstride = ctx->bsize_sz;
+  a.bstride = ctx->nhsb*4;
+  a.w = ctx->pw[p];
+  a.h = ctx->ph[p];
+  a.nhsb = ctx->nhsb;
+  a.nvsb = ctx->nvsb;
+  a.pic_w = ctx->geo.pic_width;
+  a.pic_h = ctx->geo.pic_height;
+  a.dec = ctx->geo.xdec[p];
+  a.keyframe = keyframe;
+  return a;
+}
+
+int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  dim3 grid(ctx->nhsb, ctx->nvsb, nslots);
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    FwdArgs a = fwd_args(ctx, p, slot0, false, 0);
+    if (a.dec == 0) {
+      Timed tm(ctx, "k_forward_pyramid_luma");
+      hipLaunchKernelGGL((k_forward<32, 4, false>), grid, dim3(256), 0, ctx->stream, a);
+    }
+    else {
+      Timed tm(ctx, "k_forward_pyramid_chroma");
+      hipLaunchKernelGGL((k_forward<16, 3, false>), grid, dim3(64), 0, ctx->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe) {
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  dim3 grid(ctx->nhsb, ctx->nvsb, nslots);
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    FwdArgs a = fwd_args(ctx, p, slot0, true, keyframe);
+    if (a.dec == 0) {
+      Timed tm(ctx, "k_forward_known_luma");
+      hipLaunchKernelGGL((k_forward<32, 4, true>), grid, dim3(256), 0, ctx->stream, a);
+    }
+    else {
+      Timed tm(ctx, "k_forward_known_chroma");
+      hipLaunchKernelGGL((k_forward<16, 3, true>), grid, dim3(64), 0, ctx->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    InvArgs a;
+    a.d = ctx->d[p] + (size_t)slot0*ctx->psz[p];
+    a.c = ctx->c[p] + (size_t)slot0*ctx->psz[p];
+    a.fstride = ctx->psz[p];
+    a.bsize = ctx->bsize + (size_t)slot0*ctx->bsize_sz;
+    a.bsize_fstride = ctx->bsize_sz;
+    a.bstride = ctx->nhsb*4;
+    a.w = ctx->pw[p]; a.h = ctx->ph[p]; a.nhsb = ctx->nhsb; a.nvsb = ctx->nvsb;
+    a.pic_w = ctx->geo.pic_width; a.pic_h = ctx->geo.pic_height;
+    a.dec = ctx->geo.xdec[p];
+    PostArgs q;
+    q.c = a.c; q.c_fstride = ctx->psz[p];
+    q.rec = ctx->rec[p] + (size_t)slot0*ctx->psz[p]; q.rec_fstride = ctx->psz[p];
+    q.w = a.w; q.h = a.h; q.nhsb = a.nhsb; q.nvsb = a.nvsb;
+    dim3 grid(ctx->nhsb, ctx->nvsb, nslots), grid2(ctx->nhsb + 1, ctx->nvsb + 1, nslots);
+    if (a.dec == 0) {
+      { Timed tm(ctx, "k_inverse_sb_luma");
+        hipLaunchKernelGGL((k_inverse_sb<32, 4>), grid, dim3(256), 0, ctx->stream, a); }
+      HIPCHK(hipGetLastError());
+      { Timed tm(ctx, "k_postfilter_clamp_luma");
+        hipLaunchKernelGGL((k_postfilter_clamp<32>), grid2, dim3(256), 0, ctx->stream, q); }
+    }
+    else {
+      { Timed tm(ctx, "k_inverse_sb_chroma");
+        hipLaunchKernelGGL((k_inverse_sb<16, 3>), grid, dim3(64), 0, ctx->stream, a); }
+      HIPCHK(hipGetLastError());
+      { Timed tm(ctx, "k_postfilter_clamp_chroma");
+        hipLaunchKernelGGL((k_postfilter_clamp<16>), grid2, dim3(64), 0, ctx->stream, q); }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+static int check_plane(od_hip_ctx *ctx, int slot, int pli) {
+  if (int rc = check_slots(ctx, slot, 1)) return rc;
+  if (pli < 0 || pli >= ctx->geo.nplanes) return fail(OD_HIP_EINVAL, "plane out of range");
+  return 0;
+}
+
+int od_hip_download_level(od_hip_ctx *ctx, int slot, int pli, int level, od_coeff *dst) {
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
+  if (level < 0 || level >= ctx->nlev[pli]) return fail(OD_HIP_EINVAL, "level out of range");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(dst, ctx->lev[pli] + ((size_t)slot*ctx->nlev[pli] + level)*ctx->psz[pli],
+                   ctx->psz[pli]*4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_download_coeffs(od_hip_ctx *ctx, int slot, int pli, od_coeff *dst) {
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(dst, ctx->d[pli] + (size_t)slot*ctx->psz[pli], ctx->psz[pli]*4,
+                   hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_upload_coeffs(od_hip_ctx *ctx, int slot, int pli, const od_coeff *src) {
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (!src) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(ctx->d[pli] + (size_t)slot*ctx->psz[pli], src, ctx->psz[pli]*4,
+                   hipMemcpyHostToDevice));
+  return 0;
+}
+
+int od_hip_download_recon(od_hip_ctx *ctx, int slot, int pli, unsigned char *dst) {
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(dst, ctx->rec[pli] + (size_t)slot*ctx->psz[pli], ctx->psz[pli],
+                   hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+int od_hip_band_offsets(int bs, int off[11]) {
+  static const int all[] = {1, 16, 24, 32, 64, 96, 128, 256, 384, 512};
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || !off) return fail(OD_HIP_EINVAL, "bad bs");
+  int nb = bs == 0 ? 1 : bs == 1 ? 4 : bs == 2 ? 7 : 9;
+  for (int i = 0; i <= nb; i++) off[i] = all[i];
+  return nb;
+}
+
+int od_hip_pvq_nblocks(od_hip_ctx *ctx, int pli, int level) {
+  if (!ctx) return fail(OD_HIP_EFAULT, "null context");
+  if (pli < 0 || pli >= ctx->geo.nplanes || level < 0 || level >= ctx->nlev[pli])
+    return fail(OD_HIP_EINVAL, "plane/level out of range");
+  int n = (32 >> ctx->geo.xdec[pli]) >> level;
+  return (ctx->pw[pli]/n)*(ctx->ph[pli]/n);
+}
+
+int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+                            const int16_t *qm, const int32_t *q, const double *beta) {
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  if (!qm || !q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
+  int nblk = od_hip_pvq_nblocks(ctx, pli, level);
+  if (nblk < 0) return nblk;
+  int n = (32 >> ctx->geo.xdec[pli]) >> level;
+  int bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
+  int ncoded = n*n < 512 ? n*n : 512;
+  size_t ns = ctx->geo.nslots;
+  PvqLevelArgs a;
+  a.nbands = od_hip_band_offsets(bs, a.off);
+  if (!ctx->pvq_bands[pli][level]) {
+    HIPCHK(hipMalloc((void **)&ctx->pvq_bands[pli][level],
+                     ns*nblk*a.nbands*sizeof(PvqBandRec)));
+    HIPCHK(hipMalloc((void **)&ctx->pvq_y[pli][level], ns*nblk*2*ncoded*sizeof(int32_t)));
+  }
+  HIPCHK(hipMemcpyAsync(ctx->qm_dev + bs*1024, qm, (size_t)n*n*sizeof(int16_t),
+                        hipMemcpyHostToDevice, ctx->stream));
+  a.lev = ctx->lev[pli] + ((size_t)slot0*ctx->nlev[pli] + level)*ctx->psz[pli];
+  a.lev_fstride = (size_t)ctx->nlev[pli]*ctx->psz[pli];
+  a.w = ctx->pw[pli];
+  a.n = n;
+  a.nbx = ctx->pw[pli]/n;
+  a.nby = ctx->ph[pli]/n;
+  for (int i = 0; i < a.nbands; i++) { a.q[i] = q[i]; a.beta[i] = beta[i]; }
+  a.tab = ctx->tab[bs];
+  a.qm = ctx->qm_dev + bs*1024;
+  a.bands = ctx->pvq_bands[pli][level] + (size_t)slot0*nblk*a.nbands;
+  a.y = ctx->pvq_y[pli][level] + (size_t)slot0*nblk*2*ncoded;
+  a.ncoded = ncoded;
+  dim3 grid((nblk + 63)/64, a.nbands, nslots);
+  {
+    Timed tm(ctx, "k_pvq_noref_level");
+    hipLaunchKernelGGL(k_pvq_noref_level, grid, dim3(64), 0, ctx->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
+                        od_hip_pvq_band *bands, int32_t *y) {
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  int nblk = od_hip_pvq_nblocks(ctx, pli, level);
+  if (nblk < 0) return nblk;
+  if (!ctx->pvq_bands[pli][level]) return fail(OD_HIP_EINVAL, "no PVQ results for this level");
+  int n = (32 >> ctx->geo.xdec[pli]) >> level;
+  int bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
+  int off[11];
+  int nb = od_hip_band_offsets(bs, off);
+  int ncoded = n*n < 512 ? n*n : 512;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (bands) {
+    HIPCHK(hipMemcpy(bands, ctx->pvq_bands[pli][level] + (size_t)slot*nblk*nb,
+                     (size_t)nblk*nb*sizeof(PvqBandRec), hipMemcpyDeviceToHost));
+  }
+  if (y) {
+    HIPCHK(hipMemcpy(y, ctx->pvq_y[pli][level] + (size_t)slot*nblk*2*ncoded,
+                     (size_t)nblk*2*ncoded*sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int od_hip_pvq_search_vectors(int n, int nvec, const double *x, const int32_t *k,
+                              const double *g2, int32_t *y, double *cos_dist) {
+  if (!x || !k || !g2 || !y || !cos_dist) return fail(OD_HIP_EFAULT, "null pointer");
+  if (n < 1 || n > PVQ_MAXN || nvec < 0) return fail(OD_HIP_EINVAL, "bad n/nvec");
+  if (int rc = ensure_device()) return rc;
+  if (nvec == 0) return 0;
+  size_t nv = nvec;
+  if (int rc = g_in.reserve(nv*n*8)) return rc;
+  if (int rc = g_out.reserve(nv*n*4)) return rc;
+  if (int rc = g_aux0.reserve(nv*4)) return rc;
+  if (int rc = g_aux1.reserve(nv*8)) return rc;
+  if (int rc = g_aux2.reserve(nv*8)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, x, nv*n*8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, k, nv*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux1.p, g2, nv*8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_pvq_search_vectors, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
+                     (const double *)g_in.p, (const int32_t *)g_aux0.p,
+                     (const double *)g_aux1.p, (int32_t *)g_out.p, (double *)g_aux2.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(y, g_out.p, nv*n*4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cos_dist, g_aux2.p, nv*8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_pvq_synthesis_noref(int n, int nvec, const int32_t *y, const double *g,
+                               const int16_t *qm_inv, od_coeff *out) {
+  if (!y || !g || !qm_inv || !out) return fail(OD_HIP_EFAULT, "null pointer");
+  if (n < 1 || nvec < 0) return fail(OD_HIP_EINVAL, "bad n/nvec");
+  if (int rc = ensure_device()) return rc;
+  if (nvec == 0) return 0;
+  size_t nv = nvec;
+  if (int rc = g_in.reserve(nv*n*4)) return rc;
+  if (int rc = g_out.reserve(nv*n*4)) return rc;
+  if (int rc = g_aux0.reserve(nv*n*2)) return rc;
+  if (int rc = g_aux1.reserve(nv*8)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, y, nv*n*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, qm_inv, nv*n*2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux1.p, g, nv*8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_pvq_synthesis_noref, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
+                     (const int32_t *)g_in.p, (const double *)g_aux1.p,
+                     (const int16_t *)g_aux0.p, (int32_t *)g_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, nv*n*4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_sync(od_hip_ctx *ctx) {
+  if (!ctx) return fail(OD_HIP_EFAULT, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int od_hip_timing_reset(od_hip_ctx *ctx) {
+  if (!ctx) return fail(OD_HIP_EFAULT, "null context");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto &kv : ctx->spans) {
+    for (auto &s : kv.second) { ctx->pool.push_back(s.a); ctx->pool.push_back(s.b); }
+  }
+  ctx->spans.clear();
+  ctx->timing = true;
+  return 0;
+}
+
+int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches, double *total_ms) {
+  if (!ctx || !kernel || !launches || !total_ms) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *launches = 0;
+  *total_ms = 0;
+  auto it = ctx->spans.find(kernel);
+  if (it == ctx->spans.end()) return 0;
+  for (auto &s : it->second) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s.a, s.b));
+    *total_ms += ms;
+    (*launches)++;
+  }
+  return 0;
+}
+
+}  // extern "C"

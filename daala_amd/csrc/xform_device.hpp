@@ -1,0 +1,61 @@
+// Device-side building blocks of the transform path (gfx950).
+//   - 4-point lapping pre/post filter   (reference src/filter.c:174-249)
+//   - 2x2 Haar kernel                   (reference src/tf.h:34-45)
+// The reversible DCT lifting steps live in gen_lift_dct.hpp (generated).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gen_lift_dct.hpp"
+
+// Forward lapping across a block edge: x0,x1 | x2,x3.  Floor shifts, "+1 if
+// positive" after each scale (src/filter.c:190-198).
+__device__ __forceinline__ void lap4_pre(int32_t &x0, int32_t &x1, int32_t &x2,
+                                         int32_t &x3) {
+  int32_t d3 = x0 - x3;
+  int32_t d2 = x1 - x2;
+  int32_t s1 = x1 - (d2 >> 1);
+  int32_t s0 = x0 - (d3 >> 1);
+  d2 = (d2*85) >> 6;
+  d2 += (d2 > 0);
+  d3 = (d3*75) >> 6;
+  d3 += (d3 > 0);
+  d3 += (d2*-15 + 32) >> 6;
+  d2 += (d3*33 + 32) >> 6;
+  s0 += d3 >> 1;
+  s1 += d2 >> 1;
+  x0 = s0;
+  x1 = s1;
+  x2 = s1 - d2;
+  x3 = s0 - d3;
+}
+
+// Inverse lapping; undoes the scale with C truncating division
+// (src/filter.c:237-241).
+__device__ __forceinline__ void lap4_post(int32_t &x0, int32_t &x1, int32_t &x2,
+                                          int32_t &x3) {
+  int32_t d3 = x0 - x3;
+  int32_t d2 = x1 - x2;
+  int32_t s1 = x1 - (d2 >> 1);
+  int32_t s0 = x0 - (d3 >> 1);
+  d2 -= (d3*33 + 32) >> 6;
+  d3 -= (d2*-15 + 32) >> 6;
+  d3 = d3*64/75;
+  d2 = d2*64/85;
+  s0 += d3 >> 1;
+  s1 += d2 >> 1;
+  x0 = s0;
+  x1 = s1;
+  x2 = s1 - d2;
+  x3 = s0 - d3;
+}
+
+__device__ __forceinline__ void haar2x2(int32_t &ll, int32_t &lh, int32_t &hl,
+                                        int32_t &hh) {
+  ll += hl;
+  hh -= lh;
+  int32_t m = (ll - hh) >> 1;
+  lh = m - lh;
+  hl = m - hl;
+  ll -= lh;
+  hh += hl;
+}

@@ -1,0 +1,213 @@
+/* daala_hip.h - C ABI of the MI355X (gfx950) back-end for Daala's per-block
+ * transform + quantisation hot path.
+ *
+ * Everything here is plain C: pointers, ints, no C++/torch types.  The entry
+ * points are what the reference's own code would bind (INTEGRATION.md shows the
+ * patch): each one cites the reference interface it replaces.
+ *
+ *   od_coeff          int32_t                           src/filter.h:31
+ *   od_dct_func_2d    (out, out_stride, in, in_stride)  src/dct.h:61-62
+ *
+ * Error convention follows the reference (include/daala/codec.h:89-103):
+ * 0 = success, negative = failure; od_hip_last_error() gives the text.
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails with OD_HIP_ENODEV.
+ */
+#ifndef DAALA_HIP_H
+#define DAALA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t od_coeff;
+
+#define OD_HIP_SUCCESS (0)
+#define OD_HIP_EFAULT (-1)    /* bad pointer / argument (OD_EFAULT) */
+#define OD_HIP_EINVAL (-10)   /* invalid geometry or state (OD_EINVAL) */
+#define OD_HIP_ENODEV (-30)   /* no HIP device / HIP runtime error */
+
+#define OD_HIP_NPLANES_MAX (4)
+#define OD_HIP_NBSIZES (4)    /* 4x4 .. 32x32, OD_NBSIZES src/internal.h:55 */
+
+const char *od_hip_last_error(void);
+int od_hip_device_count(void);
+const char *od_hip_version(void);
+
+/* ---------------------------------------------------------------------------
+ * 1. Per-call drop-ins for the kernel vtable (struct od_state_opt_vtbl,
+ *    src/state.h:106-126; C versions OD_FDCT_2D_C/OD_IDCT_2D_C src/dct.c:42-56).
+ *    Host pointers, strides in elements, out may alias in.  Each call is a
+ *    synchronous H2D + kernel + D2H round trip: correct, but only meant for
+ *    OD_CHECKASM-style parity checking - the batched entry points below are the
+ *    fast path.  They abort() on a HIP failure because the vtable signature
+ *    returns void (the reference aborts on internal failures the same way,
+ *    src/internal.h:128-158). */
+typedef void (*od_dct_func_2d)(od_coeff *out, int out_stride,
+ const od_coeff *in, int in_stride);
+
+void od_hip_bin_fdct4x4(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hip_bin_fdct8x8(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hip_bin_fdct16x16(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hip_bin_fdct32x32(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hip_bin_idct4x4(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hip_bin_idct8x8(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hip_bin_idct16x16(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hip_bin_idct32x32(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+
+/* Overwrites entries 0..3 of the two vtable arrays (entry 4, the 64-point
+ * float transform, is unreachable - src/encode.c:1098 - and left alone).
+ * Replaces the body of od_state_opt_vtbl_init_x86 (src/x86/x86state.c:39-96)
+ * for the fdct_2d / idct_2d members.  Returns 0 or OD_HIP_ENODEV. */
+int od_hip_vtbl_fill(od_dct_func_2d fdct_2d[OD_HIP_NBSIZES + 1],
+ od_dct_func_2d idct_2d[OD_HIP_NBSIZES + 1]);
+
+/* ---------------------------------------------------------------------------
+ * 2. Batched block transforms on host memory: nblocks dense n x n blocks
+ *    (n = 4 << bs), block b at blocks[b*n*n].  Same arithmetic as
+ *    od_bin_fdctNxN / od_bin_idctNxN (src/dct.c:137,144,335,342,774,782,2028,
+ *    2036), and for `haar` od_haar / od_haar_inv (src/dct.c:1960-2026, lossless
+ *    frames).  out may alias in. */
+int od_hip_fdct_blocks(int bs, od_coeff *out, const od_coeff *in, int nblocks);
+int od_hip_idct_blocks(int bs, od_coeff *out, const od_coeff *in, int nblocks);
+int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in,
+ int nblocks);
+
+/* nvec 4-sample vectors through od_pre_filter4 / od_post_filter4
+ * (src/filter.c:174-249). */
+int od_hip_filter4_vectors(int inverse, od_coeff *out, const od_coeff *in,
+ int nvec);
+
+/* CfL luma resample, od_resample_luma_coeffs (src/intra.c:72-109) built on
+ * od_tf_up_hv_lp (src/tf.c:82-108), 4:2:0 only: for each of nblk blocks reads
+ * the luma coefficients at luma + luma_off[b] (stride lstride) and writes an
+ * n x n dense predictor (n = 4 << bs) at pred + b*n*n. chroma_bs as in the
+ * reference: 0 => TF-merge of the 2x2 group of 4x4 luma blocks. */
+int od_hip_resample_luma_420(od_coeff *pred, const od_coeff *luma, size_t luma_len,
+ int lstride, const int32_t *luma_off, int nblk, int bs, int chroma_bs);
+
+/* ---------------------------------------------------------------------------
+ * 3. Device-resident frame pipeline.  A context owns the HBM buffers of
+ *    `nslots` frames of one geometry (the device mirror of what od_state_init
+ *    allocates per context: ctmp/dtmp planes, src/state.c:395-455).
+ *    Planes are dense, stride = padded plane width (frame padded to a multiple
+ *    of 32 here; the reference pads to 64, src/state.c:372-375 - pass the
+ *    padded frame size you use).  Only 8-bit input, 4:4:4 or 4:2:0. */
+typedef struct od_hip_ctx od_hip_ctx;
+
+typedef struct od_hip_geometry {
+  int pic_width;            /* daala_info.pic_width  (luma, unpadded) */
+  int pic_height;
+  int frame_width;          /* padded luma size, multiple of 32 */
+  int frame_height;
+  int nplanes;              /* 1..3 */
+  int xdec[OD_HIP_NPLANES_MAX];   /* 0 or 1; ydec == xdec (src/encode.c:1295) */
+  int nslots;               /* frames resident at once */
+} od_hip_geometry;
+
+od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo);
+void od_hip_ctx_destroy(od_hip_ctx *ctx);
+
+/* Input: padded 8-bit planes (what od_img_copy_pad leaves in enc->input_img,
+ * src/encode.c:2829-2841).  H2D copy into slot. */
+int od_hip_upload_planes(od_hip_ctx *ctx, int slot,
+ const unsigned char *const planes[], const int ystride[]);
+
+/* Forward PYRAMID for block-size RDO, slots [slot0, slot0+nslots): fuses
+ * od_ref_plane_to_coeff (src/state.c:1252), od_apply_prefilter_frame_sbs
+ * (src/filter.c:1556), od_prefilter_split (src/filter.c:1486) of every ancestor
+ * and od_bin_fdctNxN of every block of every size - the inputs
+ * od_block_encode sees at each level of od_encode_recursive's RDO
+ * (src/encode.c:1554-1592).  Level k of plane pli holds the transform of every
+ * (SB >> k)-sized block, SB = 32 >> xdec[pli]; luma has 4 levels, 4:2:0 chroma
+ * 3.  Results stay in HBM. */
+int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots);
+
+/* Forward with KNOWN block sizes = od_compute_dcts over the frame
+ * (src/encode.c:1286-1343, incl. the keyframe Haar merge of child DCs).
+ * bsize: luma block-size map, 1 byte per 8x8 (values 0..3), (frame_height/8)
+ * rows of `bstride` bytes, quadtree-consistent (src/state.h:207-224). */
+int od_hip_set_bsize(od_hip_ctx *ctx, int slot, const unsigned char *bsize,
+ int bstride);
+int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe);
+
+/* Inverse with known block sizes: od_bin_idctNxN of every coded block,
+ * od_postfilter_split back up the quadtree (src/decode.c:843-866,
+ * src/filter.c:1512), od_apply_postfilter_frame_sbs (src/filter.c:1588) and
+ * od_coeff_to_ref_plane (src/state.c:1320).  Input: the slot's coefficient
+ * planes (as written by od_hip_forward_known or od_hip_upload_coeffs);
+ * output: 8-bit reconstruction planes in HBM. */
+int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots);
+
+/* Host access to device-resident results (row-dense, stride = plane width). */
+int od_hip_download_level(od_hip_ctx *ctx, int slot, int pli, int level,
+ od_coeff *dst);
+int od_hip_download_coeffs(od_hip_ctx *ctx, int slot, int pli, od_coeff *dst);
+int od_hip_upload_coeffs(od_hip_ctx *ctx, int slot, int pli, const od_coeff *src);
+int od_hip_download_recon(od_hip_ctx *ctx, int slot, int pli, unsigned char *dst);
+
+/* ---------------------------------------------------------------------------
+ * 4. PVQ.  State-free part of pvq_theta (src/pvq_encoder.c:311-511): the
+ *    no-reference gain candidates of every band of every block of one pyramid
+ *    level - od_pvq_compute_gain (src/pvq.c:456), od_pvq_compute_k (:508),
+ *    pvq_search_rdo_double (src/pvq_encoder.c:121), distortion (:466).  The
+ *    host adds lambda*od_pvq_rate (adaptive entropy state) and picks.
+ *
+ *    qm: the 16-bit QM of this block size / decimation in coding order, n*n
+ *    entries (state.qm + od_qm_offset(bs, xdec), src/pvq.c:292,302).
+ *    q[band]: per-band quantiser max(1, q0*pvq_qm_q4[idx] >> 4)
+ *    (src/pvq_encoder.c:712); beta[band] from OD_PVQ_BETA (src/pvq.c:230).
+ *    Output record layout: od_hip_pvq_band (one per block per band, blocks in
+ *    raster order of the level), pulses y: [record][cand][n_band] int32 packed
+ *    per band (see od_hip_pvq_layout). */
+typedef struct od_hip_pvq_band {
+  double cg;          /* companded gain of the input, cg in pvq_theta */
+  double g;           /* raw gain */
+  double cos_dist[2];
+  double dist[2];     /* gain_weight*(qcg-cg)^2 + qcg*cg*(2-2*cos_dist) */
+  int32_t qg[2];      /* candidate gain index i */
+  int32_t k[2];       /* pulses */
+  int32_t ncand;      /* 0..2 */
+  int32_t pad;
+} od_hip_pvq_band;
+
+/* Bands of an n x n block (OD_BAND_OFFSETS src/partition.c:77-91): returns the
+ * band count and fills off[0..nb] (coding-order boundaries). */
+int od_hip_band_offsets(int bs, int off[11]);
+
+/* Runs the search for pyramid level `level` of plane pli for slots
+ * [slot0, slot0+nslots).  Results stay in HBM until downloaded. */
+int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli,
+ int level, const int16_t *qm, const int32_t *q, const double *beta);
+
+/* Number of blocks of that level in one frame; the y array of one slot holds
+ * nblocks * 2 * ncoded int32 (ncoded = min(n*n, 512)), block-major, then
+ * candidate, then coding order (DC slot unused). */
+int od_hip_pvq_nblocks(od_hip_ctx *ctx, int pli, int level);
+int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
+ od_hip_pvq_band *bands, int32_t *y);
+
+/* Stand-alone batched pieces for parity tests (host memory):
+ * nvec band vectors of length n. */
+int od_hip_pvq_search_vectors(int n, int nvec, const double *x, const int32_t *k,
+ const double *g2, int32_t *y, double *cos_dist);
+int od_hip_pvq_synthesis_noref(int n, int nvec, const int32_t *y,
+ const double *g, const int16_t *qm_inv, od_coeff *out);
+
+/* Synchronise the context's stream / time its last batch (ms, HIP events). */
+int od_hip_sync(od_hip_ctx *ctx);
+
+/* Kernel timing hooks for bench.py: HIP events recorded on the context's own
+ * stream around every launch of the named kernel since the last reset.
+ * Returns the number of launches and sum of durations in ms. */
+int od_hip_timing_reset(od_hip_ctx *ctx);
+int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches,
+ double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

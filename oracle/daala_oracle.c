@@ -742,3 +742,56 @@ int orc_pvq_noref_candidates(const coeff *x0, int n, int q0, double beta,
   }
   return nc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* CPU baseline of bench.py (kind "port"): the SAME work one bench step does on
+   the device for one 4:2:0 frame, single thread: forward pyramid of all planes,
+   no-reference PVQ candidates of every band of every block of every level,
+   forward with known block sizes, inverse to 8-bit.  qm: the reference's
+   OD_QM_BUFFER_SIZE table (state.qm), q0[pli], pvq_qm_q4[pli][20], masking.
+   Returns a checksum so the work cannot be optimised away. */
+long orc_bench_frame(const uint8_t *const pix[3], int fw, int fh, int pic_w,
+ int pic_h, const unsigned char *bsize, const int16_t *qm, const int *q0,
+ const unsigned char *pvq_qm_q4, int masking) {
+  long sum = 0;
+  int pli;
+  for (pli = 0; pli < 3; pli++) {
+    int dec = pli > 0, w = fw >> dec, h = fh >> dec, nlev = 4 - dec, k;
+    int nhsb = fw/32, nvsb = fh/32;
+    coeff *c = (coeff *)malloc(sizeof(coeff)*w*h);
+    coeff *d = (coeff *)malloc(sizeof(coeff)*w*h);
+    uint8_t *rec = (uint8_t *)malloc((size_t)w*h);
+    coeff *lev[4];
+    for (k = 0; k < nlev; k++) lev[k] = (coeff *)malloc(sizeof(coeff)*w*h);
+    orc_forward_pyramid_plane(c, lev, nlev, pix[pli], w, nhsb, nvsb, dec, pic_w, pic_h);
+    for (k = 0; k < nlev; k++) {
+      int n = (32 >> dec) >> k, bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
+      int off[11], nb = orc_band_offsets(n, off), bx, by, b;
+      const int16_t *qmb = qm + bs*2048 + dec*1024;
+      for (by = 0; by < h/n; by++) {
+        for (bx = 0; bx < w/n; bx++) {
+          coeff co[1024];
+          orc_raster_to_coding_order(co, n, lev[k] + (by*n)*w + bx*n, w);
+          for (b = 0; b < nb; b++) {
+            int nn = off[b + 1] - off[b], qg[2], kk[2], nc, q;
+            double cg, g, cd[2], dist[2], beta;
+            coeff y[2*128];
+            q = q0[pli]*pvq_qm_q4[pli*20 + bs*(bs + 1) + (b + 1) - (b + 1)/3] >> 4;
+            if (q < 1) q = 1;
+            beta = (masking && pli == 0 && bs > 0) ? 1.5 : 1.0;
+            nc = orc_pvq_noref_candidates(co + off[b], nn, q, beta, qmb + off[b], 1,
+             &cg, &g, qg, kk, cd, dist, y);
+            sum += nc ? kk[nc - 1] + y[0] : 0;
+          }
+        }
+      }
+    }
+    orc_forward_plane(c, d, pix[pli], w, nhsb, nvsb, dec, bsize, nhsb*4, pic_w, pic_h, 1);
+    orc_forward_plane(c, d, pix[pli], w, nhsb, nvsb, dec, bsize, nhsb*4, pic_w, pic_h, 0);
+    orc_inverse_plane(rec, w, c, d, nhsb, nvsb, dec, bsize, nhsb*4, pic_w, pic_h);
+    sum += rec[w*h/2] + d[w + 1];
+    for (k = 0; k < nlev; k++) free(lev[k]);
+    free(c); free(d); free(rec);
+  }
+  return sum;
+}

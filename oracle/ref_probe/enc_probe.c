@@ -56,3 +56,145 @@ int probe_forward_plane(int pic_w, int pic_h, int pli, int keyframe,
   daala_encode_free(enc);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Whole-encoder drivers (the sequence of SURVEY.md Appendix B): used for the
+   end-to-end anchors in tests/golden and as the CPU baseline (kind "reference")
+   of bench.py.  Input: nframes frames of planar 4:2:0, Y then U then V, each
+   plane dense (pic size, chroma (w+1)/2 x (h+1)/2). */
+#include <time.h>
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9*ts.tv_nsec;
+}
+
+static daala_enc_ctx *make_encoder(int w, int h, int quant, int complexity,
+ int masking, int keyrate) {
+  daala_info di;
+  daala_enc_ctx *enc;
+  daala_info_init(&di);
+  di.pic_width = w;
+  di.pic_height = h;
+  di.nplanes = 3;
+  di.plane_info[0].xdec = di.plane_info[0].ydec = 0;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = di.pixel_aspect_denominator = 1;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.keyframe_rate = keyrate;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return NULL;
+  daala_encode_ctl(enc, OD_SET_QUANT, &quant, sizeof(quant));
+  daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
+  daala_encode_ctl(enc, OD_SET_ACTIVITY_MASKING, &masking, sizeof(masking));
+  return enc;
+}
+
+/* Encodes nframes; returns total video packet bytes (headers excluded), or <0.
+   fnv: FNV-1a-32 over all video packet bytes.  seconds: wall time spent inside
+   daala_encode_img_in + daala_encode_packet_out only.  If pkt_out != NULL the
+   packets are appended there (up to pkt_cap bytes, each prefixed by a 4-byte
+   little-endian length). */
+long probe_encode_frames(int w, int h, int nframes, int quant, int complexity,
+ int masking, int keyrate, const unsigned char *frames, unsigned *fnv,
+ double *seconds, unsigned char *pkt_out, long pkt_cap) {
+  daala_enc_ctx *enc;
+  od_img img;
+  daala_packet dp;
+  long total = 0, used = 0;
+  unsigned hsh = 2166136261u;
+  double t = 0;
+  int f, cw = (w + 1) >> 1, ch = (h + 1) >> 1;
+  size_t fsz = (size_t)w*h + 2*(size_t)cw*ch;
+  enc = make_encoder(w, h, quant, complexity, masking, keyrate);
+  if (enc == NULL) return -1;
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = w;
+  img.height = h;
+  for (f = 0; f < nframes; f++) {
+    unsigned char *base = (unsigned char *)frames + fsz*f;
+    double t0;
+    int left;
+    img.planes[0].data = base;
+    img.planes[0].xdec = img.planes[0].ydec = 0;
+    img.planes[0].xstride = 1;
+    img.planes[0].ystride = w;
+    img.planes[0].bitdepth = 8;
+    img.planes[1].data = base + (size_t)w*h;
+    img.planes[2].data = base + (size_t)w*h + (size_t)cw*ch;
+    img.planes[1].xdec = img.planes[1].ydec = 1;
+    img.planes[2].xdec = img.planes[2].ydec = 1;
+    img.planes[1].xstride = img.planes[2].xstride = 1;
+    img.planes[1].ystride = img.planes[2].ystride = cw;
+    img.planes[1].bitdepth = img.planes[2].bitdepth = 8;
+    t0 = now_s();
+    if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) {
+      daala_encode_free(enc);
+      return -2;
+    }
+    while (daala_encode_packet_out(enc, 0, &dp) > 0) {
+      long i;
+      t += now_s() - t0;
+      for (i = 0; i < dp.bytes; i++) hsh = (hsh ^ dp.packet[i])*16777619u;
+      total += dp.bytes;
+      if (pkt_out != NULL && used + 4 + dp.bytes <= pkt_cap) {
+        pkt_out[used] = dp.bytes & 255;
+        pkt_out[used + 1] = (dp.bytes >> 8) & 255;
+        pkt_out[used + 2] = (dp.bytes >> 16) & 255;
+        pkt_out[used + 3] = (dp.bytes >> 24) & 255;
+        memcpy(pkt_out + used + 4, dp.packet, dp.bytes);
+        used += 4 + dp.bytes;
+      }
+      t0 = now_s();
+    }
+    t += now_s() - t0;
+  }
+  daala_encode_free(enc);
+  if (fnv != NULL) *fnv = hsh;
+  if (seconds != NULL) *seconds = t;
+  return total;
+}
+
+/* Per-frame encoder constants the device PVQ stage needs, read back after one
+   keyframe: quantizer[3], pvq_qm_q4[3][OD_QM_SIZE], qm / qm_inv
+   (OD_QM_BUFFER_SIZE int16 each; src/encode.c:3025-3050, :240). */
+int probe_encoder_params(int quant, int masking, int *quantizer,
+ unsigned char *pvq_qm_q4, int16_t *qm, int16_t *qm_inv) {
+  unsigned char frame[64*64 + 2*32*32];
+  unsigned fnv;
+  daala_enc_ctx *enc;
+  od_img img;
+  daala_packet dp;
+  int pli;
+  int left;
+  (void)fnv;
+  memset(frame, 128, sizeof(frame));
+  enc = make_encoder(64, 64, quant, 7, masking, 1);
+  if (enc == NULL) return -1;
+  memset(&img, 0, sizeof(img));
+  img.nplanes = 3;
+  img.width = img.height = 64;
+  for (pli = 0; pli < 3; pli++) {
+    img.planes[pli].data = frame + (pli == 0 ? 0 : pli == 1 ? 4096 : 4096 + 1024);
+    img.planes[pli].xdec = img.planes[pli].ydec = pli > 0;
+    img.planes[pli].xstride = 1;
+    img.planes[pli].ystride = pli ? 32 : 64;
+    img.planes[pli].bitdepth = 8;
+  }
+  if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
+  while (daala_encode_packet_out(enc, 0, &dp) > 0);
+  for (pli = 0; pli < 3; pli++) {
+    quantizer[pli] = enc->state.quantizer[pli];
+    memcpy(pvq_qm_q4 + pli*OD_QM_SIZE, enc->state.pvq_qm_q4[pli], OD_QM_SIZE);
+  }
+  memcpy(qm, enc->state.qm, sizeof(int16_t)*OD_QM_BUFFER_SIZE);
+  memcpy(qm_inv, enc->state.qm_inv, sizeof(int16_t)*OD_QM_BUFFER_SIZE);
+  daala_encode_free(enc);
+  return 0;
+}

@@ -1,0 +1,378 @@
+"""GPU parity tests: every HIP entry point of include/daala_hip.h, called through
+the C ABI (ctypes), against the CPU oracle on the same seeded inputs and against
+the committed golden vectors.  Integer paths must be bit-exact; the only
+floating-point tolerance in this file is stated where it is used."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from testlib import GOLDEN, c_int, oracle, p16, p32, pf64, pu8, random_bsize_map, synth_plane
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    import daala_amd.binding as b
+    lib = b.load()          # raises when the extension is not built: no fallback
+    assert lib.od_hip_device_count() > 0, 'no HIP device visible'
+    return b
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def orc_blocks(fn, n, blocks):
+    o = oracle()
+    out = np.zeros_like(blocks)
+    for i in range(len(blocks)):
+        getattr(o, fn)(n, p32(out[i]), n, p32(np.ascontiguousarray(blocks[i])), n)
+    return out
+
+
+@pytest.mark.parametrize('bs', (0, 1, 2, 3))
+def test_dct_blocks_ieee1180_ranges(hip, bs):
+    """The reference's own transform test recipe (dcttest, src/dct.c:3439-3469):
+    ranges (-256,255), (-5,5), (-300,300), both signs - here at the coefficient
+    scale (<<4) plus a wide range; forward, inverse on arbitrary data, and exact
+    reconstruction."""
+    n = 4 << bs
+    rng = np.random.default_rng(100 + bs)
+    parts = []
+    for lo, hi in ((-256, 255), (-5, 5), (-300, 300)):
+        v = rng.integers(lo, hi + 1, size=(400, n, n), dtype=np.int32) << 4
+        parts += [v, -v]
+    parts.append(rng.integers(-60000, 60001, size=(300, n, n), dtype=np.int32))
+    x = np.concatenate(parts)
+    y = hip.od_bin_fdct_blocks(bs, x)
+    assert np.array_equal(y, orc_blocks('orc_fdct_2d', n, x))
+    xi = hip.od_bin_idct_blocks(bs, x)
+    assert np.array_equal(xi, orc_blocks('orc_idct_2d', n, x))
+    assert np.array_equal(hip.od_bin_idct_blocks(bs, y), x)
+
+
+def test_dct_golden_vectors(hip):
+    g = golden('dct_vectors.npz')
+    for bs, n in enumerate((4, 8, 16, 32)):
+        assert np.array_equal(hip.od_bin_fdct_blocks(bs, g['x%d' % n]), g['fdct%d' % n])
+        assert np.array_equal(hip.od_bin_idct_blocks(bs, g['x%d' % n]), g['idct%d' % n])
+
+
+def test_dct_empty_and_ragged_batches(hip):
+    for bs in range(4):
+        n = 4 << bs
+        assert hip.od_bin_fdct_blocks(bs, np.zeros((0, n, n), np.int32)).shape == (0, n, n)
+        rng = np.random.default_rng(bs)
+        for cnt in (1, 3, 256//n + 1, 1000 + 7):       # not multiples of the WG batch
+            x = rng.integers(-4096, 4096, size=(cnt, n, n), dtype=np.int32)
+            assert np.array_equal(hip.od_bin_fdct_blocks(bs, x), orc_blocks('orc_fdct_2d', n, x))
+
+
+def test_vtable_dropins_strided_and_in_place(hip):
+    """od_dct_func_2d contract (src/dct.h:61-62): element strides, out may alias in."""
+    lib = hip.load()
+    f = (ctypes.c_void_p*5)()
+    i = (ctypes.c_void_p*5)()
+    lib.od_hip_vtbl_fill.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.od_hip_vtbl_fill(f, i) == 0
+    assert all(f[k] and i[k] for k in range(4)) and not f[4] and not i[4]
+    o = oracle()
+    rng = np.random.default_rng(5)
+    for bs, n in enumerate((4, 8, 16, 32)):
+        plane = rng.integers(-3000, 3001, size=(40, 48), dtype=np.int32)
+        ref_p = plane.copy()
+        sub = plane[3:, 5:]
+        subr = ref_p[3:, 5:]
+        # in place, strided
+        hip.vtable_call('od_hip_bin_fdct%dx%d' % (n, n), sub, 48, sub, 48)
+        tmp = np.ascontiguousarray(subr[:n, :n])
+        out = np.zeros_like(tmp)
+        o.orc_fdct_2d(n, p32(out), n, p32(tmp), n)
+        subr[:n, :n] = out
+        assert np.array_equal(plane, ref_p)
+        hip.vtable_call('od_hip_bin_idct%dx%d' % (n, n), sub, 48, sub, 48)
+        o.orc_idct_2d(n, p32(tmp), n, p32(out), n)
+        subr[:n, :n] = tmp
+        assert np.array_equal(plane, ref_p)
+
+
+def test_filter4_haar_cfl(hip):
+    o = oracle()
+    g = golden('filter_vectors.npz')
+    assert np.array_equal(hip.od_pre_filter4(g['x']), g['pre'])
+    assert np.array_equal(hip.od_post_filter4(g['x']), g['post'])
+    rng = np.random.default_rng(9)
+    v = rng.integers(-100000, 100001, size=(50001, 4), dtype=np.int32)
+    pre = hip.od_pre_filter4(v)
+    exp = np.zeros_like(v)
+    for k in range(0, len(v), 97):
+        o.orc_pre_filter4(p32(exp[k]), p32(np.ascontiguousarray(v[k])))
+        assert np.array_equal(pre[k], exp[k])
+    assert np.array_equal(hip.od_post_filter4(pre), v)        # exact inversion
+    for bs, ln in enumerate((2, 3, 4, 5)):
+        n = 1 << ln
+        x = g['haar_x%d' % n]
+        y = hip.od_haar_blocks(bs, x)
+        assert np.array_equal(y, g['haar_y%d' % n])
+        assert np.array_equal(hip.od_haar_blocks(bs, y, inverse=True), x)
+    luma = g['cfl_luma']
+    for bs, cbs in ((0, 0), (0, 1), (1, 2), (2, 3)):
+        p = hip.od_resample_luma_coeffs_420(luma, 64, [0], bs, cbs)
+        assert np.array_equal(p[0], g['cfl_%d_%d' % (bs, cbs)])
+    # many blocks at different offsets against the oracle
+    offs = [(y*8)*64 + x*8 for y in range(3) for x in range(7)]
+    p = hip.od_resample_luma_coeffs_420(luma, 64, offs, 0, 0)
+    for k, off in enumerate(offs):
+        a = np.zeros((4, 4), np.int32)
+        o.orc_resample_luma_coeffs(p32(a), 4, p32(np.ascontiguousarray(luma).ravel()[off:]), 64,
+                                   1, 1, 0, 0)
+        assert np.array_equal(p[k], a)
+
+
+def oracle_pyramid(pix, fw, fh, dec, pic_w, pic_h):
+    o = oracle()
+    w, h = fw >> dec, fh >> dec
+    nlev = 4 - dec
+    lev = [np.zeros((h, w), np.int32) for _ in range(nlev)]
+    arr = (ctypes.POINTER(ctypes.c_int32)*nlev)(*[p32(a) for a in lev])
+    c = np.zeros((h, w), np.int32)
+    o.orc_forward_pyramid_plane(p32(c), arr, nlev, pu8(pix), w, fw//32, fh//32, dec, pic_w, pic_h)
+    return lev
+
+
+def test_forward_pyramid_golden_and_oracle(hip):
+    g = golden('plane_forward.npz')
+    pic_w, pic_h, fw, fh = [int(v) for v in g['geom']]
+    ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nplanes=2, xdec=(0, 1), nslots=2)
+    planes = [g['pix0'], g['pix1']]
+    ctx.upload_planes(0, planes)
+    ctx.upload_planes(1, [p[::-1].copy() for p in planes])     # a second, different frame
+    ctx.forward_pyramid()
+    for pli in (0, 1):
+        for k in range(ctx.nlevels(pli)):
+            assert np.array_equal(ctx.download_level(0, pli, k), g['lev%d_%d' % (pli, k)])
+        lev = oracle_pyramid(np.ascontiguousarray(planes[pli][::-1]), fw, fh, pli, pic_w, pic_h)
+        for k in range(ctx.nlevels(pli)):
+            assert np.array_equal(ctx.download_level(1, pli, k), lev[k])
+    ctx.close()
+
+
+def test_forward_known_golden_and_inverse_roundtrip(hip):
+    g = golden('plane_forward.npz')
+    pic_w, pic_h, fw, fh = [int(v) for v in g['geom']]
+    ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nplanes=2, xdec=(0, 1), nslots=1)
+    ctx.upload_planes(0, [g['pix0'], g['pix1']])
+    ctx.set_bsize(0, g['bsize'])
+    for kf in (1, 0):
+        ctx.forward_known(keyframe=kf)
+        for pli in (0, 1):
+            assert np.array_equal(ctx.download_coeffs(0, pli), g['d%d_kf%d' % (pli, kf)])
+    ctx.inverse()                      # coefficients of the last (non-keyframe) pass
+    for pli in (0, 1):
+        assert np.array_equal(ctx.download_recon(0, pli), g['pix%d' % pli])
+    ctx.close()
+
+
+def test_set_bsize_rejects_inconsistent_maps(hip):
+    ctx = hip.DaalaHip(64, 64, nplanes=1, xdec=(0,), nslots=1)
+    bad = np.zeros((8, 8), np.uint8)
+    bad[0, 0] = 3
+    with pytest.raises(hip.HipError):
+        ctx.set_bsize(0, bad)
+    with pytest.raises(hip.HipError):
+        ctx.forward_pyramid(slot0=0, nslots=2)      # slot range
+    ctx.close()
+
+
+def test_inverse_of_quantised_coefficients_matches_oracle(hip):
+    """The decoder case: coefficients that are NOT in the image of the forward
+    path (coarsely quantised), mixed block sizes, picture not a multiple of 32."""
+    o = oracle()
+    pic_w, pic_h, fw, fh = 150, 100, 192, 128
+    nhsb, nvsb = fw//32, fh//32
+    ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nplanes=2, xdec=(0, 1), nslots=1)
+    bmap = random_bsize_map(nhsb, nvsb, 123)
+    ctx.set_bsize(0, bmap)
+    planes = [synth_plane(fw, fh, 4), synth_plane(fw//2, fh//2, 4, 1)]
+    ctx.upload_planes(0, planes)
+    ctx.forward_known(keyframe=0)
+    for pli in (0, 1):
+        d = ctx.download_coeffs(0, pli)
+        q = 96
+        dq = (np.sign(d)*((np.abs(d) + q//2)//q)*q).astype(np.int32)
+        ctx.upload_coeffs(0, pli, dq)
+    ctx.inverse()
+    for pli in (0, 1):
+        h, w = ctx.plane_shape(pli)
+        dq = ctx.download_coeffs(0, pli)
+        out = np.zeros((h, w), np.uint8); c = np.zeros((h, w), np.int32)
+        o.orc_inverse_plane(pu8(out), w, p32(c), p32(dq), nhsb, nvsb, pli, pu8(bmap), nhsb*4,
+                            pic_w, pic_h)
+        assert np.array_equal(ctx.download_recon(0, pli), out)
+    ctx.close()
+
+
+def test_full_size_1080p_roundtrip_and_sampled_oracle(hip):
+    """BASELINE config 2 geometry (1920x1080 4:2:0, padded to 1920x1088): the
+    size-independent property forward(known) -> inverse == identity on the whole
+    frame, plus the pyramid checked against the oracle on the full frame."""
+    pic_w, pic_h, fw, fh = 1920, 1080, 1920, 1088
+    ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nslots=2)
+    planes = [synth_plane(fw, fh, 7), synth_plane(fw//2, fh//2, 7, 1), synth_plane(fw//2, fh//2, 8, 1)]
+    for s in range(2):
+        ctx.upload_planes(s, planes if s == 0 else [p[:, ::-1].copy() for p in planes])
+        ctx.set_bsize(s, random_bsize_map(fw//32, fh//32, 40 + s))
+    ctx.forward_known(keyframe=0)
+    ctx.inverse()
+    for pli in range(3):
+        assert np.array_equal(ctx.download_recon(0, pli), planes[pli])
+        assert np.array_equal(ctx.download_recon(1, pli), planes[pli][:, ::-1])
+    ctx.forward_pyramid()
+    for pli in (0, 1):
+        lev = oracle_pyramid(planes[pli], fw, fh, 1 if pli else 0, pic_w, pic_h)
+        for k in range(ctx.nlevels(pli)):
+            assert np.array_equal(ctx.download_level(0, pli, k), lev[k])
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
+def test_pvq_search_vectors(hip):
+    o = oracle()
+    g = golden('pvq_search.npz')
+    for n in (8, 15, 32, 128):
+        m = g['n'] == n
+        y, cd = hip.pvq_search_vectors(g['x'][m][:, :n], g['k'][m], g['g2'][m])
+        assert np.array_equal(y, g['y'][m][:, :n])
+        assert np.array_equal(cd, g['cos_dist'][m])          # bit-exact doubles
+    rng = np.random.default_rng(77)
+    for n in (7, 8, 14, 15, 16, 31, 32, 127, 128):
+        nv = 300
+        x = rng.laplace(0, 1, size=(nv, n))*np.exp(-np.arange(n)/7.)
+        x[::3] = rng.integers(-2, 3, size=(len(x[::3]), n))    # exact ties
+        k = rng.choice([1, 2, 3, 4, 8, 13, 33, 100, 260], size=nv).astype(np.int32)
+        g2 = rng.uniform(.05, 80, size=nv)
+        y, cd = hip.pvq_search_vectors(x, k, g2)
+        for i in range(nv):
+            yo = np.zeros(n, np.int32)
+            co = o.orc_pvq_search_rdo_double(pf64(np.ascontiguousarray(x[i])), n, int(k[i]), p32(yo),
+                                             float(g2[i]))
+            assert np.array_equal(y[i], yo), (n, i)
+            assert cd[i] == co, (n, i)
+
+
+def test_pvq_synthesis_noref(hip):
+    o = oracle()
+    rng = np.random.default_rng(81)
+    for n in (8, 15, 32, 128):
+        nv = 200
+        y = rng.integers(-4, 5, size=(nv, n), dtype=np.int32)
+        y[0] = 0
+        g = rng.uniform(1, 9000, size=nv)
+        qmi = rng.integers(3000, 16000, size=(nv, n)).astype(np.int16)
+        out = hip.pvq_synthesis_noref(y, g, qmi)
+        for i in range(nv):
+            e = np.zeros(n, np.int32)
+            o.orc_pvq_synthesis_partial(p32(e), p32(np.ascontiguousarray(y[i])), pf64(np.zeros(n)), n,
+                                        1, float(g[i]), 0., 0, 1, p16(np.ascontiguousarray(qmi[i])))
+            assert np.array_equal(out[i], e)
+
+
+def level_params(prm, tag, pli, bs, xdec):
+    q0 = int(prm['quantizer_' + tag][pli])
+    pq = prm['pvq_qm_q4_' + tag][pli]
+    off = {0: [1, 16], 1: [1, 16, 24, 32, 64], 2: [1, 16, 24, 32, 64, 96, 128, 256],
+           3: [1, 16, 24, 32, 64, 96, 128, 256, 384, 512]}[bs]
+    nb = len(off) - 1
+    q = [max(1, q0*int(pq[bs*(bs + 1) + (b + 1) - (b + 1)//3]) >> 4) for b in range(nb)]
+    masking = tag.endswith('m1')
+    beta = [1.5 if (masking and pli == 0 and bs > 0) else 1.0]*nb
+    n = 4 << bs
+    base = bs*2048 + xdec*1024
+    qm = prm['qm_' + tag][base:base + n*n]
+    return off, q, beta, np.ascontiguousarray(qm)
+
+
+@pytest.mark.parametrize('tag', ('q20_m0', 'q20_m1'))
+def test_pvq_noref_level_vs_oracle(hip, tag):
+    """Frame-wide no-reference candidates (state-free part of pvq_theta) for every
+    band of every block of every pyramid level, real -v 20 QM.  beta == 1 bands are
+    bit-exact in every field.  beta == 1.5 bands (luma >= 8x8 with activity
+    masking) go through the device pow(): cg is compared to 4 ulp (value parity
+    with glibc pow is not pinned) and the integer decisions
+    (qg, k, pulses) must still be identical."""
+    o = oracle()
+    prm = golden('encoder_params.npz')
+    pic_w, pic_h, fw, fh = 150, 100, 192, 128
+    ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nplanes=2, xdec=(0, 1), nslots=1)
+    planes = [synth_plane(fw, fh, 11), synth_plane(fw//2, fh//2, 11, 1)]
+    ctx.upload_planes(0, planes)
+    ctx.forward_pyramid()
+    for pli in (0, 1):
+        for level in range(ctx.nlevels(pli)):
+            n = (32 >> pli) >> level
+            bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+            off, q, beta, qm = level_params(prm, tag, pli, bs, pli)
+            ctx.pvq_noref_search(pli, level, qm, q, beta)
+            bands, ys = ctx.pvq_download(0, pli, level)
+            lev = ctx.download_level(0, pli, level)
+            h, w = lev.shape
+            nbx = w//n
+            rng = np.random.default_rng(level)
+            for blk in rng.choice(len(bands), size=min(len(bands), 60), replace=False):
+                by, bx = divmod(int(blk), nbx)
+                block = np.ascontiguousarray(lev[by*n:by*n + n, bx*n:bx*n + n])
+                co = np.zeros(n*n, np.int32)
+                o.orc_raster_to_coding_order(p32(co), n, p32(block), n)
+                for b in range(len(off) - 1):
+                    nn = off[b + 1] - off[b]
+                    x0 = np.ascontiguousarray(co[off[b]:off[b + 1]])
+                    cg = ctypes.c_double(); g = ctypes.c_double()
+                    qg = np.zeros(2, np.int32); k = np.zeros(2, np.int32)
+                    cd = np.zeros(2); dist = np.zeros(2); y = np.zeros((2, nn), np.int32)
+                    nc = o.orc_pvq_noref_candidates(
+                        p32(x0), nn, q[b], beta[b], p16(np.ascontiguousarray(qm[off[b]:off[b + 1]])),
+                        1, ctypes.byref(cg), ctypes.byref(g),
+                        qg.ctypes.data_as(ctypes.POINTER(c_int)),
+                        k.ctypes.data_as(ctypes.POINTER(c_int)), pf64(cd), pf64(dist), p32(y))
+                    r = bands[blk, b]
+                    assert r['g'] == g.value
+                    assert r['ncand'] == nc
+                    if beta[b] == 1.0:
+                        assert r['cg'] == cg.value
+                    else:
+                        assert abs(r['cg'] - cg.value) <= 4*np.spacing(abs(cg.value))
+                    for c in range(nc):
+                        assert r['qg'][c] == qg[c] and r['k'][c] == k[c]
+                        assert np.array_equal(ys[blk, c, off[b]:off[b + 1]], y[c])
+                        if beta[b] == 1.0:
+                            assert r['cos_dist'][c] == cd[c] and r['dist'][c] == dist[c]
+    ctx.close()
+
+
+def test_pvq_theta_golden_decisions_reachable(hip):
+    """tests/golden/pvq_theta_noref.npz holds the REFERENCE's pvq_theta outcome
+    for single bands; the device candidates for the same band must contain it."""
+    g = golden('pvq_theta_noref.npz')
+    prm = golden('encoder_params.npz')
+    for n in (8, 15, 32, 128):
+        idx = [i for i in range(len(g['n'])) if g['n'][i] == n and g['qg'][i] > 0 and g['beta'][i] == 1.0]
+        if not idx:
+            continue
+        xs, ks, g2s = [], [], []
+        for i in idx:
+            bs, off = int(g['bs'][i]), int(g['off'][i])
+            tag = 'q20_m%d' % int(g['masking'][i])
+            qm = prm['qm_' + tag][bs*2048 + off:bs*2048 + off + n].astype(np.int64)
+            x0 = g['x0'][i][:n].astype(np.int64)
+            x1 = (x0*qm).astype(np.float64)*(1./32767)
+            acc = 0.0
+            for v, m in zip(x0, qm):
+                acc += float(v)*float(v)*float(m)*(1./32767)*float(m)*(1./32767)
+            cg = np.sqrt(acc)/int(g['q'][i])
+            xs.append(x1); ks.append(int(g['k'][i])); g2s.append(float(g['qg'][i])*cg)
+        y, _ = hip.pvq_search_vectors(np.array(xs), np.array(ks, np.int32), np.array(g2s))
+        for j, i in enumerate(idx):
+            assert np.array_equal(y[j], g['y'][i][:n])

@@ -1,0 +1,161 @@
+"""CPU suite: pins the oracle restatement (oracle/daala_oracle.c) to the golden
+vectors committed under tests/golden/ (generated from the real reference by
+tools/gen_golden.py).  Needs neither /root/reference nor a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from testlib import GOLDEN, c_int, oracle, p16, p32, pf64, pu8
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.mark.parametrize('n', (4, 8, 16, 32))
+def test_dct_golden(n):
+    o = oracle()
+    g = load('dct_vectors.npz')
+    for x, yf, xi in zip(g['x%d' % n], g['fdct%d' % n], g['idct%d' % n]):
+        x = np.ascontiguousarray(x)
+        y = np.zeros_like(x)
+        o.orc_fdct_2d(n, p32(y), n, p32(x), n)
+        assert np.array_equal(y, yf)
+        o.orc_idct_2d(n, p32(y), n, p32(x), n)
+        assert np.array_equal(y, xi)
+
+
+def test_dcttest_anchor_recorded():
+    # the reference's own self-test passed on the oracle-of-record build and its
+    # stdout hash is the one SURVEY.md section 4 records
+    with open(os.path.join(GOLDEN, 'dcttest.md5')) as f:
+        assert f.read().startswith('eaace07761b6fd646b83285dfbdbc5c2')
+
+
+def test_filter_haar_cfl_golden():
+    o = oracle()
+    g = load('filter_vectors.npz')
+    for x, a, b in zip(g['x'], g['pre'], g['post']):
+        x = np.ascontiguousarray(x)
+        y = np.zeros(4, np.int32)
+        o.orc_pre_filter4(p32(y), p32(x))
+        assert np.array_equal(y, a)
+        o.orc_post_filter4(p32(y), p32(x))
+        assert np.array_equal(y, b)
+    for ln in (2, 3, 4, 5):
+        n = 1 << ln
+        for x, yy in zip(g['haar_x%d' % n], g['haar_y%d' % n]):
+            x = np.ascontiguousarray(x)
+            y = np.zeros_like(x)
+            o.orc_haar(p32(y), n, p32(x), n, ln)
+            assert np.array_equal(y, yy)
+            xb = np.zeros_like(x)
+            o.orc_haar_inv(p32(xb), n, p32(y), n, ln)
+            assert np.array_equal(xb, x)
+    luma = np.ascontiguousarray(g['cfl_luma'])
+    for bs, cbs in ((0, 0), (0, 1), (1, 2), (2, 3)):
+        n = 4 << bs
+        a = np.zeros((n, n), np.int32)
+        o.orc_resample_luma_coeffs(p32(a), n, p32(luma), 64, 1, 1, bs, cbs)
+        assert np.array_equal(a, g['cfl_%d_%d' % (bs, cbs)])
+
+
+def test_coding_order_golden():
+    o = oracle()
+    g = load('coding_order.npz')
+    for n in (4, 8, 16, 32):
+        src = np.arange(n*n, dtype=np.int32)
+        dst = np.full(n*n, -1, np.int32)
+        o.orc_raster_to_coding_order(p32(dst), n, p32(src), n)
+        t = g['n%d' % n]
+        assert np.array_equal(dst[:len(t)], t)
+
+
+def test_forward_plane_and_pyramid_golden():
+    o = oracle()
+    g = load('plane_forward.npz')
+    pic_w, pic_h, fw, fh = [int(v) for v in g['geom']]
+    nhsb, nvsb = fw//32, fh//32
+    bmap = np.ascontiguousarray(g['bsize'])
+    for pli in (0, 1):
+        dec = 1 if pli else 0
+        w, h = fw >> dec, fh >> dec
+        pix = np.ascontiguousarray(g['pix%d' % pli])
+        for kf in (0, 1):
+            c = np.zeros((h, w), np.int32); d = np.zeros((h, w), np.int32)
+            o.orc_forward_plane(p32(c), p32(d), pu8(pix), w, nhsb, nvsb, dec, pu8(bmap),
+                                nhsb*4, pic_w, pic_h, kf)
+            assert np.array_equal(d, g['d%d_kf%d' % (pli, kf)])
+            if kf == 0:
+                assert np.array_equal(c, g['c%d' % pli])
+        nlev = 4 - dec
+        lev = [np.zeros((h, w), np.int32) for _ in range(nlev)]
+        arr = (ctypes.POINTER(ctypes.c_int32)*nlev)(*[p32(a) for a in lev])
+        c = np.zeros((h, w), np.int32)
+        o.orc_forward_pyramid_plane(p32(c), arr, nlev, pu8(pix), w, nhsb, nvsb, dec, pic_w, pic_h)
+        for k in range(nlev):
+            assert np.array_equal(lev[k], g['lev%d_%d' % (pli, k)])
+        # and the inverse path restores the pixels exactly (non-keyframe coefficients)
+        d = np.ascontiguousarray(g['d%d_kf0' % pli])
+        out = np.zeros((h, w), np.uint8); c3 = np.zeros((h, w), np.int32)
+        o.orc_inverse_plane(pu8(out), w, p32(c3), p32(d), nhsb, nvsb, dec, pu8(bmap), nhsb*4,
+                            pic_w, pic_h)
+        assert np.array_equal(out, pix)
+
+
+def test_pvq_search_golden():
+    o = oracle()
+    g = load('pvq_search.npz')
+    for x, y, k, g2, cd, n in zip(g['x'], g['y'], g['k'], g['g2'], g['cos_dist'], g['n']):
+        n = int(n)
+        xx = np.ascontiguousarray(x[:n])
+        yy = np.zeros(n, np.int32)
+        c = o.orc_pvq_search_rdo_double(pf64(xx), n, int(k), p32(yy), float(g2))
+        assert np.array_equal(yy, y[:n]) and c == cd
+
+
+def noref_decide(o, x0, n, q, beta, qm, rate_fn):
+    """Candidates from the oracle + a rate callback -> (qg, k, y) like pvq_theta."""
+    cg = ctypes.c_double(); g = ctypes.c_double()
+    qg = np.zeros(2, np.int32); k = np.zeros(2, np.int32)
+    cd = np.zeros(2); dist = np.zeros(2); y = np.zeros((2, n), np.int32)
+    nc = o.orc_pvq_noref_candidates(p32(x0), n, q, beta, p16(qm), 1, ctypes.byref(cg),
+                                    ctypes.byref(g), qg.ctypes.data_as(ctypes.POINTER(c_int)),
+                                    k.ctypes.data_as(ctypes.POINTER(c_int)), pf64(cd), pf64(dist),
+                                    p32(y))
+    return nc, cg.value, qg, k, cd, dist, y
+
+
+def test_pvq_theta_noref_golden_candidates_contain_decision():
+    """Without the (adaptive, host-side) rate term the oracle cannot pick, but the
+    reference's decision must be one of its candidates (or the null vector), with
+    identical pulses, and the synthesised coefficients must match."""
+    o = oracle()
+    g = load('pvq_theta_noref.npz')
+    prm = load('encoder_params.npz')
+    hits = 0
+    for i in range(len(g['n'])):
+        n, bs, off = int(g['n'][i]), int(g['bs'][i]), int(g['off'][i])
+        tag = 'q20_m%d' % int(g['masking'][i])
+        qm = np.ascontiguousarray(prm['qm_' + tag][bs*2048 + off:bs*2048 + off + n])
+        qmi = np.ascontiguousarray(prm['qm_inv_' + tag][bs*2048 + off:bs*2048 + off + n])
+        x0 = np.ascontiguousarray(g['x0'][i][:n])
+        q, beta = int(g['q'][i]), float(g['beta'][i])
+        nc, cg, qg, k, cd, dist, y = noref_decide(o, x0, n, q, beta, qm, None)
+        qg_r, k_r = int(g['qg'][i]), int(g['k'][i])
+        if qg_r == 0:
+            assert not g['out'][i].any()
+            continue
+        sel = [c for c in range(nc) if qg[c] == qg_r]
+        assert len(sel) == 1
+        c = sel[0]
+        assert k[c] == k_r and np.array_equal(y[c], g['y'][i][:n])
+        gexp = o.orc_gain_expand(float(qg_r), q, beta)
+        out = np.zeros(n, np.int32)
+        o.orc_pvq_synthesis_partial(p32(out), p32(y[c]), pf64(np.zeros(n)), n, 1, gexp, 0., 0, 1,
+                                    p16(qmi))
+        assert np.array_equal(out, g['out'][i][:n])
+        hits += 1
+    assert hits > 50

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference build (oracle/_ref, compiled
+from /root/reference by oracle/Makefile).  Dev container only; the fixtures are
+committed so that the GPU box and later rounds need neither the reference nor
+this script.  Only DATA is stored: seeded inputs and the reference's outputs."""
+import ctypes
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from testlib import (c_int, p16, p32, pf64, pu8, random_bsize_map, ref,  # noqa: E402
+                     synth_plane)
+
+G = os.path.join(ROOT, 'tests', 'golden')
+r = ref()
+pp = ref('pvq_probe')
+ep = ref('enc_probe')
+rng = np.random.default_rng(20261004)
+
+
+def dct_vectors():
+    out = {}
+    for n in (4, 8, 16, 32):
+        xs = []
+        for amp in (255, 2047, 30000):
+            xs.append(rng.integers(-amp, amp + 1, size=(6, n, n), dtype=np.int32))
+        imp = np.zeros((2, n, n), np.int32)
+        imp[0, 0, 0] = 255 << 4
+        imp[1, n - 1, n - 1] = -(256 << 4)
+        x = np.concatenate(xs + [imp])
+        y = np.zeros_like(x)
+        xi = np.zeros_like(x)
+        for i in range(len(x)):
+            getattr(r, 'od_bin_fdct%dx%d' % (n, n))(p32(y[i]), n, p32(x[i]), n)
+            getattr(r, 'od_bin_idct%dx%d' % (n, n))(p32(xi[i]), n, p32(x[i]), n)
+        out['x%d' % n] = x
+        out['fdct%d' % n] = y
+        out['idct%d' % n] = xi
+    np.savez_compressed(os.path.join(G, 'dct_vectors.npz'), **out)
+
+
+def filter_vectors():
+    v = rng.integers(-40000, 40001, size=(512, 4), dtype=np.int32)
+    v[:64] = rng.integers(-4, 5, size=(64, 4))
+    pre = np.zeros_like(v)
+    post = np.zeros_like(v)
+    for i in range(len(v)):
+        r.od_pre_filter4(p32(pre[i]), p32(v[i]))
+        r.od_post_filter4(p32(post[i]), p32(v[i]))
+    ln_out = {}
+    for ln in (2, 3, 4, 5):
+        n = 1 << ln
+        x = rng.integers(-255, 256, size=(4, n, n), dtype=np.int32)
+        y = np.zeros_like(x)
+        for i in range(4):
+            r.od_haar(p32(y[i]), n, p32(x[i]), n, ln)
+        ln_out['haar_x%d' % n] = x
+        ln_out['haar_y%d' % n] = y
+    luma = rng.integers(-3000, 3001, size=(32, 64), dtype=np.int32)
+    cfl = {}
+    for bs, cbs in ((0, 0), (0, 1), (1, 2), (2, 3)):
+        n = 4 << bs
+        b = np.zeros((n, n), np.int32)
+        r.od_resample_luma_coeffs(p32(b), n, p32(luma), 64, 1, 1, bs, cbs)
+        cfl['cfl_%d_%d' % (bs, cbs)] = b
+    np.savez_compressed(os.path.join(G, 'filter_vectors.npz'), x=v, pre=pre, post=post,
+                        cfl_luma=luma, **ln_out, **cfl)
+
+
+def plane_forward():
+    pic_w, pic_h, fw, fh = 150, 100, 192, 128     # reference pads to multiples of 64
+    nhsb, nvsb = fw//32, fh//32
+    out = {'geom': np.array([pic_w, pic_h, fw, fh], np.int32)}
+    bmap = random_bsize_map(nhsb, nvsb, 77)
+    out['bsize'] = bmap
+    for pli in (0, 1):
+        dec = 1 if pli else 0
+        w, h = fw >> dec, fh >> dec
+        pix = synth_plane(w, h, seed=21 + pli, chroma=dec)
+        out['pix%d' % pli] = pix
+        for kf in (0, 1):
+            c = np.zeros((h, w), np.int32)
+            d = np.zeros((h, w), np.int32)
+            assert ep.probe_forward_plane(pic_w, pic_h, pli, kf, pu8(pix), pu8(bmap), p32(c),
+                                          p32(d)) == 0
+            out['d%d_kf%d' % (pli, kf)] = d
+            if kf == 0:
+                out['c%d' % pli] = c
+        # uniform maps = pyramid levels (see tests/test_oracle_vs_ref.py)
+        for bs in range(4 - dec):
+            um = np.full_like(bmap, 3 - bs)
+            c = np.zeros((h, w), np.int32)
+            d = np.zeros((h, w), np.int32)
+            assert ep.probe_forward_plane(pic_w, pic_h, pli, 0, pu8(pix), pu8(um), p32(c),
+                                          p32(d)) == 0
+            out['lev%d_%d' % (pli, bs)] = d
+    np.savez_compressed(os.path.join(G, 'plane_forward.npz'), **out)
+
+
+def pvq_vectors():
+    xs, ks, g2s, ys, cds, ns = [], [], [], [], [], []
+    for n in (8, 15, 32, 128):
+        for _ in range(40):
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                x = rng.laplace(0, 1, size=n)*np.exp(-np.arange(n)/9.)
+            elif kind == 1:
+                x = rng.integers(-3, 4, size=n).astype(np.float64)
+            else:
+                x = rng.integers(-300, 301, size=n)*rng.integers(9000, 32768, size=n)*(1./32767)
+            k = int(rng.choice([1, 2, 3, 5, 9, 20, 64, 200]))
+            g2 = float(rng.uniform(.1, 50))
+            y = np.zeros(n, np.int32)
+            cd = pp.probe_pvq_search_rdo_double(pf64(x), n, k, p32(y), g2)
+            xp = np.zeros(128)
+            xp[:n] = x
+            yp = np.zeros(128, np.int32)
+            yp[:n] = y
+            xs.append(xp); ys.append(yp); ks.append(k); g2s.append(g2); cds.append(cd); ns.append(n)
+    np.savez_compressed(os.path.join(G, 'pvq_search.npz'), x=np.array(xs), y=np.array(ys),
+                        k=np.array(ks, np.int32), g2=np.array(g2s), cos_dist=np.array(cds),
+                        n=np.array(ns, np.int32))
+
+
+def encoder_params():
+    out = {}
+    for quant in (5, 20):
+        for masking in (0, 1):
+            q = (c_int*3)()
+            pq = np.zeros(3*20, np.uint8)
+            qm = np.zeros(4*2*1024, np.int16)
+            qmi = np.zeros(4*2*1024, np.int16)
+            assert ep.probe_encoder_params(quant, masking, q, pu8(pq), p16(qm), p16(qmi)) == 0
+            tag = 'q%d_m%d' % (quant, masking)
+            out['quantizer_' + tag] = np.array(list(q), np.int32)
+            out['pvq_qm_q4_' + tag] = pq.reshape(3, 20)
+            out['qm_' + tag] = qm
+            out['qm_inv_' + tag] = qmi
+    np.savez_compressed(os.path.join(G, 'encoder_params.npz'), **out)
+
+
+def pvq_theta_decisions():
+    """Keyframe-luma pvq_theta outcomes with a null reference (no-ref branch) and a
+    freshly reset adaptation context, using the real QM of -v 20."""
+    prm = np.load(os.path.join(G, 'encoder_params.npz'))
+    recs = {'x0': [], 'n': [], 'bs': [], 'band': [], 'q': [], 'beta': [], 'qg': [], 'k': [],
+            'y': [], 'out': [], 'off': []}
+    offs = {0: [1, 16], 1: [1, 16, 24, 32, 64], 2: [1, 16, 24, 32, 64, 96, 128, 256],
+            3: [1, 16, 24, 32, 64, 96, 128, 256, 384, 512]}
+    for masking in (0, 1):
+        tag = 'q20_m%d' % masking
+        qm_all, qmi_all = prm['qm_' + tag], prm['qm_inv_' + tag]
+        q0 = int(prm['quantizer_' + tag][0])
+        pq = prm['pvq_qm_q4_' + tag][0]
+        for bs in range(4):
+            off = offs[bs]
+            for band in range(len(off) - 1):
+                n = off[band + 1] - off[band]
+                qm = np.ascontiguousarray(qm_all[bs*2048 + off[band]:bs*2048 + off[band] + n])
+                qmi = np.ascontiguousarray(qmi_all[bs*2048 + off[band]:bs*2048 + off[band] + n])
+                idx = bs*(bs + 1) + (band + 1) - (band + 1)//3
+                q = max(1, q0*int(pq[idx]) >> 4)
+                beta = 1.5 if (masking and bs > 0) else 1.0
+                for amp in (6, 60, 600):
+                    x0 = (rng.laplace(0, amp, size=n)*np.exp(-np.arange(n)/(n/2.))).astype(np.int32)
+                    out = np.zeros(n, np.int32); y = np.zeros(n, np.int32)
+                    it = c_int(); mt = c_int(); vk = c_int(); sd = ctypes.c_double(0)
+                    qg = pp.probe_pvq_theta(p32(out), p32(x0.copy()), p32(np.zeros(n, np.int32)), n,
+                                            q, p32(y), ctypes.byref(it), ctypes.byref(mt),
+                                            ctypes.byref(vk), beta, ctypes.byref(sd), 1, 1, 0, bs,
+                                            p16(qm), p16(qmi))
+                    pad = lambda a: np.concatenate([a, np.zeros(128 - n, np.int32)])  # noqa
+                    recs['x0'].append(pad(x0)); recs['y'].append(pad(y)); recs['out'].append(pad(out))
+                    recs['n'].append(n); recs['bs'].append(bs); recs['band'].append(band)
+                    recs['q'].append(q); recs['beta'].append(beta); recs['qg'].append(qg)
+                    recs['k'].append(vk.value); recs['off'].append(off[band])
+                    recs.setdefault('masking', []).append(masking)
+    np.savez_compressed(os.path.join(G, 'pvq_theta_noref.npz'),
+                        **{k: np.array(v) for k, v in recs.items()})
+
+
+def e2e_anchors():
+    """Whole-encoder anchors: packet bytes + FNV-1a of the reference bitstream for a
+    seeded synthetic CIF frame."""
+    w, h = 352, 288
+    fr = np.concatenate([synth_plane(w, h, 1).ravel(), synth_plane(w//2, h//2, 1, 1).ravel(),
+                         synth_plane(w//2, h//2, 2, 1).ravel()])
+    lines = []
+    for quant, masking in ((20, 1), (20, 0), (5, 1)):
+        fnv = ctypes.c_uint(); sec = ctypes.c_double()
+        ep.probe_encode_frames.restype = ctypes.c_long
+        nbytes = ep.probe_encode_frames(w, h, 1, quant, 7, masking, 1, pu8(fr), ctypes.byref(fnv),
+                                        ctypes.byref(sec), None, 0)
+        lines.append('cif synth seed1 q=%d masking=%d complexity=7: bytes=%d fnv1a=%08x'
+                     % (quant, masking, nbytes, fnv.value))
+    with open(os.path.join(G, 'e2e_anchors.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+
+
+def dcttest_md5():
+    out = subprocess.run([os.path.join(ROOT, 'oracle', '_ref', 'dcttest')], capture_output=True)
+    assert out.returncode == 0
+    md5 = hashlib.md5(out.stdout).hexdigest()
+    with open(os.path.join(G, 'dcttest.md5'), 'w') as f:
+        f.write('%s  dcttest stdout (reference src/dct.c:2192-3951, -DOD_DCT_TEST '
+                '-DOD_DCT_CHECK_OVERFLOW), %d lines\n' % (md5, out.stdout.count(b'\n')))
+    print(md5)
+
+
+if __name__ == '__main__':
+    dct_vectors()
+    filter_vectors()
+    plane_forward()
+    pvq_vectors()
+    encoder_params()
+    pvq_theta_decisions()
+    e2e_anchors()
+    if '--dcttest' in sys.argv:
+        dcttest_md5()
+    print('golden fixtures written to', G)
