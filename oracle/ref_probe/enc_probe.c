@@ -100,9 +100,15 @@ static daala_enc_ctx *make_encoder(int w, int h, int quant, int complexity,
    daala_encode_img_in + daala_encode_packet_out only.  If pkt_out != NULL the
    packets are appended there (up to pkt_cap bytes, each prefixed by a 4-byte
    little-endian length). */
-long probe_encode_frames(int w, int h, int nframes, int quant, int complexity,
+/* fdct_2d / idct_2d: optional replacement kernels installed into the context's
+   od_state_opt_vtbl after creation (entries 0..3) - the drop-in seam of
+   src/state.c:347-353 / src/x86/x86state.c:39-96 exercised at run time, without
+   touching the reference sources.  NULL keeps the pure-C tables. */
+long probe_encode_frames_vtbl(int w, int h, int nframes, int quant, int complexity,
  int masking, int keyrate, const unsigned char *frames, unsigned *fnv,
- double *seconds, unsigned char *pkt_out, long pkt_cap) {
+ double *seconds, unsigned char *pkt_out, long pkt_cap,
+ const od_dct_func_2d *fdct_2d, const od_dct_func_2d *idct_2d,
+ unsigned char *recon_out) {
   daala_enc_ctx *enc;
   od_img img;
   daala_packet dp;
@@ -113,6 +119,13 @@ long probe_encode_frames(int w, int h, int nframes, int quant, int complexity,
   size_t fsz = (size_t)w*h + 2*(size_t)cw*ch;
   enc = make_encoder(w, h, quant, complexity, masking, keyrate);
   if (enc == NULL) return -1;
+  if (fdct_2d != NULL && idct_2d != NULL) {
+    int i;
+    for (i = 0; i < OD_NBSIZES; i++) {
+      enc->state.opt_vtbl.fdct_2d[i] = fdct_2d[i];
+      enc->state.opt_vtbl.idct_2d[i] = idct_2d[i];
+    }
+  }
   memset(&img, 0, sizeof(img));
   img.nplanes = 3;
   img.width = w;
@@ -155,10 +168,30 @@ long probe_encode_frames(int w, int h, int nframes, int quant, int complexity,
     }
     t += now_s() - t0;
   }
+  if (recon_out != NULL) {
+    /* reconstruction of the last frame, visible area, Y U V dense */
+    od_img *rec = enc->state.ref_imgs + enc->state.ref_imgi[OD_FRAME_SELF];
+    unsigned char *o = recon_out;
+    int pli, y;
+    for (pli = 0; pli < 3; pli++) {
+      int pw = pli ? cw : w, ph = pli ? ch : h;
+      for (y = 0; y < ph; y++) {
+        memcpy(o, rec->planes[pli].data + (size_t)y*rec->planes[pli].ystride, pw);
+        o += pw;
+      }
+    }
+  }
   daala_encode_free(enc);
   if (fnv != NULL) *fnv = hsh;
   if (seconds != NULL) *seconds = t;
   return total;
+}
+
+long probe_encode_frames(int w, int h, int nframes, int quant, int complexity,
+ int masking, int keyrate, const unsigned char *frames, unsigned *fnv,
+ double *seconds, unsigned char *pkt_out, long pkt_cap) {
+  return probe_encode_frames_vtbl(w, h, nframes, quant, complexity, masking,
+   keyrate, frames, fnv, seconds, pkt_out, pkt_cap, NULL, NULL, NULL);
 }
 
 /* Per-frame encoder constants the device PVQ stage needs, read back after one
