@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--skip-pvq', action='store_true', help='profiling aid: transforms only (INVALID as a bench result)')
     args = ap.parse_args()
 
     import torch
@@ -153,8 +154,9 @@ def main():
 
     def step():
         ctx.forward_pyramid(0, FRAMES)
-        for pli, level, q, beta, qm in lvl:
-            ctx.pvq_noref_search(pli, level, qm, q, beta, 0, FRAMES)
+        if not args.skip_pvq:
+            for pli, level, q, beta, qm in lvl:
+                ctx.pvq_noref_search(pli, level, qm, q, beta, 0, FRAMES)
         ctx.forward_known(0, FRAMES, keyframe=1)
         ctx.inverse(0, FRAMES)
 
@@ -193,7 +195,8 @@ def main():
         'k_postfilter_clamp_chroma': FRAMES*s_c*5,
     }
     kernels = {}
-    for name in list(alg_bytes) + ['k_pvq_noref_level']:
+    pvq_names = ['k_pvq_noref<15>', 'k_pvq_noref<8>', 'k_pvq_noref<32>', 'k_pvq_noref<128>']
+    for name in list(alg_bytes) + pvq_names:
         n, ms = ctx.timing_get(name)
         if n:
             kernels[name] = {'launches': n, 'avg_ms': ms/n}
@@ -223,14 +226,15 @@ def main():
             'kernels': {k: {kk: round(vv, 4) if isinstance(vv, float) else vv
                             for kk, vv in v.items()} for k, v in kernels.items()},
         }
-        if 'k_pvq_noref_level' in kernels:
+        if any(nm in kernels for nm in pvq_names):
             # band vectors searched per second (each band = up to 2 gain candidates)
             nb = {0: 1, 1: 4, 2: 7, 3: 9}
             bands = 0
             for pli, level, q, beta, qm in lvl:
                 n = (32 >> ctx.xdec[pli]) >> level
                 bands += ctx.pvq_nblocks(pli, level)*nb[{4: 0, 8: 1, 16: 2, 32: 3}[n]]
-            tot_ms = kernels['k_pvq_noref_level']['avg_ms']*kernels['k_pvq_noref_level']['launches']
+            tot_ms = sum(kernels[nm]['avg_ms']*kernels[nm]['launches'] for nm in pvq_names
+                         if nm in kernels)
             line['pvq'] = {'bands_per_s': round(bands*FRAMES*args.steps/(tot_ms*1e-3), 1),
                            'bands_per_frame': bands,
                            'share_of_device_time': round(
@@ -245,6 +249,8 @@ def main():
             refenc = cpu_reference_encoder(frames, 3)
             if refenc:
                 line['cpu_reference_encoder'] = refenc
+        if args.skip_pvq:
+            line['INVALID'] = 'profiling run with --skip-pvq'
         print(json.dumps(line))
     ctx.close()
     if dist is not None:

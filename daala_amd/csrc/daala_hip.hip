@@ -16,6 +16,7 @@
 #include "xform_kernels.hpp"
 
 static_assert(sizeof(PvqBandRec) == sizeof(od_hip_pvq_band), "record layout");
+static_assert(sizeof(od_hip_pvq_band) == 72, "record layout");
 
 namespace {
 
@@ -135,9 +136,11 @@ struct od_hip_ctx {
   size_t bsize_sz;
   uint16_t *tab[OD_HIP_NBSIZES];             // coding tables on device
   int16_t *qm_dev;                           // scratch QM (1024 int16)
+  double *rsq;                               // 1/sqrt(i) table (pvq_rsqrt_tab)
+  int pvq_impl = 3;                          // 3 = register-resident, 2 = LDS-resident
   // PVQ results per (plane, level)
-  PvqBandRec *pvq_bands[OD_HIP_NPLANES_MAX][4];
-  int32_t *pvq_y[OD_HIP_NPLANES_MAX][4];
+  PvqSoA pvq[OD_HIP_NPLANES_MAX][4];         // device SoA, all slots
+  bool pvq_alloc[OD_HIP_NPLANES_MAX][4];
   // timing
   struct Span { hipEvent_t a, b; };
   std::map<std::string, std::vector<Span>> spans;
@@ -187,6 +190,25 @@ int check_slots(od_hip_ctx *ctx, int slot0, int nslots) {
   return 0;
 }
 
+}  // namespace
+
+namespace {
+template <int N>
+void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk, int nslots, hipStream_t s,
+                int impl, const double *rsq) {
+  if (impl == 2 || (impl == 3 && N == 32)) {   // N = 32: the LDS variant is faster (VGPR pressure)
+    dim3 grid((unsigned)((nblk + 63)/64), nlist, nslots);
+    hipLaunchKernelGGL(k_pvq_noref<N>, grid, dim3(64), 0, s, a);
+  }
+  else {
+    constexpr int BPW = PvqGeom<N>::BPW;
+    PvqLevelArgs3 aa;
+    aa.a = a;
+    aa.rsq = rsq;
+    dim3 grid((unsigned)((nblk + BPW - 1)/BPW), nlist, nslots);
+    hipLaunchKernelGGL(k_pvq_noref_v3<N>, grid, dim3(64), 0, s, aa);
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -323,11 +345,12 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   memset(ctx->d, 0, sizeof(ctx->d));
   memset(ctx->c, 0, sizeof(ctx->c));
   memset(ctx->rec, 0, sizeof(ctx->rec));
-  memset(ctx->pvq_bands, 0, sizeof(ctx->pvq_bands));
-  memset(ctx->pvq_y, 0, sizeof(ctx->pvq_y));
+  memset(ctx->pvq, 0, sizeof(ctx->pvq));
+  memset(ctx->pvq_alloc, 0, sizeof(ctx->pvq_alloc));
   memset(ctx->tab, 0, sizeof(ctx->tab));
   ctx->bsize = nullptr;
   ctx->qm_dev = nullptr;
+  ctx->rsq = nullptr;
   bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
   size_t ns = geo->nslots;
   for (int p = 0; ok && p < geo->nplanes; p++) {
@@ -346,6 +369,12 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   ok = ok && hipMalloc((void **)&ctx->bsize, ns*ctx->bsize_sz) == hipSuccess;
   ok = ok && hipMemset(ctx->bsize, 3, ns*ctx->bsize_sz) == hipSuccess;
   ok = ok && hipMalloc((void **)&ctx->qm_dev, 4*1024*sizeof(int16_t)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&ctx->rsq, PVQ_RSQ_TAB*sizeof(double)) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_pvq_fill_rsqrt, dim3(PVQ_RSQ_TAB/256), dim3(256), 0, ctx->stream, ctx->rsq);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  if (const char *e = getenv("OD_HIP_PVQ_IMPL")) ctx->pvq_impl = atoi(e);
   const uint16_t *tabs[4] = {CODING_TO_RASTER_4, CODING_TO_RASTER_8, CODING_TO_RASTER_16,
                              CODING_TO_RASTER_32};
   const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
@@ -373,13 +402,15 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
     if (ctx->c[p]) (void)hipFree(ctx->c[p]);
     if (ctx->rec[p]) (void)hipFree(ctx->rec[p]);
     for (int l = 0; l < 4; l++) {
-      if (ctx->pvq_bands[p][l]) (void)hipFree(ctx->pvq_bands[p][l]);
-      if (ctx->pvq_y[p][l]) (void)hipFree(ctx->pvq_y[p][l]);
+      PvqSoA &o = ctx->pvq[p][l];
+      void *ptrs[] = {o.cg, o.g, o.cos_dist, o.dist, o.qg, o.k, o.ncand, o.y};
+      for (void *q : ptrs) if (q) (void)hipFree(q);
     }
   }
   for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
   if (ctx->bsize) (void)hipFree(ctx->bsize);
   if (ctx->qm_dev) (void)hipFree(ctx->qm_dev);
+  if (ctx->rsq) (void)hipFree(ctx->rsq);
   for (auto &kv : ctx->spans) for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ctx->pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -612,10 +643,18 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
   size_t ns = ctx->geo.nslots;
   PvqLevelArgs a;
   a.nbands = od_hip_band_offsets(bs, a.off);
-  if (!ctx->pvq_bands[pli][level]) {
-    HIPCHK(hipMalloc((void **)&ctx->pvq_bands[pli][level],
-                     ns*nblk*a.nbands*sizeof(PvqBandRec)));
-    HIPCHK(hipMalloc((void **)&ctx->pvq_y[pli][level], ns*nblk*2*ncoded*sizeof(int32_t)));
+  size_t nrec = (size_t)a.nbands*nblk, ny = (size_t)2*nblk*(ncoded - 1);
+  PvqSoA &o = ctx->pvq[pli][level];
+  if (!ctx->pvq_alloc[pli][level]) {
+    HIPCHK(hipMalloc((void **)&o.cg, ns*nrec*8));
+    HIPCHK(hipMalloc((void **)&o.g, ns*nrec*8));
+    HIPCHK(hipMalloc((void **)&o.cos_dist, ns*2*nrec*8));
+    HIPCHK(hipMalloc((void **)&o.dist, ns*2*nrec*8));
+    HIPCHK(hipMalloc((void **)&o.qg, ns*2*nrec*4));
+    HIPCHK(hipMalloc((void **)&o.k, ns*2*nrec*4));
+    HIPCHK(hipMalloc((void **)&o.ncand, ns*nrec*4));
+    HIPCHK(hipMalloc((void **)&o.y, ns*ny*4));
+    ctx->pvq_alloc[pli][level] = true;
   }
   HIPCHK(hipMemcpyAsync(ctx->qm_dev + bs*1024, qm, (size_t)n*n*sizeof(int16_t),
                         hipMemcpyHostToDevice, ctx->stream));
@@ -628,15 +667,32 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
   for (int i = 0; i < a.nbands; i++) { a.q[i] = q[i]; a.beta[i] = beta[i]; }
   a.tab = ctx->tab[bs];
   a.qm = ctx->qm_dev + bs*1024;
-  a.bands = ctx->pvq_bands[pli][level] + (size_t)slot0*nblk*a.nbands;
-  a.y = ctx->pvq_y[pli][level] + (size_t)slot0*nblk*2*ncoded;
-  a.ncoded = ncoded;
-  dim3 grid((nblk + 63)/64, a.nbands, nslots);
-  {
-    Timed tm(ctx, "k_pvq_noref_level");
-    hipLaunchKernelGGL(k_pvq_noref_level, grid, dim3(64), 0, ctx->stream, a);
+  a.rec_fstride = nrec;
+  a.y_fstride = ny;
+  a.out.cg = o.cg + slot0*nrec;
+  a.out.g = o.g + slot0*nrec;
+  a.out.ncand = o.ncand + slot0*nrec;
+  a.out.cos_dist = o.cos_dist + slot0*2*nrec;
+  a.out.dist = o.dist + slot0*2*nrec;
+  a.out.qg = o.qg + slot0*2*nrec;
+  a.out.k = o.k + slot0*2*nrec;
+  a.out.y = o.y + slot0*ny;
+  // one launch per distinct band size (the no-reference sizes are 15, 8, 32, 128)
+  static const int sizes[4] = {15, 8, 32, 128};
+  for (int si = 0; si < 4; si++) {
+    int nlist = 0;
+    for (int b = 0; b < a.nbands; b++) {
+      if (a.off[b + 1] - a.off[b] == sizes[si]) a.band_list[nlist++] = b;
+    }
+    if (!nlist) continue;
+    switch (sizes[si]) {
+      case 15: { Timed tm(ctx, "k_pvq_noref<15>"); launch_pvq<15>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
+      case 8: { Timed tm(ctx, "k_pvq_noref<8>"); launch_pvq<8>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
+      case 32: { Timed tm(ctx, "k_pvq_noref<32>"); launch_pvq<32>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
+      default: { Timed tm(ctx, "k_pvq_noref<128>"); launch_pvq<128>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
+    }
+    HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -645,20 +701,52 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
   if (int rc = check_plane(ctx, slot, pli)) return rc;
   int nblk = od_hip_pvq_nblocks(ctx, pli, level);
   if (nblk < 0) return nblk;
-  if (!ctx->pvq_bands[pli][level]) return fail(OD_HIP_EINVAL, "no PVQ results for this level");
+  if (!ctx->pvq_alloc[pli][level]) return fail(OD_HIP_EINVAL, "no PVQ results for this level");
   int n = (32 >> ctx->geo.xdec[pli]) >> level;
   int bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
   int off[11];
   int nb = od_hip_band_offsets(bs, off);
   int ncoded = n*n < 512 ? n*n : 512;
+  size_t nrec = (size_t)nb*nblk, ny = (size_t)2*nblk*(ncoded - 1);
+  PvqSoA &o = ctx->pvq[pli][level];
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (bands) {
-    HIPCHK(hipMemcpy(bands, ctx->pvq_bands[pli][level] + (size_t)slot*nblk*nb,
-                     (size_t)nblk*nb*sizeof(PvqBandRec), hipMemcpyDeviceToHost));
+    std::vector<double> cg(nrec), g(nrec), cd(2*nrec), di(2*nrec);
+    std::vector<int32_t> qg(2*nrec), k(2*nrec), nc(nrec);
+    HIPCHK(hipMemcpy(cg.data(), o.cg + slot*nrec, nrec*8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g.data(), o.g + slot*nrec, nrec*8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cd.data(), o.cos_dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(di.data(), o.dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(qg.data(), o.qg + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(k.data(), o.k + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nc.data(), o.ncand + slot*nrec, nrec*4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; b++) {
+      for (int blk = 0; blk < nblk; blk++) {
+        size_t r = (size_t)b*nblk + blk;
+        od_hip_pvq_band &d = bands[(size_t)blk*nb + b];
+        d.cg = cg[r]; d.g = g[r]; d.ncand = nc[r]; d.pad = 0;
+        for (int c = 0; c < 2; c++) {
+          d.cos_dist[c] = cd[c*nrec + r]; d.dist[c] = di[c*nrec + r];
+          d.qg[c] = qg[c*nrec + r]; d.k[c] = k[c*nrec + r];
+        }
+      }
+    }
   }
   if (y) {
-    HIPCHK(hipMemcpy(y, ctx->pvq_y[pli][level] + (size_t)slot*nblk*2*ncoded,
-                     (size_t)nblk*2*ncoded*sizeof(int32_t), hipMemcpyDeviceToHost));
+    // device: band-major [band][cand][block][n_b]  ->  API: [block][cand][ncoded]
+    std::vector<int32_t> yd(ny);
+    HIPCHK(hipMemcpy(yd.data(), o.y + slot*ny, ny*4, hipMemcpyDeviceToHost));
+    memset(y, 0, (size_t)nblk*2*ncoded*sizeof(int32_t));
+    for (int b = 0; b < nb; b++) {
+      int nbnd = off[b + 1] - off[b];
+      const int32_t *src = yd.data() + (size_t)2*nblk*(off[b] - 1);
+      for (int c = 0; c < 2; c++) {
+        for (int blk = 0; blk < nblk; blk++) {
+          memcpy(y + ((size_t)blk*2 + c)*ncoded + off[b],
+                 src + ((size_t)c*nblk + blk)*nbnd, nbnd*sizeof(int32_t));
+        }
+      }
+    }
   }
   return 0;
 }

@@ -141,7 +141,7 @@ __global__ void k_pvq_synthesis_noref(int n, int nvec, const int32_t *__restrict
   }
 }
 
-struct PvqBandRec {      // mirrors od_hip_pvq_band (include/daala_hip.h)
+struct PvqBandRec {      // mirrors od_hip_pvq_band (include/daala_hip.h); host-side AoS
   double cg, g;
   double cos_dist[2];
   double dist[2];
@@ -151,71 +151,574 @@ struct PvqBandRec {      // mirrors od_hip_pvq_band (include/daala_hip.h)
   int32_t pad;
 };
 
+// Device-side result layout of one (plane, level), per frame slot: structure of
+// arrays, band-major, so that a wave (64 consecutive blocks of one band) writes
+// contiguous memory.  All arrays are [band][block]:
+struct PvqSoA {
+  double *cg, *g;           // [nbands*nblk]
+  double *cos_dist, *dist;  // [2][nbands*nblk] per frame
+  int32_t *qg, *k;          // [2][nbands*nblk] per frame
+  int32_t *ncand;           // [nbands*nblk]
+  // pulses: band b occupies y + 2*nblk*(off[b]-1), laid out [cand][block][n_b]
+  int32_t *y;
+};
+
 struct PvqLevelArgs {
   const int32_t *lev;      // level plane, frame 0
   size_t lev_fstride;      // elements between frames
   int w;                   // plane stride
   int n;                   // block size
   int nbx, nby;            // blocks per row / column
-  int nbands;
+  int nbands;              // bands of this block size
   int off[11];             // band boundaries (coding order)
   int q[10];
   double beta[10];
+  int band_list[10];       // bands handled by this launch (all of size N)
   const uint16_t *tab;     // coding index -> raster offset (y*n + x)
   const int16_t *qm;       // n*n, coding order
-  PvqBandRec *bands;       // [frame][block][band]
-  int32_t *y;              // [frame][block][cand][ncoded]
-  int ncoded;
+  PvqSoA out;              // frame 0
+  size_t rec_fstride;      // nbands*nblk (elements between frames of the record arrays)
+  size_t y_fstride;        // 2*nblk*(ncoded-1)
 };
 
-// No-reference candidates of every (block, band) of one pyramid level: the
-// state-free part of pvq_theta (src/pvq_encoder.c:352-357, :452-481).
-// Thread layout: x = block within frame (fastest), y = band, z = frame, so a
-// wave holds the same band of 64 neighbouring blocks (uniform n).
-__global__ __launch_bounds__(64) void k_pvq_noref_level(PvqLevelArgs a) {
-  const long blk = (long)blockIdx.x*blockDim.x + threadIdx.x;
-  const int band = blockIdx.y, f = blockIdx.z;
+// No-reference candidates of every (block, band) of one pyramid level for the
+// bands of size N: the state-free part of pvq_theta (src/pvq_encoder.c:352-357,
+// :452-481).  One wave per workgroup; lane = block, so a wave holds the same
+// band of 64 consecutive blocks.  Per-lane vectors live in LDS as [j][lane]
+// (stride 65: conflict free both for the per-lane scans and for the transposed
+// cooperative output): P = x0[j]*qm[j] (the reference's int*int product, :455),
+// Y = pulses.  |x_j| is recomputed as fabs((double)P*S) where needed, so a 128-
+// coefficient band costs 66.5 KB of LDS per wave (2 waves per CU).
+template <int N>
+__global__ __launch_bounds__(64) void k_pvq_noref(PvqLevelArgs a) {
+  constexpr int LD = 65;
+  __shared__ int32_t P[N*LD];
+  __shared__ int32_t Y[N*LD];
+  const int lane = threadIdx.x;
+  const long blk0 = (long)blockIdx.x*64;
+  const long blk = blk0 + lane;
+  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
   const long nblk = (long)a.nbx*a.nby;
-  if (blk >= nblk) return;
-  const int bx = blk%a.nbx, by = blk/a.nbx;
-  const int o0 = a.off[band], nn = a.off[band + 1] - o0;
-  const int32_t *src = a.lev + (size_t)f*a.lev_fstride + (size_t)(by*a.n)*a.w + bx*a.n;
+  const bool live = blk < nblk;
+  const int o0 = a.off[band];
   const int16_t *qm = a.qm + o0;
   const int q0 = a.q[band];
   const double beta = a.beta[band];
-  int32_t x0[PVQ_MAXN];
-  double x1[PVQ_MAXN], xa[PVQ_MAXN];
+  // scalar arrays: [frame][band][block]; per-candidate arrays: [frame][cand][band][block]
+  const size_t rin = (size_t)band*nblk + (live ? blk : 0);
+  const size_t rec = (size_t)f*a.rec_fstride + rin;
+  const size_t rec2 = (size_t)f*2*a.rec_fstride + rin;
+  const size_t recs = a.rec_fstride;
   double acc = 0;
-  for (int i = 0; i < nn; i++) {
-    int ro = a.tab[o0 + i];
-    int32_t c = src[(size_t)(ro/a.n)*a.w + (ro%a.n)];
-    x0[i] = c;
-    // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
-    acc += c*(double)c*qm[i]*PVQ_QM_SCALE_1*qm[i]*PVQ_QM_SCALE_1;
+  if (live) {
+    const int bx = blk%a.nbx, by = blk/a.nbx;
+    const int32_t *src = a.lev + (size_t)f*a.lev_fstride + (size_t)(by*a.n)*a.w + bx*a.n;
+    for (int i = 0; i < N; i++) {
+      const int ro = a.tab[o0 + i];
+      const int32_t c = src[(size_t)(ro/a.n)*a.w + (ro%a.n)];
+      const int qi = qm[i];
+      // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
+      acc += c*(double)c*qi*PVQ_QM_SCALE_1*qi*PVQ_QM_SCALE_1;
+      P[i*LD + lane] = c*qi;
+    }
   }
   const double g = sqrt(acc);
   const double cg = pvq_gain_compand(g, q0, beta);
-  for (int i = 0; i < nn; i++) x1[i] = x0[i]*qm[i]*PVQ_QM_SCALE_1;   // int*int first
-  PvqBandRec rec;
-  rec.cg = cg; rec.g = g; rec.pad = 0;
-  rec.qg[0] = rec.qg[1] = 0; rec.k[0] = rec.k[1] = 0;
-  rec.cos_dist[0] = rec.cos_dist[1] = 0; rec.dist[0] = rec.dist[1] = 0;
-  int32_t *ybase = a.y + (((size_t)f*nblk + blk)*2)*a.ncoded + o0;
+  // |x|, sum of squares and L1 norm are the same for both gain candidates
+  double xx = 0, l1 = 0;
+  if (live) {
+    for (int j = 0; j < N; j++) {
+      const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
+      xx += xj*xj;
+      l1 += xj;
+    }
+  }
+  const double norm_1 = 1./sqrt(1e-30 + xx);
+  const double l1_inv = 1./(l1 > 1e-100 ? l1 : 1e-100);
+  const double delta_rate = 3./N;
   int nc = 0;
   int i0 = (int)floor(cg);
   if (i0 < 1) i0 = 1;
-  for (int i = i0; i <= ceil(cg) && nc < 2; i++, nc++) {
-    const double qcg = i;
-    const int k = pvq_k_noref(qcg, nn, beta);
-    int32_t yp[PVQ_MAXN];
-    const double cd = pvq_search_dev(x1, xa, nn, k, yp, qcg*cg);
-    rec.qg[nc] = i;
-    rec.k[nc] = k;
-    rec.cos_dist[nc] = cd;
-    rec.dist[nc] = 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd);
-    int32_t *yo = ybase + (size_t)nc*a.ncoded;
-    for (int j = 0; j < nn; j++) yo[j] = yp[j];
+  const int i1 = live ? (int)ceil(cg) : 0;       // loop bound `i <= ceil(cg)`
+  for (int c = 0; c < 2; c++) {
+    const int gi = i0 + c;
+    const bool has = live && gi <= i1;           // wave-uniform loop, lanes masked
+    int k = 0;
+    double xy = 0, yy = 0, lambda = 0, qcg = gi;
+    int i = 0;
+    if (has) {
+      k = pvq_k_noref(qcg, N, beta);
+      lambda = PVQ_LAMBDA/(1e-30 + qcg*cg);
+      if (k > 2) {
+        for (int j = 0; j < N; j++) {
+          const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
+          int p = (int)floor(k*xj*l1_inv);
+          p = p > 0 ? p : 0;
+          Y[j*LD + lane] = p;
+          xy += xj*p;
+          yy += p*p;
+          i += p;
+        }
+      }
+      else {
+        for (int j = 0; j < N; j++) Y[j*LD + lane] = 0;
+      }
+    }
+    const int rdo_pulses = 1 + k/4;
+    // greedy phase (src/pvq_encoder.c:168-190)
+    for (; i < k - rdo_pulses; i++) {
+      int pos = 0;
+      double best_xy = -10, best_yy = 1;
+#pragma unroll 4
+      for (int j = 0; j < N; j++) {
+        const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
+        double txy = xy + xj;
+        const double tyy = yy + 2*Y[j*LD + lane] + 1;
+        txy *= txy;
+        if (j == 0 || txy*best_yy > best_xy*tyy) {
+          best_xy = txy;
+          best_yy = tyy;
+          pos = j;
+        }
+      }
+      const int yp = Y[pos*LD + lane];
+      xy = xy + fabs(P[pos*LD + lane]*PVQ_QM_SCALE_1);
+      yy = yy + 2*yp + 1;
+      Y[pos*LD + lane] = yp + 1;
+    }
+    // RDO phase (src/pvq_encoder.c:195-220); the reference tabulates
+    // rsqrt(yy + 2y + 1) for y = 0..3 per pulse (:205) - same values, same here.
+    for (; i < k; i++) {
+      int pos = 0;
+      double best_cost = -1e5;
+      const double r0 = pvq_rsqrt_small((int)(yy + 1)), r1 = pvq_rsqrt_small((int)(yy + 3));
+      const double r2 = pvq_rsqrt_small((int)(yy + 5)), r3 = pvq_rsqrt_small((int)(yy + 7));
+#pragma unroll 4
+      for (int j = 0; j < N; j++) {
+        const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
+        const int yj = Y[j*LD + lane];
+        double txy = xy + xj;
+        const double rs = yj == 0 ? r0 : yj == 1 ? r1 : yj == 2 ? r2 : yj == 3 ? r3
+                          : pvq_rsqrt_small((int)(yy + 2*yj + 1));
+        txy = 2*txy*norm_1*rs - lambda*j*delta_rate;
+        if (j == 0 || txy > best_cost) {
+          best_cost = txy;
+          pos = j;
+        }
+      }
+      const int yp = Y[pos*LD + lane];
+      xy = xy + fabs(P[pos*LD + lane]*PVQ_QM_SCALE_1);
+      yy = yy + 2*yp + 1;
+      Y[pos*LD + lane] = yp + 1;
+    }
+    if (has) {
+      const double cd = xy/(1e-100 + sqrt(xx*yy));
+      a.out.qg[c*recs + rec2] = gi;
+      a.out.k[c*recs + rec2] = k;
+      a.out.cos_dist[c*recs + rec2] = cd;
+      a.out.dist[c*recs + rec2] = 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd);
+      nc++;
+    }
+    else if (live) {
+      a.out.qg[c*recs + rec2] = 0;
+      a.out.k[c*recs + rec2] = 0;
+      a.out.cos_dist[c*recs + rec2] = 0;
+      a.out.dist[c*recs + rec2] = 0;
+      for (int j = 0; j < N; j++) Y[j*LD + lane] = 0;
+    }
+    __syncthreads();
+    // cooperative, coalesced store of the signed pulses of this candidate:
+    // [cand][block][N] is contiguous over the wave's 64 blocks.
+    {
+      int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) +
+                    ((size_t)c*nblk + blk0)*N;
+      const long lim = (nblk - blk0 < 64 ? nblk - blk0 : 64)*N;
+      for (int e = lane; e < lim; e += 64) {
+        const int b = e/N, j = e%N;
+        const int v = Y[j*LD + b];
+        yo[e] = P[j*LD + b] < 0 ? -v : v;
+      }
+    }
+    __syncthreads();
   }
-  rec.ncand = nc;
-  a.bands[((size_t)f*nblk + blk)*a.nbands + band] = rec;
+  if (live) {
+    a.out.cg[rec] = cg;
+    a.out.g[rec] = g;
+    a.out.ncand[rec] = nc;
+  }
+}
+
+// ===========================================================================
+// v3: register-resident search.  A band of N coefficients is owned by G lanes
+// (G = 1 for N <= 32, G = 4 for N = 127/128), NL = ceil(N/G) consecutive
+// coefficients per lane, all in VGPRs (every array index is a compile-time
+// constant after unrolling).  Exactness:
+//   * floating-point sums (gain, xx, l1, projection xy) are order dependent, so
+//     they run as ONE sequential chain in index order; with G > 1 the running sum
+//     is handed from lane g to lane g+1 (G rounds in lock step).
+//   * RDO-phase argmax compares plain doubles with strict '>' and first-index
+//     wins: a total order, so per-lane scans + an ordered combine are exact.
+//   * greedy-phase argmax uses the reference's cross-multiplied compare
+//     fl(a_j*b_best) > fl(a_best*b_j), which is NOT guaranteed transitive under
+//     rounding.  With G > 1 the per-lane scans + ordered combine give a candidate
+//     w; w is then VERIFIED: it is the sequential result if it strictly beats
+//     every earlier element and no later element strictly beats it.  If any band
+//     of the wave fails the check (only possible at ~1-ulp near-ties) the wave
+//     redoes that pulse with the literal sequential scan (lane to lane hand-off).
+// ===========================================================================
+
+// 1/sqrt(i) table (i < PVQ_RSQ_TAB) filled on the device by k_pvq_fill_rsqrt with
+// the same operations as pvq_rsqrt_small, so lookups are bit-identical.
+#define PVQ_RSQ_TAB 4096
+__global__ void k_pvq_fill_rsqrt(double *tab) {
+  int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < PVQ_RSQ_TAB) tab[i] = i >= 1 ? pvq_rsqrt_small(i) : 0;
+}
+
+__device__ __attribute__((noinline)) double pvq_rsqrt_slow(int i) {
+  return 1./sqrt((double)i);
+}
+
+__device__ __forceinline__ double pvq_rsqrt_tab(const double *tab, int i) {
+  if (__builtin_expect(i < PVQ_RSQ_TAB, 1)) return tab[i];
+  return pvq_rsqrt_slow(i);
+}
+
+template <int N>
+struct PvqGeom {
+  static constexpr int G = N > 32 ? 4 : 1;
+  static constexpr int NL = (N + G - 1)/G;
+  static constexpr int BPW = 64/G;               // bands per wave
+};
+
+// Per-band search state shared by all candidates of one input vector.
+template <int N>
+struct PvqVec {
+  static constexpr int NL = PvqGeom<N>::NL;
+  double x[NL];        // |x_j| of this lane's chunk, 0 beyond the band
+  uint32_t neg;        // sign bits of the chunk
+  double xx, l1_inv, norm_1;
+};
+
+// Sequential-order sum of term(j) over the whole band, result on every lane.
+template <int N, typename F>
+__device__ __forceinline__ double pvq_chain_sum(int g, int lane, F term) {
+  constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL;
+  double acc = 0;
+  if (G == 1) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) acc += term(j);
+    return acc;
+  }
+#pragma unroll
+  for (int r = 0; r < G; r++) {
+    if (g == r) {
+#pragma unroll
+      for (int j = 0; j < NL; j++) {
+        if (r*NL + j < N) acc += term(j);
+      }
+    }
+    if (r + 1 < G) {
+      double up = __shfl_up(acc, 1, 64);
+      if (g == r + 1) acc = up;
+    }
+  }
+  return __shfl(acc, (lane/G)*G + G - 1, 64);
+}
+
+template <int N>
+__device__ __forceinline__ void pvq_vec_finish(PvqVec<N> &v, int g, int lane) {
+  v.xx = pvq_chain_sum<N>(g, lane, [&](int j) { return v.x[j]*v.x[j]; });
+  double l1 = pvq_chain_sum<N>(g, lane, [&](int j) { return v.x[j]; });
+  v.norm_1 = 1./sqrt(1e-30 + v.xx);
+  v.l1_inv = 1./(l1 > 1e-100 ? l1 : 1e-100);
+}
+
+// One codeword search (pvq_search_rdo_double, src/pvq_encoder.c:121-225) for the
+// band owned by this lane group.  `act`: this band really has a candidate (lanes
+// of inactive bands run with k = 0).  Returns the cosine distance; y = unsigned
+// pulses of this lane's chunk.
+template <int N>
+__device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int lane, int k,
+                                                double g2, const double *rsq,
+                                                int (&y)[PvqGeom<N>::NL]) {
+  constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL;
+  const int base = (lane/G)*G;                  // first lane of my band
+  const int nvalid = (N - g*NL) < NL ? (N - g*NL) : NL;
+  const double lambda = PVQ_LAMBDA/(1e-30 + g2);
+  const double delta_rate = 3./N;
+  double xy = 0, yy = 0;
+  int i = 0;
+  if (k > 2) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      int p = (int)floor(k*v.x[j]*v.l1_inv);
+      y[j] = p > 0 ? p : 0;
+    }
+    xy = pvq_chain_sum<N>(g, lane, [&](int j) { return v.x[j]*y[j]; });
+    int s2 = 0, s1 = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) { s2 += y[j]*y[j]; s1 += y[j]; }
+    if (G > 1) {
+      s2 += __shfl_xor(s2, 1, 64); s1 += __shfl_xor(s1, 1, 64);
+      s2 += __shfl_xor(s2, 2, 64); s1 += __shfl_xor(s1, 2, 64);
+    }
+    // yy accumulates exact integers in double (< 2^53): any order is exact.
+    // NOTE: the reference adds ypulse[j]*ypulse[j] as int products one by one;
+    // each partial sum is an exactly representable integer, so the value is the same.
+    yy = (double)s2;
+    i = s1;
+  }
+  else {
+#pragma unroll
+    for (int j = 0; j < NL; j++) y[j] = 0;
+  }
+  const int rdo_pulses = 1 + k/4;
+  // ---- greedy phase ----------------------------------------------------------
+  // wave-uniform trip count: bands that are done idle (masked) meanwhile
+  while (__any(i < k - rdo_pulses)) {
+    const bool run = i < k - rdo_pulses;
+    double ba = 0, bb = 1;
+    int bpos = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      if (G*NL == N || j < nvalid) {
+        double a = xy + v.x[j];
+        const double b = yy + (2*y[j] + 1);
+        a *= a;
+        if (j == 0 || a*bb > ba*b) { ba = a; bb = b; bpos = j; }
+      }
+    }
+    int wl = bpos, wg = 0;            // winner: local index and owning lane group index
+    if (G > 1) {
+      double ca = __shfl(ba, base, 64), cb = __shfl(bb, base, 64);
+      int cp = __shfl(bpos, base, 64);
+      wg = 0;
+#pragma unroll
+      for (int r = 1; r < G; r++) {
+        const double ra = __shfl(ba, base + r, 64), rb = __shfl(bb, base + r, 64);
+        const int rp = __shfl(bpos, base + r, 64);
+        if (ra*cb > ca*rb) { ca = ra; cb = rb; cp = rp; wg = r; }
+      }
+      wl = cp;
+      // verification: w = (wg, wl) must strictly beat every earlier element and
+      // must not be strictly beaten by any later one
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < NL; j++) {
+        if (j < nvalid) {
+          double a = xy + v.x[j];
+          const double b = yy + (2*y[j] + 1);
+          a *= a;
+          const bool before = g < wg || (g == wg && j < wl);
+          const bool after = g > wg || (g == wg && j > wl);
+          if (before) ok = ok && (ca*b > a*cb);
+          if (after) ok = ok && !(a*cb > ca*b);
+        }
+      }
+      if (__any(run && !ok)) {
+        // literal sequential scan, incumbent handed from lane to lane
+        double ia = 0, ib = 1;
+        int ip = 0, ig = 0;
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+          if (g == r) {
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+              if (j < nvalid) {
+                double a = xy + v.x[j];
+                const double b = yy + (2*y[j] + 1);
+                a *= a;
+                if ((r == 0 && j == 0) || a*ib > ia*b) { ia = a; ib = b; ip = j; ig = r; }
+              }
+            }
+          }
+          if (r + 1 < G) {
+            const double ua = __shfl_up(ia, 1, 64), ub = __shfl_up(ib, 1, 64);
+            const int up = __shfl_up(ip, 1, 64), ug = __shfl_up(ig, 1, 64);
+            if (g == r + 1) { ia = ua; ib = ub; ip = up; ig = ug; }
+          }
+        }
+        wl = __shfl(ip, base + G - 1, 64);
+        wg = __shfl(ig, base + G - 1, 64);
+      }
+    }
+    // apply the pulse
+    double xw = 0;
+    int yw = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      if (j == wl) { xw = v.x[j]; yw = y[j]; }
+    }
+    if (G > 1) {
+      xw = __shfl(xw, base + wg, 64);
+      yw = __shfl(yw, base + wg, 64);
+    }
+    if (run) {
+      xy = xy + xw;
+      yy = yy + (2*yw + 1);
+      if (g == wg) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) y[j] += (j == wl);
+      }
+      i++;
+    }
+  }
+  // ---- RDO phase -------------------------------------------------------------
+  // cost_j = 2*(xy + x_j)*norm_1*rsqrt(yy + 2*y_j + 1) - lambda*j*delta_rate, plain
+  // double compare, strict '>', first index wins (src/pvq_encoder.c:195-220).
+  while (__any(i < k)) {
+    const bool run = i < k;
+    const int iy = (int)yy;
+    // the reference tabulates y = 0..3 per pulse (:205); same values here
+    const double r0 = pvq_rsqrt_tab(rsq, iy + 1), r1 = pvq_rsqrt_tab(rsq, iy + 3);
+    const double r2 = pvq_rsqrt_tab(rsq, iy + 5), r3 = pvq_rsqrt_tab(rsq, iy + 7);
+    double bc = 0;
+    int bpos = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      if (G*NL == N || j < nvalid) {
+        const int yj = y[j];
+        double rs = yj == 0 ? r0 : yj == 1 ? r1 : yj == 2 ? r2 : r3;
+        if (__builtin_expect(yj > 3, 0)) rs = pvq_rsqrt_tab(rsq, iy + 2*yj + 1);
+        double c = xy + v.x[j];
+        c = 2*c*v.norm_1*rs - lambda*(g*NL + j)*delta_rate;
+        if (j == 0 || c > bc) { bc = c; bpos = j; }
+      }
+    }
+    int wl = bpos, wg = 0;
+    if (G > 1) {
+      double cc = __shfl(bc, base, 64);
+      int cp = __shfl(bpos, base, 64);
+#pragma unroll
+      for (int r = 1; r < G; r++) {
+        const double rc = __shfl(bc, base + r, 64);
+        const int rp = __shfl(bpos, base + r, 64);
+        if (rc > cc) { cc = rc; cp = rp; wg = r; }
+      }
+      wl = cp;
+    }
+    double xw = 0;
+    int yw = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      if (j == wl) { xw = v.x[j]; yw = y[j]; }
+    }
+    if (G > 1) {
+      xw = __shfl(xw, base + wg, 64);
+      yw = __shfl(yw, base + wg, 64);
+    }
+    if (run) {
+      xy = xy + xw;
+      yy = yy + (2*yw + 1);
+      if (g == wg) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) y[j] += (j == wl);
+      }
+      i++;
+    }
+  }
+  return xy/(1e-100 + sqrt(v.xx*yy));
+}
+
+struct PvqLevelArgs3 {
+  PvqLevelArgs a;
+  const double *rsq;
+};
+
+// No-reference candidates (state-free part of pvq_theta, src/pvq_encoder.c:352-357,
+// :452-481) of the bands of size N of one pyramid level, register-resident.
+#ifndef PVQ_V3_WAVES
+#define PVQ_V3_WAVES(N) ((N) <= 15 ? 4 : (N) <= 32 ? 3 : 2)
+#endif
+template <int N>
+__global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelArgs3 aa) {
+  const PvqLevelArgs &a = aa.a;
+  constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
+  __shared__ int32_t Yst[BPW*N + 1];
+  const int lane = threadIdx.x;
+  const int g = lane%G, inst = lane/G;
+  const long blk0 = (long)blockIdx.x*BPW;
+  const long blk = blk0 + inst;
+  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
+  const long nblk = (long)a.nbx*a.nby;
+  const bool live = blk < nblk;
+  const int o0 = a.off[band];
+  const int q0 = a.q[band];
+  const double beta = a.beta[band];
+  const size_t rin = (size_t)band*nblk + (live ? blk : 0);
+  const size_t rec = (size_t)f*a.rec_fstride + rin;
+  const size_t rec2 = (size_t)f*2*a.rec_fstride + rin;
+  // gather this lane's chunk: coefficient and QM entry
+  int32_t cf[NL];
+  int qi[NL];
+  {
+    const long bsafe = live ? blk : 0;
+    const int bx = bsafe%a.nbx, by = bsafe/a.nbx;
+    const int32_t *src = a.lev + (size_t)f*a.lev_fstride + (size_t)(by*a.n)*a.w + bx*a.n;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int jj = g*NL + j;
+      if (live && jj < N) {
+        const int ro = a.tab[o0 + jj];
+        cf[j] = src[(size_t)(ro/a.n)*a.w + (ro%a.n)];
+        qi[j] = a.qm[o0 + jj];
+      }
+      else { cf[j] = 0; qi[j] = 0; }
+    }
+  }
+  // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
+  const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
+    return cf[j]*(double)cf[j]*qi[j]*PVQ_QM_SCALE_1*qi[j]*PVQ_QM_SCALE_1;
+  });
+  const double gain = sqrt(acc);
+  const double cg = pvq_gain_compand(gain, q0, beta);
+  PvqVec<N> v;
+  v.neg = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int pr = cf[j]*qi[j];                    // the reference's int*int product (:455)
+    v.x[j] = fabs(pr*PVQ_QM_SCALE_1);
+    v.neg |= (uint32_t)(pr < 0) << j;
+  }
+  pvq_vec_finish<N>(v, g, lane);
+  int i0 = (int)floor(cg);
+  if (i0 < 1) i0 = 1;
+  const int i1 = live ? (int)ceil(cg) : 0;
+  int nc = 0;
+  for (int c = 0; c < 2; c++) {
+    const int gi = i0 + c;
+    const bool has = live && gi <= i1;
+    const double qcg = gi;
+    const int k = has ? pvq_k_noref(qcg, N, beta) : 0;
+    int y[NL];
+    const double cd = pvq_search_v3<N>(v, g, lane, k, qcg*cg, aa.rsq, y);
+    if (live && g == 0) {
+      a.out.qg[c*a.rec_fstride + rec2] = has ? gi : 0;
+      a.out.k[c*a.rec_fstride + rec2] = k;
+      a.out.cos_dist[c*a.rec_fstride + rec2] = has ? cd : 0;
+      a.out.dist[c*a.rec_fstride + rec2] =
+          has ? 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd) : 0;
+    }
+    nc += has;
+    // signed pulses -> LDS -> coalesced [cand][block][N] store
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int jj = g*NL + j;
+      if (jj < N) Yst[inst*N + jj] = has ? (((v.neg >> j) & 1) ? -y[j] : y[j]) : 0;
+    }
+    __syncthreads();
+    {
+      int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) +
+                    ((size_t)c*nblk + blk0)*N;
+      const long lim = (nblk - blk0 < BPW ? nblk - blk0 : BPW)*N;
+      for (int e = lane; e < lim; e += 64) yo[e] = Yst[e];
+    }
+    __syncthreads();
+  }
+  if (live && g == 0) {
+    a.out.cg[rec] = cg;
+    a.out.g[rec] = gain;
+    a.out.ncand[rec] = nc;
+  }
 }
