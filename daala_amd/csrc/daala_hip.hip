@@ -14,6 +14,7 @@
 #include "coding_order_tables.h"
 #include "pvq_kernels.hpp"
 #include "xform_kernels.hpp"
+#include "xform_rt_kernels.hpp"
 
 static_assert(sizeof(PvqBandRec) == sizeof(od_hip_pvq_band), "record layout");
 static_assert(sizeof(od_hip_pvq_band) == 72, "record layout");
@@ -138,6 +139,7 @@ struct od_hip_ctx {
   int16_t *qm_dev;                           // scratch QM (1024 int16)
   double *rsq;                               // 1/sqrt(i) table (pvq_rsqrt_tab)
   int pvq_impl = 3;                          // 3 = register-resident, 2 = LDS-resident
+  int xform_impl = 2;                        // 2 = row-tile (one wave per 64xSB tile), 1 = one WG per SB
   // PVQ results per (plane, level)
   PvqSoA pvq[OD_HIP_NPLANES_MAX][4];         // device SoA, all slots
   bool pvq_alloc[OD_HIP_NPLANES_MAX][4];
@@ -375,6 +377,7 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
     ok = hipGetLastError() == hipSuccess;
   }
   if (const char *e = getenv("OD_HIP_PVQ_IMPL")) ctx->pvq_impl = atoi(e);
+  if (const char *e = getenv("OD_HIP_XFORM_IMPL")) ctx->xform_impl = atoi(e);
   const uint16_t *tabs[4] = {CODING_TO_RASTER_4, CODING_TO_RASTER_8, CODING_TO_RASTER_16,
                              CODING_TO_RASTER_32};
   const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
@@ -505,11 +508,19 @@ int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
     FwdArgs a = fwd_args(ctx, p, slot0, false, 0);
     if (a.dec == 0) {
       Timed tm(ctx, "k_forward_pyramid_luma");
-      hipLaunchKernelGGL((k_forward<32, 4, false>), grid, dim3(256), 0, ctx->stream, a);
+      if (ctx->xform_impl == 1)
+        hipLaunchKernelGGL((k_forward<32, 4, false>), grid, dim3(256), 0, ctx->stream, a);
+      else
+        hipLaunchKernelGGL((k_forward_rt<32, 4, false>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+                           dim3(64), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_pyramid_chroma");
-      hipLaunchKernelGGL((k_forward<16, 3, false>), grid, dim3(64), 0, ctx->stream, a);
+      if (ctx->xform_impl == 1)
+        hipLaunchKernelGGL((k_forward<16, 3, false>), grid, dim3(64), 0, ctx->stream, a);
+      else
+        hipLaunchKernelGGL((k_forward_rt<16, 3, false>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+                           dim3(64), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
   }
@@ -523,11 +534,19 @@ int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe) {
     FwdArgs a = fwd_args(ctx, p, slot0, true, keyframe);
     if (a.dec == 0) {
       Timed tm(ctx, "k_forward_known_luma");
-      hipLaunchKernelGGL((k_forward<32, 4, true>), grid, dim3(256), 0, ctx->stream, a);
+      if (ctx->xform_impl == 1)
+        hipLaunchKernelGGL((k_forward<32, 4, true>), grid, dim3(256), 0, ctx->stream, a);
+      else
+        hipLaunchKernelGGL((k_forward_rt<32, 4, true>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+                           dim3(64), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_known_chroma");
-      hipLaunchKernelGGL((k_forward<16, 3, true>), grid, dim3(64), 0, ctx->stream, a);
+      if (ctx->xform_impl == 1)
+        hipLaunchKernelGGL((k_forward<16, 3, true>), grid, dim3(64), 0, ctx->stream, a);
+      else
+        hipLaunchKernelGGL((k_forward_rt<16, 3, true>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+                           dim3(64), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
   }
@@ -554,14 +573,22 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
     dim3 grid(ctx->nhsb, ctx->nvsb, nslots), grid2(ctx->nhsb + 1, ctx->nvsb + 1, nslots);
     if (a.dec == 0) {
       { Timed tm(ctx, "k_inverse_sb_luma");
-        hipLaunchKernelGGL((k_inverse_sb<32, 4>), grid, dim3(256), 0, ctx->stream, a); }
+        if (ctx->xform_impl == 1)
+          hipLaunchKernelGGL((k_inverse_sb<32, 4>), grid, dim3(256), 0, ctx->stream, a);
+        else
+          hipLaunchKernelGGL((k_inverse_rt<32, 4>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+                             dim3(64), 0, ctx->stream, a); }
       HIPCHK(hipGetLastError());
       { Timed tm(ctx, "k_postfilter_clamp_luma");
         hipLaunchKernelGGL((k_postfilter_clamp<32>), grid2, dim3(256), 0, ctx->stream, q); }
     }
     else {
       { Timed tm(ctx, "k_inverse_sb_chroma");
-        hipLaunchKernelGGL((k_inverse_sb<16, 3>), grid, dim3(64), 0, ctx->stream, a); }
+        if (ctx->xform_impl == 1)
+          hipLaunchKernelGGL((k_inverse_sb<16, 3>), grid, dim3(64), 0, ctx->stream, a);
+        else
+          hipLaunchKernelGGL((k_inverse_rt<16, 3>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+                             dim3(64), 0, ctx->stream, a); }
       HIPCHK(hipGetLastError());
       { Timed tm(ctx, "k_postfilter_clamp_chroma");
         hipLaunchKernelGGL((k_postfilter_clamp<16>), grid2, dim3(64), 0, ctx->stream, q); }
