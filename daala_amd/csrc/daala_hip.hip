@@ -512,7 +512,7 @@ int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
         hipLaunchKernelGGL((k_forward<32, 4, false>), grid, dim3(256), 0, ctx->stream, a);
       else
         hipLaunchKernelGGL((k_forward_rt<32, 4, false>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
-                           dim3(64), 0, ctx->stream, a);
+                           dim3(128), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_pyramid_chroma");
@@ -520,7 +520,7 @@ int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
         hipLaunchKernelGGL((k_forward<16, 3, false>), grid, dim3(64), 0, ctx->stream, a);
       else
         hipLaunchKernelGGL((k_forward_rt<16, 3, false>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
-                           dim3(64), 0, ctx->stream, a);
+                           dim3(128), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
   }
@@ -538,7 +538,7 @@ int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe) {
         hipLaunchKernelGGL((k_forward<32, 4, true>), grid, dim3(256), 0, ctx->stream, a);
       else
         hipLaunchKernelGGL((k_forward_rt<32, 4, true>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
-                           dim3(64), 0, ctx->stream, a);
+                           dim3(128), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_known_chroma");
@@ -546,7 +546,7 @@ int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe) {
         hipLaunchKernelGGL((k_forward<16, 3, true>), grid, dim3(64), 0, ctx->stream, a);
       else
         hipLaunchKernelGGL((k_forward_rt<16, 3, true>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
-                           dim3(64), 0, ctx->stream, a);
+                           dim3(128), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
   }

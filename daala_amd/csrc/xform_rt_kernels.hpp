@@ -17,13 +17,28 @@
 #pragma once
 #include "xform_kernels.hpp"
 
+// A row-tile workgroup is exactly ONE wave, so no s_barrier is needed: DS
+// operations of a wave execute in order, and the only thing to wait for before
+// another lane's LDS data is read is the wave's own outstanding LDS traffic.
+// Unlike __syncthreads() this does NOT wait for global stores (vmcnt), so the
+// level stores stay in flight while the next level is computed.
+__device__ __forceinline__ void rt_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void rt_lap4_pre16(int16_t *p, int stride) {
+  int32_t x0 = p[0], x1 = p[stride], x2 = p[2*stride], x3 = p[3*stride];
+  lap4_pre(x0, x1, x2, x3);
+  p[0] = (int16_t)x0; p[stride] = (int16_t)x1; p[2*stride] = (int16_t)x2; p[3*stride] = (int16_t)x3;
+}
+
 template <int SB> struct RowTile {
   static constexpr int W = 64;               // tile width (samples)
   static constexpr int NSB = W/SB;           // superblocks per tile
   static constexpr int LDZ = W + 1;          // coefficient tile stride
   static constexpr int HAW = W + 4;          // lapped tile incl. 2-sample halo
   static constexpr int HAH = SB + 4;
-  static constexpr int LDA = W + 5;
+  static constexpr int LDA = W + 6;          // int16 tile: even stride keeps rows dword aligned
 };
 
 // Store an SB x 64 int32 tile (stride 65 in LDS) to a plane; 4 rows x 256 B per
@@ -60,23 +75,62 @@ __device__ __forceinline__ void rt_load_tile(int32_t *Z, const int32_t *__restri
   }
 }
 
-// Forward path of one row tile.  PYRAMID: all blocks of all levels (stores one
-// plane per level).  KNOWN: only the quadtree leaves + keyframe DC merge
-// (od_compute_dcts, src/encode.c:1286-1343).
-template <int SB, int NLEV, bool KNOWN>
-__global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
+// Raw workgroup barrier for the two waves of a row-tile workgroup: waits for the
+// wave's LDS traffic only (no vmcnt: global stores stay in flight).
+__device__ __forceinline__ void rt_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Store a rectangle of the coefficient tile: rows [row0, row0+NR), columns
+// [col0, col0+NC) (NC in {32, 64}), one int4 per lane.
+template <int SB, int NR, int NC>
+__device__ __forceinline__ void rt_store_rect(int32_t *__restrict__ dst, int w, int x0,
+                                              const int32_t *Z, int row0, int col0, int lane) {
   using T = RowTile<SB>;
-  __shared__ int32_t A[T::HAH*T::LDA];
+  constexpr int LPR = NC/4;                     // lanes per row
+  constexpr int RPI = 64/LPR;                   // rows per wave instruction
+  const int rr = lane % RPI, c4 = col0 + (lane/RPI)*4;
+  if (x0 + c4 < w) {
+#pragma unroll
+    for (int it = 0; it < (NR + RPI - 1)/RPI; it++) {
+      const int r = row0 + it*RPI + rr;
+      if (NR % RPI == 0 || it*RPI + rr < NR) {
+        const int32_t *p = Z + r*T::LDZ + c4;
+        *reinterpret_cast<int4 *>(dst + (size_t)r*w + c4) = make_int4(p[0], p[1], p[2], p[3]);
+      }
+    }
+  }
+}
+
+// Forward path of one row tile, TWO waves per tile.
+//   level 0 (block size SB): wave w owns the columns [32w, 32w+32) - for luma that
+//     is one whole 32x32 block, for chroma two 16x16 blocks - for both separable
+//     passes and for the level-0 split lapping: nothing crosses waves.
+//   levels >= 1: wave w owns the rows [w*SB/2, (w+1)*SB/2) of the tile at every
+//     level (blocks nest), again nothing crosses waves.
+// So the only workgroup barriers are: after the load, between the two frame-lapping
+// phases, after them, and between level 0 and level 1.
+// PYRAMID: all blocks of all levels (one plane per level).  KNOWN: only the quadtree
+// leaves + keyframe DC merge (od_compute_dcts, src/encode.c:1286-1343).
+template <int SB, int NLEV, bool KNOWN>
+__global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
+  using T = RowTile<SB>;
+  // lapped spatial tile as int16: |value| <= 6452 for pixel-driven data
+  // (tools/range_analysis.py); halves its LDS footprint
+  __shared__ int16_t A[T::HAH*T::LDA];
   __shared__ int32_t Z[SB*T::LDZ];
   __shared__ uint8_t bsz[16*T::NSB];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
   const int tx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
   const int x0 = tx*T::W, y0 = sby*SB;
   const int sbx0 = tx*T::NSB;                          // first superblock of the tile
   const int nsb = min(T::NSB, a.nhsb - sbx0);          // superblocks really present
   const int dec = a.dec;
   if (KNOWN) {
-    for (int e = lane; e < 16*T::NSB; e += 64) {
+    for (int e = tid; e < 16*T::NSB; e += 128) {
       const int s = e >> 4, c = e & 15;
       bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
                                  (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
@@ -87,7 +141,7 @@ __global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
     // A1: 8-bit pixels -> (p - 128) << 4, dword loads starting 4 bytes left of the tile
     const uint8_t *pix = a.pix + (size_t)f*a.pix_fstride;
     constexpr int DW = T::HAW/4 + 1;                   // 18 dwords cover x0-4 .. x0+67
-    for (int e = lane; e < T::HAH*DW; e += 64) {
+    for (int e = tid; e < T::HAH*DW; e += 128) {
       const int ty = e/DW, dx = e%DW;
       const int gy = min(max(y0 - 2 + ty, 0), a.h - 1);
       const int gx = min(max(x0 - 4 + dx*4, 0), a.w - 4);
@@ -96,34 +150,25 @@ __global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
       for (int b = 0; b < 4; b++) {
         const int txx = dx*4 + b - 2;
         if (txx >= 0 && txx < T::HAW) {
-          A[ty*T::LDA + txx] = ((int32_t)((v >> (8*b)) & 255) - 128) << 4;
+          A[ty*T::LDA + txx] = (int16_t)(((int32_t)((v >> (8*b)) & 255) - 128) << 4);
         }
       }
     }
   }
-  __syncthreads();
+  rt_barrier();
   // A4: frame lapping.  Horizontal SB boundaries first (vertical taps over every
   // column of the halo'd tile), then vertical boundaries (src/filter.c:1566-1584).
-  for (int c = lane; c < T::HAW; c += 64) {
-    if (sby > 0) {
-      int32_t *p = A + c;
-      lap4_pre(p[0], p[T::LDA], p[2*T::LDA], p[3*T::LDA]);
-    }
-    if (sby < a.nvsb - 1) {
-      int32_t *p = A + SB*T::LDA + c;
-      lap4_pre(p[0], p[T::LDA], p[2*T::LDA], p[3*T::LDA]);
-    }
+  for (int c = tid; c < T::HAW; c += 128) {
+    if (sby > 0) rt_lap4_pre16(A + c, T::LDA);
+    if (sby < a.nvsb - 1) rt_lap4_pre16(A + SB*T::LDA + c, T::LDA);
   }
-  __syncthreads();
-  for (int e = lane; e < (T::NSB + 1)*SB; e += 64) {
+  rt_barrier();
+  for (int e = tid; e < (T::NSB + 1)*SB; e += 128) {
     const int s = e/SB, row = e%SB;                    // boundary left of tile SB s
     const int gb = sbx0 + s;                           // global boundary index
-    if (gb >= 1 && gb <= a.nhsb - 1 && s <= nsb) {
-      int32_t *p = A + (2 + row)*T::LDA + s*SB;
-      lap4_pre(p[0], p[1], p[2], p[3]);
-    }
+    if (gb >= 1 && gb <= a.nhsb - 1 && s <= nsb) rt_lap4_pre16(A + (2 + row)*T::LDA + s*SB, 1);
   }
-  __syncthreads();
+  rt_barrier();
   auto cell = [&](int byi, int bxt, int n) -> int {    // max(obs, dec) of a tile block
     const int s = (bxt*n)/SB, bxs = bxt - s*(SB/n);
     const int nl = n << dec;
@@ -131,13 +176,19 @@ __global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
     return o > dec ? o : dec;
   };
   int32_t *out = a.out + (size_t)f*a.out_fstride + (size_t)y0*a.w + x0;
+  // One transform level.  K == 0: this wave's 32 columns (lanes 0..31), the whole
+  // tile height; K >= 1: all 64 columns, this wave's block rows.
 #define RT_FWD_LEVEL(K)                                                                \
   if constexpr (K < NLEV) {                                                            \
     constexpr int N = SB >> K;                                                         \
     constexpr int NBY = SB/N;                                                          \
-    const int col = lane, bxt = col/N, i = col%N;                                      \
-    const bool present = (bxt*N)/SB < nsb;                                             \
-    for (int byi = 0; byi < NBY; byi++) {                                              \
+    constexpr int BY_PER_WAVE = K == 0 ? 1 : NBY/2;                                    \
+    const int col = K == 0 ? wv*32 + (lane & 31) : lane;                               \
+    const bool lane_on = K == 0 ? lane < 32 : true;                                    \
+    const int bxt = col/N, i = col%N;                                                  \
+    const bool present = lane_on && (bxt*N)/SB < nsb;                                  \
+    for (int bb = 0; bb < BY_PER_WAVE; bb++) {                                         \
+      const int byi = K == 0 ? 0 : wv*BY_PER_WAVE + bb;                                \
       const bool go = present && (!KNOWN || cell(byi, bxt, N) == 3 - K);               \
       int32_t v[N];                                                                    \
       if (go) {                                                                        \
@@ -147,43 +198,43 @@ __global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
         _Pragma("unroll") for (int k = 0; k < N; k++)                                  \
           Z[(byi*N + i)*T::LDZ + bxt*N + k] = v[k];                                    \
       }                                                                                \
-      __syncthreads();                                                                 \
+      rt_sync();                                                                       \
       if (go) {                                                                        \
         _Pragma("unroll") for (int k = 0; k < N; k++)                                  \
           v[k] = Z[(byi*N + k)*T::LDZ + col];                                          \
         LiftDct<N, true>::fwd(v);                                                      \
       }                                                                                \
-      __syncthreads();                                                                 \
+      rt_sync();                                                                       \
       if (go) {                                                                        \
         _Pragma("unroll") for (int k = 0; k < N; k++)                                  \
           Z[(byi*N + i)*T::LDZ + bxt*N + k] = v[k];                                    \
       }                                                                                \
-    }                                                                                  \
-    __syncthreads();                                                                   \
-    if (!KNOWN) {                                                                      \
-      rt_store_tile<SB>(out + (size_t)K*a.out_lstride, a.w, x0, Z);                    \
-      __syncthreads();                                                                 \
-    }                                                                                  \
-    if constexpr (K + 1 < NLEV) {                                                      \
-      /* A5: split lapping of the blocks that are split at this level */              \
-      for (int byi = 0; byi < NBY; byi++) {                                            \
+      rt_sync();                                                                       \
+      if (!KNOWN) {                                                                    \
+        if (K == 0) rt_store_rect<SB, SB, 32>(out, a.w, x0, Z, 0, wv*32, lane);        \
+        else rt_store_rect<SB, N, 64>(out + (size_t)K*a.out_lstride, a.w, x0, Z, byi*N, 0, lane); \
+        rt_sync();                                                                     \
+      }                                                                                \
+      if constexpr (K + 1 < NLEV) {                                                    \
+        /* A5: split lapping of this block row: taps across the horizontal centre */   \
+        /* line of each block (per column), then across the vertical centre line   */  \
         const bool sp = present && (!KNOWN || cell(byi, bxt, N) < 3 - K);              \
         if (sp && (tx*(T::W/N) + bxt + 1)*N <= a.pic_w) {                              \
-          int32_t *p = A + (2 + byi*N + N/2 - 2)*T::LDA + 2 + col;                     \
-          lap4_pre(p[0], p[T::LDA], p[2*T::LDA], p[3*T::LDA]);                         \
+          rt_lap4_pre16(A + (2 + byi*N + N/2 - 2)*T::LDA + 2 + col, T::LDA);           \
         }                                                                              \
-      }                                                                                \
-      __syncthreads();                                                                 \
-      for (int e = lane; e < SB*(T::W/N); e += 64) {                                   \
-        const int bx2 = e/SB, row = e%SB, by2 = row/N;                                 \
-        const bool sp = (bx2*N)/SB < nsb && (!KNOWN || cell(by2, bx2, N) < 3 - K);     \
-        if (sp && (sby*NBY + by2 + 1)*N <= a.pic_h) {                                  \
-          int32_t *p = A + (2 + row)*T::LDA + 2 + bx2*N + N/2 - 2;                     \
-          lap4_pre(p[0], p[1], p[2], p[3]);                                            \
+        rt_sync();                                                                     \
+        constexpr int NBX = K == 0 ? 32/N : T::W/N;      /* blocks per wave row */     \
+        for (int e = lane; e < N*NBX; e += 64) {                                       \
+          const int bx2 = (K == 0 ? wv*(32/N) : 0) + e/N, row = byi*N + e%N;           \
+          const bool sp2 = (bx2*N)/SB < nsb && (!KNOWN || cell(byi, bx2, N) < 3 - K);  \
+          if (sp2 && (sby*NBY + byi + 1)*N <= a.pic_h) {                               \
+            rt_lap4_pre16(A + (2 + row)*T::LDA + 2 + bx2*N + N/2 - 2, 1);              \
+          }                                                                            \
         }                                                                              \
+        rt_sync();                                                                     \
       }                                                                                \
-      __syncthreads();                                                                 \
     }                                                                                  \
+    if (K == 0) rt_barrier();    /* level >= 1 regions mix both level-0 column halves */ \
   }
   RT_FWD_LEVEL(0)
   RT_FWD_LEVEL(1)
@@ -191,12 +242,13 @@ __global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
   RT_FWD_LEVEL(3)
 #undef RT_FWD_LEVEL
   if (KNOWN) {
+    rt_barrier();
     if (a.keyframe) {
       // Haar merge of the four child DCs of every split block, finest first
       for (int k = NLEV - 2; k >= 0; k--) {
         const int n = SB >> k, nby = SB/n, nbx = T::W/n, hh = n/2;
-        if (lane < nby*nbx) {
-          const int byi = lane/nbx, bxt = lane%nbx;
+        if (tid < nby*nbx) {
+          const int byi = tid/nbx, bxt = tid%nbx;
           if ((bxt*n)/SB < nsb && cell(byi, bxt, n) < 3 - k) {
             int32_t *p = Z + (byi*n)*T::LDZ + bxt*n;
             int32_t q0 = p[0], q1 = p[hh], q2 = p[hh*T::LDZ], q3 = p[hh*T::LDZ + hh];
@@ -204,10 +256,10 @@ __global__ __launch_bounds__(64) void k_forward_rt(FwdArgs a) {
             p[0] = q0; p[hh] = q1; p[hh*T::LDZ] = q2; p[hh*T::LDZ + hh] = q3;
           }
         }
-        __syncthreads();
+        rt_barrier();
       }
     }
-    rt_store_tile<SB>(out, a.w, x0, Z);
+    rt_store_rect<SB, SB/2, 64>(out, a.w, x0, Z, wv*(SB/2), 0, lane);
   }
 }
 
@@ -240,22 +292,22 @@ __device__ __forceinline__ void rt_inverse_body(int32_t *Z, const uint8_t *bsz, 
         _Pragma("unroll") for (int k = 0; k < N; k++) v[k] = Z[row*T::LDZ + bxt*N + k];\
         LiftDct<N, M24>::inv(v);                                                       \
       }                                                                                \
-      __syncthreads();                                                                 \
+      rt_sync();                                                                 \
       if (go) {                                                                        \
         _Pragma("unroll") for (int k = 0; k < N; k++)                                  \
           Z[(byi*N + k)*T::LDZ + bxt*N + i] = v[k];                                    \
       }                                                                                \
-      __syncthreads();                                                                 \
+      rt_sync();                                                                 \
       if (go) {                                                                        \
         _Pragma("unroll") for (int k = 0; k < N; k++) v[k] = Z[row*T::LDZ + bxt*N + k];\
         LiftDct<N, M24>::inv(v);                                                       \
       }                                                                                \
-      __syncthreads();                                                                 \
+      rt_sync();                                                                 \
       if (go) {                                                                        \
         _Pragma("unroll") for (int k = 0; k < N; k++)                                  \
           Z[(byi*N + k)*T::LDZ + bxt*N + i] = v[k];                                    \
       }                                                                                \
-      __syncthreads();                                                                 \
+      rt_sync();                                                                 \
     }                                                                                  \
   }
   RT_INV_LEVEL(0)
@@ -272,7 +324,7 @@ __device__ __forceinline__ void rt_inverse_body(int32_t *Z, const uint8_t *bsz, 
         lap4_post(p[0], p[1], p[2], p[3]);
       }
     }
-    __syncthreads();
+    rt_sync();
     for (int byi = 0; byi < nby; byi++) {              // taps across horizontal centre lines
       const int col = lane, bxt = col/n;
       if ((bxt*n)/SB < nsb && cell(byi, bxt, n) < 3 - k && (tx*nbx + bxt + 1)*n <= pic_w) {
@@ -280,7 +332,7 @@ __device__ __forceinline__ void rt_inverse_body(int32_t *Z, const uint8_t *bsz, 
         lap4_post(p[0], p[T::LDZ], p[2*T::LDZ], p[3*T::LDZ]);
       }
     }
-    __syncthreads();
+    rt_sync();
   }
 }
 
@@ -301,7 +353,7 @@ __global__ __launch_bounds__(64) void k_inverse_rt(InvArgs a) {
                      : 3;
   }
   rt_load_tile<SB>(Z, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0);
-  __syncthreads();
+  rt_sync();
   // range check for the 24-bit multiplier
   int mx = 0;
   for (int e = lane; e < SB*T::W; e += 64) {
