@@ -325,7 +325,7 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   if (ensure_device()) return nullptr;
   if (geo->frame_width <= 0 || geo->frame_height <= 0 || geo->frame_width%32 ||
       geo->frame_height%32 || geo->pic_width > geo->frame_width ||
-      geo->pic_height > geo->frame_height || geo->pic_width <= 0 || geo->pic_height <= 0 ||
+      geo->pic_height > geo->frame_height || geo->pic_width <= 0 || geo->pic_height < 0 ||
       geo->nplanes < 1 || geo->nplanes > 3 || geo->nslots < 1) {
     fail(OD_HIP_EINVAL, "invalid geometry");
     return nullptr;

@@ -376,3 +376,24 @@ def test_pvq_theta_golden_decisions_reachable(hip):
         y, _ = hip.pvq_search_vectors(np.array(xs), np.array(ks, np.int32), np.array(g2s))
         for j, i in enumerate(idx):
             assert np.array_equal(y[j], g['y'][i][:n])
+
+
+def test_sb_row_strips_on_device_equal_full_frame(hip):
+    """Config-3 style sharding: each 'rank' transforms its strip of superblock rows
+    (+1 halo SB row each side) on the device; stacking the owned rows must equal the
+    full-frame pyramid.  Ranks are emulated sequentially on the one GPU; the
+    collective itself is covered by tests/test_sharding_gloo.py."""
+    from daala_amd import sharding
+    pic_w, pic_h, fw, fh = 150, 200, 192, 224
+    planes = [synth_plane(fw, fh, 31), synth_plane(fw//2, fh//2, 31, 1)]
+    xdec = (0, 1)
+    full = sharding.hip_strip_compute()(planes, (pic_w, pic_h, fw, fh))
+    for world in (2, 3, 7):
+        parts = [sharding.strip_pyramid(sharding.SbRowShard(pic_w, pic_h, fw, fh, world, r), planes,
+                                        xdec, sharding.hip_strip_compute()) for r in range(world)]
+        for pli, d in enumerate(xdec):
+            for k in range(4 - d):
+                got = np.concatenate([p[pli][k] for p in parts], axis=0)
+                assert np.array_equal(got, full[pli][k]), (world, pli, k)
+    lev = oracle_pyramid(planes[0], fw, fh, 0, pic_w, pic_h)
+    assert np.array_equal(full[0][3], lev[3])
