@@ -305,3 +305,79 @@ class DaalaHip(object):
         _chk(self.lib.od_hip_timing_get(self.ctx, kernel.encode(), ctypes.byref(n),
                                         ctypes.byref(ms)))
         return n.value, ms.value
+
+
+class PvqThetaOut(ctypes.Structure):
+    """od_hip_pvq_theta_out (include/daala_hip.h)."""
+    _fields_ = [('cg', ctypes.c_double), ('cgr', ctypes.c_double), ('g', ctypes.c_double),
+                ('gr', ctypes.c_double), ('corr', ctypes.c_double), ('theta', ctypes.c_double),
+                ('gain_offset', ctypes.c_double), ('skip_dist', ctypes.c_double),
+                ('null_dist', ctypes.c_double),
+                ('icgr', ctypes.c_int32), ('m', ctypes.c_int32), ('s', ctypes.c_int32),
+                ('nref', ctypes.c_int32), ('nnoref', ctypes.c_int32),
+                ('theta_searched', ctypes.c_int32), ('noref_searched', ctypes.c_int32),
+                ('pad', ctypes.c_int32),
+                ('ref_qg', ctypes.c_int32*12), ('ref_itheta', ctypes.c_int32*12),
+                ('ref_ts', ctypes.c_int32*12), ('ref_k', ctypes.c_int32*12),
+                ('ref_qtheta', ctypes.c_double*12), ('ref_cos_dist', ctypes.c_double*12),
+                ('ref_dist', ctypes.c_double*12),
+                ('nr_qg', ctypes.c_int32*2), ('nr_k', ctypes.c_int32*2),
+                ('nr_cos_dist', ctypes.c_double*2), ('nr_dist', ctypes.c_double*2)]
+
+
+def pvq_theta_vectors(x0, r0, qm, q0, beta, robust, is_keyframe, pli):
+    """pvq_theta candidates (no rate term) for [nvec][n] inputs/predictions."""
+    lib = load()
+    x0 = _c32(x0)
+    r0 = _c32(r0)
+    nvec, n = x0.shape
+    qm = np.ascontiguousarray(qm, dtype=np.int16)
+    q0 = np.ascontiguousarray(q0, dtype=np.int32)
+    out = (PvqThetaOut*nvec)()
+    y_ref = np.zeros((nvec, 12, n), np.int32)
+    y_nr = np.zeros((nvec, 2, n), np.int32)
+    lib.od_hip_pvq_theta_vectors.argtypes = [c_int, c_int, I32P, I32P, I16P, I32P,
+                                             ctypes.c_double, c_int, c_int, c_int,
+                                             ctypes.POINTER(PvqThetaOut), I32P, I32P]
+    _chk(lib.od_hip_pvq_theta_vectors(n, nvec, _p32(x0), _p32(r0), qm.ctypes.data_as(I16P),
+                                      _p32(q0), float(beta), int(robust), int(is_keyframe),
+                                      int(pli), out, _p32(y_ref), _p32(y_nr)))
+    return out, y_ref, y_nr
+
+
+def pvq_synthesis_vectors(y, ref, gr, noref, g, theta, qm, qm_inv):
+    lib = load()
+    y = _c32(y)
+    ref = _c32(ref)
+    nvec, n = y.shape
+    gr = np.ascontiguousarray(gr, dtype=np.float64)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    noref = np.ascontiguousarray(noref, dtype=np.int32)
+    qm = np.ascontiguousarray(qm, dtype=np.int16)
+    qm_inv = np.ascontiguousarray(qm_inv, dtype=np.int16)
+    out = np.empty_like(y)
+    lib.od_hip_pvq_synthesis_vectors.argtypes = [c_int, c_int, I32P, I32P, F64P, I32P, F64P, F64P,
+                                                 I16P, I16P, I32P]
+    _chk(lib.od_hip_pvq_synthesis_vectors(n, nvec, _p32(y), _p32(ref), gr.ctypes.data_as(F64P),
+                                          _p32(noref), g.ctypes.data_as(F64P),
+                                          theta.ctypes.data_as(F64P), qm.ctypes.data_as(I16P),
+                                          qm_inv.ctypes.data_as(I16P), _p32(out)))
+    return out
+
+
+def od_hv_intra_pred_blocks(d, bsize, bs, bx, by):
+    """OD_CLEAR + od_hv_intra_pred for blocks (bx[i], by[i]) (4x4 units) of plane d."""
+    lib = load()
+    d = _c32(d)
+    h, w = d.shape
+    bsize = np.ascontiguousarray(bsize, dtype=np.uint8)
+    bx = np.ascontiguousarray(bx, dtype=np.int32)
+    by = np.ascontiguousarray(by, dtype=np.int32)
+    n = 4 << bs
+    pred = np.empty((len(bx), n*n), np.int32)
+    lib.od_hip_hv_intra_pred_blocks.argtypes = [I32P, c_int, c_int, U8P, c_int, c_int, c_int, I32P,
+                                                I32P, I32P]
+    _chk(lib.od_hip_hv_intra_pred_blocks(_p32(d), w, h, bsize.ctypes.data_as(U8P), bsize.shape[1],
+                                         bs, len(bx), _p32(bx), _p32(by), _p32(pred)))
+    return pred

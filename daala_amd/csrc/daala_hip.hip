@@ -13,11 +13,13 @@
 #include "../../include/daala_hip.h"
 #include "coding_order_tables.h"
 #include "pvq_kernels.hpp"
+#include "pvq_theta_kernels.hpp"
 #include "xform_kernels.hpp"
 #include "xform_rt_kernels.hpp"
 
 static_assert(sizeof(PvqBandRec) == sizeof(od_hip_pvq_band), "record layout");
 static_assert(sizeof(od_hip_pvq_band) == 72, "record layout");
+static_assert(sizeof(PvqThetaOut) == sizeof(od_hip_pvq_theta_out), "record layout");
 
 namespace {
 
@@ -64,7 +66,7 @@ struct DevBuf {
 };
 
 // Scratch for the host-pointer entry points (sections 1, 2 of the header).
-DevBuf g_in, g_out, g_aux0, g_aux1, g_aux2;
+DevBuf g_in, g_out, g_aux0, g_aux1, g_aux2, g_aux3, g_aux4, g_aux5, g_aux6;
 
 template <int N, bool INV>
 int launch_dct_blocks(int32_t *out, const int32_t *in, int nblocks, hipStream_t s) {
@@ -821,6 +823,106 @@ int od_hip_pvq_synthesis_noref(int n, int nvec, const int32_t *y, const double *
                      (const int16_t *)g_aux0.p, (int32_t *)g_out.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, g_out.p, nv*n*4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_pvq_theta_vectors(int n, int nvec, const od_coeff *x0, const od_coeff *r0,
+                             const int16_t *qm, const int32_t *q0, double beta, int robust,
+                             int is_keyframe, int pli, od_hip_pvq_theta_out *out,
+                             int32_t *y_ref, int32_t *y_noref) {
+  if (!x0 || !r0 || !qm || !q0 || !out || !y_ref || !y_noref) return fail(OD_HIP_EFAULT, "null pointer");
+  if (n < 2 || n > PVQ_MAXN || nvec < 0) return fail(OD_HIP_EINVAL, "bad n/nvec");
+  if (int rc = ensure_device()) return rc;
+  if (nvec == 0) return 0;
+  size_t nv = nvec;
+  if (int rc = g_in.reserve(nv*n*4)) return rc;
+  if (int rc = g_aux0.reserve(nv*n*4)) return rc;
+  if (int rc = g_aux1.reserve((size_t)n*2)) return rc;
+  if (int rc = g_aux2.reserve(nv*4)) return rc;
+  if (int rc = g_out.reserve(nv*sizeof(PvqThetaOut))) return rc;
+  if (int rc = g_aux3.reserve(nv*12*n*4)) return rc;
+  if (int rc = g_aux4.reserve(nv*2*n*4)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, x0, nv*n*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, r0, nv*n*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux1.p, qm, (size_t)n*2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux2.p, q0, nv*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(g_aux3.p, 0, nv*12*n*4));
+  HIPCHK(hipMemset(g_aux4.p, 0, nv*2*n*4));
+  hipLaunchKernelGGL(k_pvq_theta_vectors, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
+                     (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const int16_t *)g_aux1.p,
+                     (const int32_t *)g_aux2.p, beta, robust, is_keyframe, pli,
+                     (PvqThetaOut *)g_out.p, (int32_t *)g_aux3.p, (int32_t *)g_aux4.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, nv*sizeof(PvqThetaOut), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(y_ref, g_aux3.p, nv*12*n*4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(y_noref, g_aux4.p, nv*2*n*4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coeff *ref,
+                                 const double *gr, const int32_t *noref, const double *g,
+                                 const double *theta, const int16_t *qm, const int16_t *qm_inv,
+                                 od_coeff *out) {
+  if (!y || !ref || !gr || !noref || !g || !theta || !qm || !qm_inv || !out)
+    return fail(OD_HIP_EFAULT, "null pointer");
+  if (n < 1 || n > PVQ_MAXN || nvec < 0) return fail(OD_HIP_EINVAL, "bad n/nvec");
+  if (int rc = ensure_device()) return rc;
+  if (nvec == 0) return 0;
+  size_t nv = nvec;
+  if (int rc = g_in.reserve(nv*n*4)) return rc;
+  if (int rc = g_aux0.reserve(nv*n*4)) return rc;
+  if (int rc = g_aux1.reserve(nv*8)) return rc;
+  if (int rc = g_aux2.reserve(nv*4)) return rc;
+  if (int rc = g_aux3.reserve(nv*8)) return rc;
+  if (int rc = g_aux4.reserve(nv*8)) return rc;
+  if (int rc = g_aux5.reserve((size_t)n*2)) return rc;
+  if (int rc = g_aux6.reserve((size_t)n*2)) return rc;
+  if (int rc = g_out.reserve(nv*n*4)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, y, nv*n*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, ref, nv*n*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux1.p, gr, nv*8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux2.p, noref, nv*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux3.p, g, nv*8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux4.p, theta, nv*8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux5.p, qm, (size_t)n*2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux6.p, qm_inv, (size_t)n*2, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_pvq_synthesis_vectors, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
+                     (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const double *)g_aux1.p,
+                     (const int32_t *)g_aux2.p, (const double *)g_aux3.p, (const double *)g_aux4.p,
+                     (const int16_t *)g_aux5.p, (const int16_t *)g_aux6.p, (int32_t *)g_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, nv*n*4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h, const unsigned char *bsize,
+                                int bstride, int bs, int nblk, const int32_t *bx,
+                                const int32_t *by, od_coeff *pred) {
+  if (!d || !bsize || !bx || !by || !pred) return fail(OD_HIP_EFAULT, "null pointer");
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblk < 0 || w <= 0 || h <= 0 || w%8 || h%8 ||
+      bstride < w/8) return fail(OD_HIP_EINVAL, "bad geometry");
+  int n = 4 << bs;
+  for (int i = 0; i < nblk; i++) {
+    if (bx[i] < 0 || by[i] < 0 || (bx[i] << 2) + n > w || (by[i] << 2) + n > h)
+      return fail(OD_HIP_EINVAL, "block outside the plane");
+  }
+  if (int rc = ensure_device()) return rc;
+  if (nblk == 0) return 0;
+  size_t nb = nblk, bh = h/8;
+  if (int rc = g_in.reserve((size_t)w*h*4)) return rc;
+  if (int rc = g_aux0.reserve(bh*bstride)) return rc;
+  if (int rc = g_aux1.reserve(nb*4)) return rc;
+  if (int rc = g_aux2.reserve(nb*4)) return rc;
+  if (int rc = g_out.reserve(nb*n*n*4)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, d, (size_t)w*h*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, bsize, bh*bstride, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux1.p, bx, nb*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux2.p, by, nb*4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_hv_intra_pred_blocks, dim3((nblk + 63)/64), dim3(64), 0, 0,
+                     (const int32_t *)g_in.p, w, (const uint8_t *)g_aux0.p, bstride, bs, nblk,
+                     (const int32_t *)g_aux1.p, (const int32_t *)g_aux2.p, (int32_t *)g_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(pred, g_out.p, nb*n*n*4, hipMemcpyDeviceToHost));
   return 0;
 }
 

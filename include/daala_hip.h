@@ -197,6 +197,42 @@ int od_hip_pvq_search_vectors(int n, int nvec, const double *x, const int32_t *k
 int od_hip_pvq_synthesis_noref(int n, int nvec, const int32_t *y,
  const double *g, const int16_t *qm_inv, od_coeff *out);
 
+/* Complete candidate enumeration of pvq_theta (src/pvq_encoder.c:311-481) for
+ * nvec band vectors of length n, WITHOUT the rate term: with-reference (gain i,
+ * angle j) candidates in the reference's loop order, then the no-reference
+ * ones.  The host reproduces the decision with cost = dist + lambda*od_pvq_rate,
+ * '<' for with-reference and '<=' for no-reference candidates (:435, :469).
+ * x0/r0: [nvec][n] input and prediction, qm: [n] (shared), q0: [nvec].
+ * y_ref: [nvec][12][n] (n-1 entries used), y_noref: [nvec][2][n]. */
+typedef struct od_hip_pvq_theta_out {
+  double cg, cgr, g, gr, corr, theta, gain_offset, skip_dist, null_dist;
+  int32_t icgr, m, s, nref, nnoref, theta_searched, noref_searched, pad;
+  int32_t ref_qg[12], ref_itheta[12], ref_ts[12], ref_k[12];
+  double ref_qtheta[12], ref_cos_dist[12], ref_dist[12];
+  int32_t nr_qg[2], nr_k[2];
+  double nr_cos_dist[2], nr_dist[2];
+} od_hip_pvq_theta_out;
+
+int od_hip_pvq_theta_vectors(int n, int nvec, const od_coeff *x0, const od_coeff *r0,
+ const int16_t *qm, const int32_t *q0, double beta, int robust, int is_keyframe,
+ int pli, od_hip_pvq_theta_out *out, int32_t *y_ref, int32_t *y_noref);
+
+/* Decoder-side synthesis of nvec bands, pvq_synthesis (src/pvq_decoder.c:104-118)
+ * = Householder rebuild from the reference + od_pvq_synthesis_partial
+ * (src/pvq.c:552-585), both the no-reference and the with-reference branch.
+ * y, ref, out: [nvec][n]; gr, noref, g, theta: [nvec]; qm, qm_inv: [n]. */
+int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coeff *ref,
+ const double *gr, const int32_t *noref, const double *g, const double *theta,
+ const int16_t *qm, const int16_t *qm_inv, od_coeff *out);
+
+/* Keyframe luma predictor of od_encode_compute_pred (src/encode.c:732-737):
+ * OD_CLEAR + od_hv_intra_pred (src/intra.c:37-61) for nblk blocks of size bs at
+ * 4x4-unit positions (bx[i], by[i]) of the w x h coefficient plane d.
+ * pred: [nblk][n*n]. */
+int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h,
+ const unsigned char *bsize, int bstride, int bs, int nblk, const int32_t *bx,
+ const int32_t *by, od_coeff *pred);
+
 /* Synchronise the context's stream / time its last batch (ms, HIP events). */
 int od_hip_sync(od_hip_ctx *ctx);
 

@@ -795,3 +795,116 @@ long orc_bench_frame(const uint8_t *const pix[3], int fw, int fh, int pic_w,
   }
   return sum;
 }
+
+/* ------------------------------------------------------------------------ */
+/* A16, complete: every candidate pvq_theta (reference src/pvq_encoder.c:311-511)
+   evaluates for one band, WITHOUT the rate term (od_pvq_rate needs the adaptive
+   entropy state and stays on the host).  With-reference candidates (gain i,
+   angle j) come first, in the reference's loop order, then the no-reference
+   ones.  The caller reproduces the decision with
+     cost = dist + lambda*rate,  '<' for with-ref, '<=' for no-ref candidates.
+   Layout of the outputs (MAXC = 12 with-ref, 2 no-ref candidates):
+     y_ref[c][n] (n-1 entries used), y_noref[c][n]. */
+typedef struct orc_theta_out {
+  double cg, cgr, g, gr, corr, theta, gain_offset, skip_dist, null_dist;
+  int32_t icgr, m, s, nref, nnoref, theta_searched, noref_searched, pad;
+  int32_t ref_qg[12], ref_itheta[12], ref_ts[12], ref_k[12];
+  double ref_qtheta[12], ref_cos_dist[12], ref_dist[12];
+  int32_t nr_qg[2], nr_k[2];
+  double nr_cos_dist[2], nr_dist[2];
+} orc_theta_out;
+
+void orc_pvq_theta_candidates(const coeff *x0, const coeff *r0, int n, int q0,
+ double beta, int robust, int is_keyframe, int pli, const int16_t *qm,
+ orc_theta_out *o, coeff *y_ref, coeff *y_noref) {
+  double x[1024], r[1024], g, gr, cg, cgr, corr = 0, gain_offset, theta = 0;
+  const double gain_weight = 1.4;
+  int i, icgr, m = 0, s = 1, cfl_enabled, nodesync = robust || is_keyframe;
+  memset(o, 0, sizeof(*o));
+  for (i = 0; i < n; i++) {
+    x[i] = x0[i]*qm[i]*QM_SCALE_1;
+    r[i] = r0[i]*qm[i]*QM_SCALE_1;
+    corr += x[i]*r[i];
+  }
+  cfl_enabled = is_keyframe && pli != 0;
+  cg = orc_pvq_compute_gain(x0, n, q0, &g, beta, qm);
+  cgr = orc_pvq_compute_gain(r0, n, q0, &gr, beta, qm);
+  if (cfl_enabled) cgr = 1;
+  icgr = (int)floor(.5 + cgr);
+  gain_offset = cgr - icgr;
+  corr = corr/(1e-100 + g*gr);
+  corr = corr < 1. ? corr : 1.;
+  corr = corr > -1. ? corr : -1.;
+  o->null_dist = gain_weight*cg*cg;
+  if (is_keyframe) o->skip_dist = gain_weight*cg*cg;
+  else o->skip_dist = gain_weight*(cg - cgr)*(cg - cgr) + cgr*cg*(2 - 2*corr);
+  {
+    int isnull = 1;
+    for (i = 0; i < n; i++) if (r0[i]) isnull = 0;
+    if (n <= 128 && !isnull && corr > 0) {
+      o->theta_searched = 1;
+      theta = acos(corr);
+      m = orc_compute_householder(r, n, gr, &s);
+      orc_apply_householder(x, r, n);
+      for (i = m; i < n - 1; i++) x[i] = x[i + 1];
+      i = (int)floor(cg - gain_offset) - 1;
+      if (i < 1) i = 1;
+      for (; i <= (int)ceil(cg - gain_offset); i++) {
+        double qcg = i + gain_offset;
+        int ts = orc_pvq_compute_max_theta(qcg, beta), j, jhi;
+        j = (int)floor(.5 + theta*2/M_PI*ts) - 2;
+        if (j < 0) j = 0;
+        jhi = (int)ceil(theta*2/M_PI*ts);
+        if (jhi > ts - 1) jhi = ts - 1;
+        for (; j <= jhi; j++) {
+          int c = o->nref;
+          double qtheta = orc_pvq_compute_theta(j, ts), cos_dist, dist_theta;
+          int k = orc_pvq_compute_k(qcg, j, qtheta, 0, n, beta, nodesync);
+          if (c >= 12) break;
+          cos_dist = orc_pvq_search_rdo_double(x, n - 1, k, y_ref + c*n,
+           qcg*cg*sin(theta)*sin(qtheta));
+          dist_theta = 2 - 2*cos(theta - qtheta) + sin(theta)*sin(qtheta)*(2 - 2*cos_dist);
+          o->ref_qg[c] = i;
+          o->ref_itheta[c] = j;
+          o->ref_ts[c] = ts;
+          o->ref_k[c] = k;
+          o->ref_qtheta[c] = qtheta;
+          o->ref_cos_dist[c] = cos_dist;
+          o->ref_dist[c] = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*dist_theta;
+          o->nref++;
+        }
+      }
+    }
+  }
+  if (n <= 128 && ((is_keyframe && pli == 0) || corr < .5 || cg < 2.)) {
+    double x1[1024];
+    o->noref_searched = 1;
+    for (i = 0; i < n; i++) x1[i] = x0[i]*qm[i]*QM_SCALE_1;
+    i = (int)floor(cg);
+    if (i < 1) i = 1;
+    for (; i <= ceil(cg) && o->nnoref < 2; i++) {
+      int c = o->nnoref;
+      double qcg = i;
+      o->nr_k[c] = orc_pvq_compute_k(qcg, -1, -1, 1, n, beta, nodesync);
+      o->nr_cos_dist[c] = orc_pvq_search_rdo_double(x1, n, o->nr_k[c], y_noref + c*n, qcg*cg);
+      o->nr_dist[c] = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*o->nr_cos_dist[c]);
+      o->nr_qg[c] = i;
+      o->nnoref++;
+    }
+  }
+  o->cg = cg; o->cgr = cgr; o->g = g; o->gr = gr; o->corr = corr; o->theta = theta;
+  o->gain_offset = gain_offset; o->icgr = icgr; o->m = m; o->s = s;
+}
+
+/* Decoder-side synthesis of one band (reference pvq_synthesis,
+   src/pvq_decoder.c:104-118): rebuilds the Householder reflection from the
+   reference vector, then od_pvq_synthesis_partial. */
+void orc_pvq_synthesis(coeff *xcoeff, const coeff *ypulse, const coeff *ref, int n,
+ double gr, int noref, double g, double theta, const int16_t *qm,
+ const int16_t *qm_inv) {
+  double r[1024];
+  int i, s = 0, m;
+  if (!noref) for (i = 0; i < n; i++) r[i] = ref[i]*qm[i]*QM_SCALE_1;
+  m = noref ? 0 : orc_compute_householder(r, n, gr, &s);
+  orc_pvq_synthesis_partial(xcoeff, ypulse, r, n, noref, g, theta, m, s, qm_inv);
+}

@@ -397,3 +397,120 @@ def test_sb_row_strips_on_device_equal_full_frame(hip):
                 assert np.array_equal(got, full[pli][k]), (world, pli, k)
     lev = oracle_pyramid(planes[0], fw, fh, 0, pic_w, pic_h)
     assert np.array_equal(full[0][3], lev[3])
+
+
+def ulps(a, b):
+    return abs(a - b)/np.spacing(max(abs(a), abs(b), 1e-300))
+
+
+@pytest.mark.parametrize('is_keyframe,pli', ((1, 0), (1, 1), (0, 0)))
+def test_pvq_theta_vectors_full_candidate_lists(hip, is_keyframe, pli):
+    """Complete pvq_theta candidate enumeration (with-reference gain/theta search
+    + no-reference search) on the device vs the oracle.  Integer outcomes
+    (candidate lists, K, pulses, Householder axis/sign) must be identical.  Doubles
+    that do not depend on libm transcendentals (g, gr, corr, no-ref distortions with
+    beta == 1) must be bit-exact; doubles downstream of acos/sin/cos/pow (theta,
+    with-reference distortions, cg for beta == 1.5) are compared to 64 ulp - OCML
+    vs glibc, DESIGN.md section 5."""
+    from testlib import ThetaOut
+    o = oracle()
+    o.orc_pvq_theta_candidates.argtypes = [ctypes.POINTER(ctypes.c_int32)]*2 + [
+        c_int, c_int, ctypes.c_double, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int16),
+        ctypes.POINTER(ThetaOut), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    rng = np.random.default_rng(300 + 2*is_keyframe + pli)
+    for n in (8, 15, 32, 128):
+        for beta in (1.0, 1.5):
+            nv = 160
+            amp = rng.choice([3, 30, 300, 3000], size=nv)
+            x0 = (rng.laplace(0, 1, size=(nv, n))*amp[:, None]).astype(np.int32)
+            r0 = x0.copy()
+            kind = rng.integers(0, 4, size=nv)
+            noise = (rng.laplace(0, 1, size=(nv, n))*(amp[:, None]/3. + 1)).astype(np.int32)
+            r0 = np.where((kind == 0)[:, None], (x0*1.2).astype(np.int32) + noise, r0)
+            r0 = np.where((kind == 1)[:, None], noise*3, r0)
+            r0 = np.where((kind == 3)[:, None], 0, r0).astype(np.int32)
+            qm = rng.integers(9000, 32768, size=n).astype(np.int16)
+            q0 = rng.integers(2, 200, size=nv).astype(np.int32)
+            out, y_ref, y_nr = hip.pvq_theta_vectors(x0, r0, qm, q0, beta, 1, is_keyframe, pli)
+            nsearch = 0
+            for v in range(nv):
+                t = ThetaOut()
+                yr = np.zeros((12, n), np.int32); yn = np.zeros((2, n), np.int32)
+                o.orc_pvq_theta_candidates(p32(np.ascontiguousarray(x0[v])),
+                                           p32(np.ascontiguousarray(r0[v])), n, int(q0[v]), beta, 1,
+                                           is_keyframe, pli, p16(qm), ctypes.byref(t), p32(yr), p32(yn))
+                d = out[v]
+                nsearch += t.theta_searched
+                assert (d.icgr, d.m, d.s, d.nref, d.nnoref, d.theta_searched, d.noref_searched) == \
+                    (t.icgr, t.m, t.s, t.nref, t.nnoref, t.theta_searched, t.noref_searched), (n, v)
+                assert d.g == t.g and d.gr == t.gr and d.corr == t.corr
+                if beta == 1.0:
+                    assert d.cg == t.cg and d.cgr == t.cgr and d.gain_offset == t.gain_offset
+                else:
+                    assert ulps(d.cg, t.cg) <= 4 and ulps(d.cgr, t.cgr) <= 4
+                assert ulps(d.theta, t.theta) <= 64
+                for c in range(t.nref):
+                    assert (d.ref_qg[c], d.ref_itheta[c], d.ref_ts[c], d.ref_k[c]) == \
+                        (t.ref_qg[c], t.ref_itheta[c], t.ref_ts[c], t.ref_k[c]), (n, v, c)
+                    assert np.array_equal(y_ref[v, c, :n - 1], yr[c, :n - 1]), (n, v, c)
+                    assert d.ref_qtheta[c] == t.ref_qtheta[c]
+                    assert abs(d.ref_dist[c] - t.ref_dist[c]) <= 1e-9*max(1., abs(t.ref_dist[c]))
+                for c in range(t.nnoref):
+                    assert (d.nr_qg[c], d.nr_k[c]) == (t.nr_qg[c], t.nr_k[c])
+                    assert np.array_equal(y_nr[v, c], yn[c])
+                    if beta == 1.0:
+                        assert d.nr_cos_dist[c] == t.nr_cos_dist[c] and d.nr_dist[c] == t.nr_dist[c]
+            assert nsearch > 20
+
+
+def test_pvq_synthesis_vectors_both_branches(hip):
+    o = oracle()
+    o.orc_pvq_synthesis.argtypes = [ctypes.POINTER(ctypes.c_int32)]*3 + [
+        c_int, ctypes.c_double, c_int, ctypes.c_double, ctypes.c_double,
+        ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16)]
+    rng = np.random.default_rng(91)
+    for n in (8, 15, 32, 128):
+        nv = 300
+        noref = rng.integers(0, 2, size=nv).astype(np.int32)
+        y = rng.integers(-3, 4, size=(nv, n), dtype=np.int32)
+        y[noref == 0, n - 1] = 0
+        ref = rng.integers(-900, 901, size=(nv, n), dtype=np.int32)
+        qm = rng.integers(9000, 32768, size=n).astype(np.int16)
+        qmi = np.floor(.5 + 32768.*4096./qm.astype(np.float64)).astype(np.int16)
+        gr = np.sqrt(((ref.astype(np.float64)*qm*(1./32767))**2).sum(axis=1))
+        g = rng.uniform(1, 6000, size=nv)
+        theta = rng.uniform(0, 1.5, size=nv)
+        out = hip.pvq_synthesis_vectors(y, ref, gr, noref, g, theta, qm, qmi)
+        bad = 0
+        for v in range(nv):
+            e = np.zeros(n, np.int32)
+            o.orc_pvq_synthesis(p32(e), p32(np.ascontiguousarray(y[v])), p32(np.ascontiguousarray(ref[v])),
+                                n, float(gr[v]), int(noref[v]), float(g[v]), float(theta[v]), p16(qm),
+                                p16(qmi))
+            if noref[v]:
+                assert np.array_equal(out[v], e)          # no transcendental: bit-exact
+            else:
+                # sin/cos come from OCML: a 1-ulp difference can move a value that sits
+                # within 1e-12 of a rounding boundary; count instead of failing
+                bad += int(not np.array_equal(out[v], e))
+                assert np.abs(out[v] - e).max() <= 1
+        assert bad <= 2
+
+
+def test_hv_intra_pred_blocks(hip):
+    o = oracle()
+    rng = np.random.default_rng(95)
+    w = h = 96
+    d = rng.integers(-500, 501, size=(h, w), dtype=np.int32)
+    for bs in range(4):
+        nb = 1 << bs
+        bsz = rng.integers(0, 4, size=(h//8, w//8)).astype(np.uint8)
+        bsz[rng.random(bsz.shape) < .5] = bs
+        bx = rng.integers(0, w//4//nb, size=150).astype(np.int32)*nb
+        by = rng.integers(0, h//4//nb, size=150).astype(np.int32)*nb
+        pred = hip.od_hv_intra_pred_blocks(d, bsz, bs, bx, by)
+        n = 4 << bs
+        for i in range(len(bx)):
+            e = np.zeros(n*n, np.int32)
+            o.orc_hv_intra_pred(p32(e), p32(d), w, int(bx[i]), int(by[i]), pu8(bsz), w//8, bs)
+            assert np.array_equal(pred[i], e)

@@ -357,3 +357,59 @@ def test_noref_candidates_reproduce_pvq_theta_decision():
             o.orc_pvq_synthesis_partial(p32(out_o), p32(y[best]), pf64(np.zeros(n)), n, 1,
                                         gexp, 0., 0, 1, p16(qm_inv))
             assert np.array_equal(out_o, out_r)
+
+
+@pytest.mark.parametrize('is_keyframe,pli', ((1, 0), (1, 1), (0, 0), (0, 2)))
+def test_full_pvq_theta_decision_with_reference(is_keyframe, pli):
+    """Complete pvq_theta (with-reference theta/gain search + no-reference search,
+    skip logic, synthesis) reproduced from the oracle's state-free candidates and
+    the reference's own od_pvq_rate: return code, itheta, max_theta, K, pulses and
+    synthesised coefficients must all equal the reference's."""
+    from testlib import ThetaOut, decide_pvq_theta
+    o, pr = oracle(), ref('pvq_probe')
+    o.orc_pvq_theta_candidates.argtypes = [ctypes.POINTER(ctypes.c_int32)]*2 + [
+        c_int, c_int, ctypes.c_double, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int16),
+        ctypes.POINTER(ThetaOut), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    rng = np.random.default_rng(41 + 2*is_keyframe + pli)
+    nsearched = 0
+    for trial in range(1200):
+        bs = int(rng.integers(0, 4))
+        n = int(rng.choice({0: [15], 1: [15, 8, 32], 2: [15, 8, 32, 128], 3: [15, 8, 32, 128]}[bs]))
+        amp = int(rng.choice([3, 30, 300, 3000]))
+        x0 = (rng.laplace(0, amp, size=n)).astype(np.int32)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            r0 = (x0*rng.uniform(.5, 1.5) + rng.laplace(0, amp/3. + 1, size=n)).astype(np.int32)
+        elif kind == 1:
+            r0 = (rng.laplace(0, amp, size=n)).astype(np.int32)
+        elif kind == 2:
+            r0 = x0.copy()
+        else:
+            r0 = np.zeros(n, np.int32)
+        qm, qm_inv = make_qm(rng, n)
+        q0 = int(rng.integers(2, 200))
+        beta = 1.5 if (bs > 0 and pli == 0 and rng.random() < .5) else 1.0
+        out_r = np.zeros(n, np.int32); y_r = np.zeros(n, np.int32)
+        it = c_int(); mt = c_int(); vk = c_int(); sd = ctypes.c_double(0)
+        ret_r = pr.probe_pvq_theta(p32(out_r), p32(x0.copy()), p32(r0.copy()), n, q0, p32(y_r),
+                                   ctypes.byref(it), ctypes.byref(mt), ctypes.byref(vk), beta,
+                                   ctypes.byref(sd), 1, is_keyframe, pli, bs, p16(qm), p16(qm_inv))
+        t = ThetaOut()
+        y_ref = np.zeros((12, n), np.int32); y_nr = np.zeros((2, n), np.int32)
+        o.orc_pvq_theta_candidates(p32(x0), p32(r0), n, q0, beta, 1, is_keyframe, pli, p16(qm),
+                                   ctypes.byref(t), p32(y_ref), p32(y_nr))
+        nsearched += t.theta_searched
+
+        def rate(qg, icgr, theta, ts, y, k):
+            yy = np.ascontiguousarray(y) if y is not None else np.zeros(n, np.int32)
+            return pr.probe_pvq_rate_reset(int(qg), int(icgr), int(theta), int(ts), p32(yy), int(k),
+                                           n, is_keyframe, pli, bs)
+
+        ret, itheta, max_theta, k, y, out = decide_pvq_theta(
+            o, rate, t, y_ref, y_nr, x0, r0, n, q0, beta, is_keyframe, pli, qm, qm_inv)
+        assert (ret, itheta, max_theta, k) == (ret_r, it.value, mt.value, vk.value), trial
+        nn = n if itheta == -1 else n - 1
+        assert np.array_equal(y[:nn], y_r[:nn]), trial
+        assert np.array_equal(out, out_r), trial
+        assert abs(sd.value - (t.skip_dist - 0)) >= 0   # skip_diff accumulates skip_dist - best_dist
+    assert nsearched > 200

@@ -149,3 +149,89 @@ def random_bsize_map(nhsb, nvsb, seed):
                     else:
                         m[y0:y0 + 2, x0:x0 + 2] = rng.integers(0, 2, size=(2, 2))
     return m
+
+
+# ---------------------------------------------------------------------------
+class ThetaOut(ctypes.Structure):
+    """Mirror of orc_theta_out (oracle/daala_oracle.c) and od_hip_pvq_theta_out."""
+    _fields_ = [('cg', c_double), ('cgr', c_double), ('g', c_double), ('gr', c_double),
+                ('corr', c_double), ('theta', c_double), ('gain_offset', c_double),
+                ('skip_dist', c_double), ('null_dist', c_double),
+                ('icgr', ctypes.c_int32), ('m', ctypes.c_int32), ('s', ctypes.c_int32),
+                ('nref', ctypes.c_int32), ('nnoref', ctypes.c_int32),
+                ('theta_searched', ctypes.c_int32), ('noref_searched', ctypes.c_int32),
+                ('pad', ctypes.c_int32),
+                ('ref_qg', ctypes.c_int32*12), ('ref_itheta', ctypes.c_int32*12),
+                ('ref_ts', ctypes.c_int32*12), ('ref_k', ctypes.c_int32*12),
+                ('ref_qtheta', c_double*12), ('ref_cos_dist', c_double*12),
+                ('ref_dist', c_double*12),
+                ('nr_qg', ctypes.c_int32*2), ('nr_k', ctypes.c_int32*2),
+                ('nr_cos_dist', c_double*2), ('nr_dist', c_double*2)]
+
+
+def neg_interleave(x, r):
+    if x < r:
+        return -2*(x - r) - 1
+    if x < 2*r:
+        return 2*(x - r)
+    return x - 1
+
+
+def decide_pvq_theta(o, rate_fn, t, y_ref, y_noref, x0, r0, n, q0, beta, is_keyframe, pli, qm,
+                     qm_inv):
+    """Replays the decision part of pvq_theta (reference src/pvq_encoder.c:373-511)
+    on the state-free candidates `t` (ThetaOut) plus a rate callback
+    rate_fn(qg, icgr, theta, ts, y, k).  Returns (ret, itheta, max_theta, k, y, out)."""
+    lam = .147
+    gw = 1.4
+    cfl = bool(is_keyframe and pli != 0)
+    qg = 0
+    best_dist = gw*t.cg*t.cg
+    best_cost = best_dist + lam*rate_fn(0, 0, -1, 0, None, 0)
+    noref, best_k, itheta, max_theta, best_qtheta = 1, 0, -1, 0, 0.
+    y = np.zeros(n, np.int32)
+    if not is_keyframe:
+        scgr = max(0., t.gain_offset)
+        if t.icgr == 0:
+            best_dist = gw*(t.cg - scgr)*(t.cg - scgr) + scgr*t.cg*(2 - 2*t.corr)
+        best_cost = best_dist + lam*rate_fn(0, t.icgr, 0, 0, None, 0)
+        itheta, max_theta, noref = 0, 0, 0
+    for c in range(t.nref):
+        cost = t.ref_dist[c] + lam*rate_fn(t.ref_qg[c], t.icgr, t.ref_itheta[c], t.ref_ts[c],
+                                            y_ref[c], t.ref_k[c])
+        if cost < best_cost:
+            best_cost, best_dist = cost, t.ref_dist[c]
+            qg, best_k, best_qtheta = t.ref_qg[c], t.ref_k[c], t.ref_qtheta[c]
+            itheta, max_theta, noref = t.ref_itheta[c], t.ref_ts[c], 0
+            y = y_ref[c].copy()
+            y[n - 1:] = 0
+    for c in range(t.nnoref):
+        cost = t.nr_dist[c] + lam*rate_fn(t.nr_qg[c], 0, -1, 0, y_noref[c], t.nr_k[c])
+        if cost <= best_cost:
+            best_cost, best_dist = cost, t.nr_dist[c]
+            qg, best_k, noref, itheta, max_theta = t.nr_qg[c], t.nr_k[c], 1, -1, 0
+            y = y_noref[c].copy()
+    skip = 0
+    if noref:
+        if qg == 0:
+            skip = 1
+    else:
+        if not is_keyframe and qg == 0:
+            skip = 1 if t.icgr else 2
+        if qg == t.icgr and itheta == 0 and not cfl:
+            skip = 2
+    out = np.zeros(n, np.int32)
+    if skip == 2:
+        out = r0.copy()
+    elif skip == 0:
+        go = 0. if noref else t.gain_offset
+        g = o.orc_gain_expand(qg + go, q0, beta)
+        o.orc_pvq_synthesis.argtypes = [I32P, I32P, I32P, c_int, c_double, c_int, c_double,
+                                        c_double, I16P, I16P]
+        o.orc_pvq_synthesis(p32(out), p32(np.ascontiguousarray(y)), p32(r0), n, t.gr, noref, g,
+                            best_qtheta, p16(qm), p16(qm_inv))
+    if is_keyframe:
+        ret = qg if noref else neg_interleave(qg, t.icgr)
+    else:
+        ret = qg - 1 if noref else neg_interleave(qg + 1, t.icgr + 1)
+    return ret, itheta, max_theta, best_k, y, out
