@@ -635,7 +635,8 @@ template <int N>
 __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelArgs3 aa) {
   const PvqLevelArgs &a = aa.a;
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
-  __shared__ int32_t Yst[BPW*N + 1];
+  __shared__ int32_t Yst[BPW*N + 1 + BPW*(G + 1)];
+  __shared__ int32_t Org[64];
   const int lane = threadIdx.x;
   const int g = lane%G, inst = lane/G;
   const long blk0 = (long)blockIdx.x*BPW;
@@ -649,10 +650,19 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
   const size_t rin = (size_t)band*nblk + (live ? blk : 0);
   const size_t rec = (size_t)f*a.rec_fstride + rin;
   const size_t rec2 = (size_t)f*2*a.rec_fstride + rin;
-  // gather this lane's chunk: coefficient and QM entry
+  // Gather the band of the wave's BPW blocks.  Reading "lane = block" straight
+  // from the raster level plane costs one L1 transaction per lane (64 per load):
+  // the first profile showed the N = 15 kernel bound by exactly that rate.  So
+  // the wave loads cooperatively with lane = coefficient-within-block (lanes that
+  // share a block share its few 64-byte sectors), stages in LDS and every lane
+  // then picks up its own chunk.
+  constexpr int CH = NL + 1;                       // padded chunk stride in LDS
+  constexpr int LDSN = (G*CH) | 1;                 // odd per-band stride
+  static_assert(BPW*LDSN <= BPW*N + 1 + BPW*(G + 1), "staging fits");
   int32_t cf[NL];
   int qi[NL];
-  {
+  constexpr bool STAGE = N > 32;   // measured: pays for the 128-coefficient bands only
+  if (!STAGE) {
     const long bsafe = live ? blk : 0;
     const int bx = bsafe%a.nbx, by = bsafe/a.nbx;
     const int32_t *src = a.lev + (size_t)f*a.lev_fstride + (size_t)(by*a.n)*a.w + bx*a.n;
@@ -666,6 +676,33 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
       }
       else { cf[j] = 0; qi[j] = 0; }
     }
+  }
+  else {
+    const int32_t *plane = a.lev + (size_t)f*a.lev_fstride;
+    const int nb_here = (int)(nblk - blk0 < BPW ? nblk - blk0 : BPW);
+    if (lane < nb_here) {                          // block origins: one division per block
+      const long bb = blk0 + lane;
+      const int bx = bb%a.nbx, by = bb/a.nbx;
+      Org[lane] = (by*a.n)*a.w + bx*a.n;
+    }
+    __syncthreads();
+    const int lg = a.n == 4 ? 2 : a.n == 8 ? 3 : a.n == 16 ? 4 : 5;
+    for (int e = lane; e < nb_here*N; e += 64) {
+      const int b = e/N, jj = e%N;
+      const int ro = a.tab[o0 + jj];
+      Yst[b*LDSN + (jj/NL)*CH + jj%NL] = plane[(size_t)Org[b] + (ro >> lg)*a.w + (ro & (a.n - 1))];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int jj = g*NL + j;
+      if (live && jj < N) {
+        cf[j] = Yst[inst*LDSN + g*CH + j];
+        qi[j] = a.qm[o0 + jj];
+      }
+      else { cf[j] = 0; qi[j] = 0; }
+    }
+    __syncthreads();
   }
   // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
   const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
