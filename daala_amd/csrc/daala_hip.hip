@@ -926,6 +926,44 @@ int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h, const unsigned 
   return 0;
 }
 
+int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out) {
+  if (!x || !y || !out) return fail(OD_HIP_EFAULT, "null pointer");
+  if (n < 0 || fn < 0 || fn > 6) return fail(OD_HIP_EINVAL, "bad arguments");
+  if (int rc = ensure_device()) return rc;
+  if (n == 0) return 0;
+  size_t nb = (size_t)n*8;
+  if (int rc = g_in.reserve(nb)) return rc;
+  if (int rc = g_aux0.reserve(nb)) return rc;
+  if (int rc = g_out.reserve(nb)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, x, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, y, nb, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_libm_probe, dim3((n + 255)/256), dim3(256), 0, 0, fn, n,
+                     (const double *)g_in.p, (const double *)g_aux0.p, (double *)g_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, nb, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int od_hip_calibrate_traffic(int mode, size_t bytes) {
+  if (mode < 0 || mode > 2 || bytes < 1024) return fail(OD_HIP_EINVAL, "bad arguments");
+  if (int rc = ensure_device()) return rc;
+  bytes &= ~(size_t)1023;
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_aux0.reserve(64)) return rc;
+  HIPCHK(hipMemset(g_in.p, 1, bytes));
+  HIPCHK(hipDeviceSynchronize());
+  dim3 grid(2048), blk(256);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_calib_read_dword, grid, blk, 0, 0, (const uint32_t *)g_in.p, bytes/4, (uint32_t *)g_aux0.p);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_calib_read_int4, grid, blk, 0, 0, (const int4 *)g_in.p, bytes/16, (uint32_t *)g_aux0.p);
+  else
+    hipLaunchKernelGGL(k_calib_write_int4, grid, blk, 0, 0, (int4 *)g_in.p, bytes/16);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
 int od_hip_sync(od_hip_ctx *ctx) {
   if (!ctx) return fail(OD_HIP_EFAULT, "null context");
   HIPCHK(hipSetDevice(ctx->device));

@@ -106,11 +106,41 @@ __device__ __forceinline__ int pvq_k_noref(double qcg, int n, double beta) {
   return k > 1 ? k : 1;
 }
 
-// od_gain_compand (src/pvq.c:422-425).  beta != 1 goes through the device pow():
-// value parity with glibc pow is NOT pinned.
+// x^(1/1.5) rounded to nearest, for the only non-trivial beta the codec uses
+// (OD_PVQ_BETA, src/pvq.c:230: 1 or 1.5).  The reference calls libm
+// pow(x, 1./1.5); glibc's pow is accurate to < 0.52 ulp, i.e. it returns the
+// correctly rounded value except when the true result lies within ~0.02 ulp of a
+// rounding boundary.  OCML's pow is only good to ~1 ulp (measured: 24 % of results
+// differ from glibc by 1 ulp), so the value is computed here in double-double:
+//   y = 1./1.5 as a double is 2/3 - d,  d = 2^-54/1.5 ... exactly (2/3 - y);
+//   x^y = cbrt(x^2) * exp(-d*ln x),  cbrt refined by one Newton step evaluated in
+//   double-double (error ~1e-32), the exp factor is 1 - d*ln x to first order
+//   (|d*ln x| < 3e-15, second order < 1e-29).
+// Explicit fma() only builds exact products/residuals; nothing here is contracted.
+__device__ inline double pvq_pow_2_3(double x) {
+  if (!(x > 0)) return x == 0 ? 0. : pow(x, 1./1.5);
+  // exact x^2 = zh + zl
+  const double zh = x*x, zl = fma(x, x, -zh);
+  const double c0 = cbrt(zh);
+  // c0^2 = ph + pl, c0^3 = th + tl (tl to first order)
+  const double ph = c0*c0, pl = fma(c0, c0, -ph);
+  const double th = ph*c0, tl = fma(ph, c0, -th) + pl*c0;
+  // residual r = (zh + zl) - (th + tl), the leading terms cancel exactly
+  const double r = ((zh - th) - tl) + zl;
+  const double e = r/(3.*ph);                       // Newton correction, |e| < 2 ulp(c0)
+  // exponent correction: y = 1./1.5 is 2/3 - d with d = (2/3 - y) exactly:
+  // 1./1.5 = 0x3FE5555555555555 => d = 2/3 - y = 2^-54 * (2/3) ... = 3.700743415417188e-17
+  const double d = 3.7007434154171883e-17;
+  const double corr = e - c0*(d*log(x));
+  return c0 + corr;
+}
+
+// od_gain_compand (src/pvq.c:422-425).
 __device__ __forceinline__ double pvq_gain_compand(double g, int q0, double beta) {
   if (beta == 1) return g/q0;
-  return PVQ_COMPAND_SCALE*pow(g*(1./PVQ_COMPAND_SCALE), 1./beta)/q0;
+  const double x = g*(1./PVQ_COMPAND_SCALE);
+  const double p = beta == 1.5 ? pvq_pow_2_3(x) : pow(x, 1./beta);
+  return PVQ_COMPAND_SCALE*p/q0;
 }
 
 __global__ void k_pvq_search_vectors(int n, int nvec, const double *__restrict__ x,

@@ -239,3 +239,23 @@ __global__ void k_hv_intra_pred_blocks(const int32_t *__restrict__ d, int w,
   }
   else if (left) for (int i = 1; i < 4; i++) pred[i*n] = t[-n + i*w];
 }
+
+// Diagnostic: evaluates the transcendental functions the PVQ path uses so that
+// tests can quantify OCML vs host-libm agreement.
+// fn: 0 pow(x, y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y, 6 pvq_pow_2_3(x).
+__global__ void k_libm_probe(int fn, int n, const double *__restrict__ x,
+                             const double *__restrict__ y, double *__restrict__ out) {
+  const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  switch (fn) {
+    case 0: r = pow(x[i], y[i]); break;
+    case 1: r = acos(x[i]); break;
+    case 2: r = sin(x[i]); break;
+    case 3: r = cos(x[i]); break;
+    case 4: r = sqrt(x[i]); break;
+    case 6: r = pvq_pow_2_3(x[i]); break;
+    default: r = x[i]/y[i]; break;
+  }
+  out[i] = r;
+}

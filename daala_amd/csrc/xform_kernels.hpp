@@ -499,3 +499,29 @@ __global__ void k_resample_luma_420(int32_t *__restrict__ pred, const int32_t *_
   if (y < 4 && x < 4) v = (S[x][y]*v + 64) >> 7;
   pred[e] = v;
 }
+
+// Calibration kernels for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters
+// (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE under-reports wide
+// streaming reads by 2x and other widths are uncalibrated): stream a buffer of
+// known size with the SAME access widths the transform kernels use - dword loads
+// (the u8 pixel tile), int4 loads (coefficient tiles) and int4 stores.
+__global__ void k_calib_read_dword(const uint32_t *__restrict__ src, size_t n, uint32_t *sink) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x)
+    acc ^= src[i];
+  if (acc == 0x12345678u) *sink = acc;
+}
+
+__global__ void k_calib_read_int4(const int4 *__restrict__ src, size_t n, uint32_t *sink) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x) {
+    int4 v = src[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+
+__global__ void k_calib_write_int4(int4 *__restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x)
+    dst[i] = make_int4((int)i, 1, 2, 3);
+}

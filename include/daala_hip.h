@@ -233,6 +233,17 @@ int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h,
  const unsigned char *bsize, int bstride, int bs, int nblk, const int32_t *bx,
  const int32_t *by, od_coeff *pred);
 
+/* Diagnostic: the device's pow/acos/sin/cos/sqrt/divide on n doubles, so tests can
+ * quantify agreement with the host libm the reference uses.
+ * fn: 0 pow(x,y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y. */
+int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out);
+
+/* Profiling aid: streams a `bytes`-sized device buffer once with the access width
+ * the transform kernels use (mode 0: dword loads, 1: int4 loads, 2: int4 stores) so
+ * that the rocprofv3 FETCH_SIZE / WRITE_SIZE counters can be calibrated against a
+ * known byte count (tools/profile_round.sh). */
+int od_hip_calibrate_traffic(int mode, size_t bytes);
+
 /* Synchronise the context's stream / time its last batch (ms, HIP events). */
 int od_hip_sync(od_hip_ctx *ctx);
 
