@@ -107,6 +107,37 @@ def cpu_reference_encoder(frames, nframes):
             'what': 'full reference encoder incl. entropy coding + RDO (oracle/_ref)'}
 
 
+KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel name
+    'k_forward_pyramid_luma': 'k_forward_rt<32, 4, false>',
+    'k_forward_pyramid_chroma': 'k_forward_rt<16, 3, false>',
+    'k_forward_known_luma': 'k_forward_rt<32, 4, true>',
+    'k_forward_known_chroma': 'k_forward_rt<16, 3, true>',
+    'k_inverse_sb_luma': 'k_inverse_rt<32, 4>',
+    'k_inverse_sb_chroma': 'k_inverse_rt<16, 3>',
+    'k_postfilter_clamp_luma': 'k_postfilter_clamp<32>',
+    'k_postfilter_clamp_chroma': 'k_postfilter_clamp<16>',
+}
+
+
+def measured_traffic(label):
+    """HBM bytes per launch of a kernel from the newest committed PMC profile
+    (profiles/*_traffic.json: FETCH_SIZE and WRITE_SIZE from separate rocprofv3
+    --pmc passes of this same bench, calibrated with known-size streams;
+    tools/profile_round.sh + tools/summarize_profile.py).  None if absent: the
+    counters cannot be read from inside an un-profiled run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    for name, v in t['kernels'].items():
+        if KERNEL_SYMBOL.get(label, '\0') in name:
+            return {'hbm_bytes_per_launch': int(v['hbm_bytes']), 'fetch_bytes': int(v['fetch_bytes']),
+                    'write_bytes': int(v['write_bytes']), 'source': os.path.basename(files[-1])}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -209,6 +240,7 @@ def main():
         hb = {k: v for k, v in kernels.items() if k in alg_bytes}
         dom = max(hb, key=lambda k: hb[k]['avg_ms']*hb[k]['launches'])
         ach = hb[dom]['GBps']
+        traffic = measured_traffic(dom)
         line = {
             'metric': 'encode Mpixels/s (intra hot path: lapping+DCT pyramid, PVQ no-ref '
                       'search, known-size forward, inverse; bit-exact vs oracle)',
@@ -222,7 +254,8 @@ def main():
                        'frames_per_gpu': FRAMES, 'parallelism': 'independent frames per GPU'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 2),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 5),
-                         'traffic': None},
+                         'algorithmic_bytes_per_launch': alg_bytes[dom],
+                         'traffic': traffic},
             'kernels': {k: {kk: round(vv, 4) if isinstance(vv, float) else vv
                             for kk, vv in v.items()} for k, v in kernels.items()},
         }

@@ -32,6 +32,21 @@ __device__ __forceinline__ void rt_lap4_pre16(int16_t *p, int stride) {
   p[0] = (int16_t)x0; p[stride] = (int16_t)x1; p[2*stride] = (int16_t)x2; p[3*stride] = (int16_t)x3;
 }
 
+// XCD-aware tile order (cdna guide T1).  Workgroups are dealt round-robin over the
+// 8 XCDs, each with its own L2; neighbouring tiles share input sectors (2-sample
+// halo, 64-byte sectors), so each XCD is given a CONTIGUOUS run of tiles.  Pure
+// speed: any mapping is correct.  Bijective for every grid size.
+__device__ __forceinline__ void rt_tile_coords(int &tx, int &sby, int &f) {
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  const unsigned total = gx*gy*gridDim.z;
+  const unsigned lin = blockIdx.x + gx*(blockIdx.y + gy*blockIdx.z);
+  const unsigned q = total/8, r = total%8, xcd = lin%8, idx = lin/8;
+  const unsigned m = (xcd < r ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q) + idx;
+  tx = m%gx;
+  sby = (m/gx)%gy;
+  f = m/(gx*gy);
+}
+
 template <int SB> struct RowTile {
   static constexpr int W = 64;               // tile width (samples)
   static constexpr int NSB = W/SB;           // superblocks per tile
@@ -124,7 +139,8 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
   __shared__ uint8_t bsz[16*T::NSB];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  const int tx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
+  int tx, sby, f;
+  rt_tile_coords(tx, sby, f);
   const int x0 = tx*T::W, y0 = sby*SB;
   const int sbx0 = tx*T::NSB;                          // first superblock of the tile
   const int nsb = min(T::NSB, a.nhsb - sbx0);          // superblocks really present
@@ -342,7 +358,8 @@ __global__ __launch_bounds__(64) void k_inverse_rt(InvArgs a) {
   __shared__ int32_t Z[SB*T::LDZ];
   __shared__ uint8_t bsz[16*T::NSB];
   const int lane = threadIdx.x;
-  const int tx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
+  int tx, sby, f;
+  rt_tile_coords(tx, sby, f);
   const int x0 = tx*T::W, y0 = sby*SB;
   const int sbx0 = tx*T::NSB;
   const int nsb = min(T::NSB, a.nhsb - sbx0);
