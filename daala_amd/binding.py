@@ -381,3 +381,15 @@ def od_hv_intra_pred_blocks(d, bsize, bs, bx, by):
     _chk(lib.od_hip_hv_intra_pred_blocks(_p32(d), w, h, bsize.ctypes.data_as(U8P), bsize.shape[1],
                                          bs, len(bx), _p32(bx), _p32(by), _p32(pred)))
     return pred
+
+
+def od_compute_dist_blocks(bs, x, y, mag2, activity_masking):
+    lib = load()
+    x = _c32(x)
+    y = _c32(y)
+    mag2 = np.ascontiguousarray(mag2, dtype=np.float64)
+    out = np.empty(x.shape[0], np.float64)
+    lib.od_hip_compute_dist_blocks.argtypes = [c_int, c_int, I32P, I32P, F64P, c_int, F64P]
+    _chk(lib.od_hip_compute_dist_blocks(bs, x.shape[0], _p32(x), _p32(y), mag2.ctypes.data_as(F64P),
+                                        int(activity_masking), out.ctypes.data_as(F64P)))
+    return out

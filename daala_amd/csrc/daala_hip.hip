@@ -926,6 +926,28 @@ int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h, const unsigned 
   return 0;
 }
 
+int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coeff *y,
+                               const double *mag2, int activity_masking, double *dist) {
+  if (!x || !y || !mag2 || !dist) return fail(OD_HIP_EFAULT, "null pointer");
+  if (bs < 1 || bs >= OD_HIP_NBSIZES || nblk < 0) return fail(OD_HIP_EINVAL, "bad bs/nblk");
+  if (int rc = ensure_device()) return rc;
+  if (nblk == 0) return 0;
+  size_t n = 4u << bs, bytes = (size_t)nblk*n*n*4;
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_aux0.reserve(bytes)) return rc;
+  if (int rc = g_aux1.reserve(64*8)) return rc;
+  if (int rc = g_out.reserve((size_t)nblk*8)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, x, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, y, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux1.p, mag2, 64*8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_compute_dist_blocks, dim3((nblk + 63)/64), dim3(64), 0, 0, (int)n, nblk,
+                     (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const double *)g_aux1.p,
+                     activity_masking, (double *)g_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(dist, g_out.p, (size_t)nblk*8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out) {
   if (!x || !y || !out) return fail(OD_HIP_EFAULT, "null pointer");
   if (n < 0 || fn < 0 || fn > 6) return fail(OD_HIP_EINVAL, "bad arguments");

@@ -12,6 +12,7 @@
 // coefficients) is required identical in tests/ (DESIGN.md section 5).
 #pragma once
 #include "pvq_kernels.hpp"
+#include "gen_lift_dct.hpp"
 
 struct PvqThetaOut {       // == od_hip_pvq_theta_out == orc_theta_out
   double cg, cgr, g, gr, corr, theta, gain_offset, skip_dist, null_dist;
@@ -258,4 +259,75 @@ __global__ void k_libm_probe(int fn, int n, const double *__restrict__ x,
     default: r = x[i]/y[i]; break;
   }
   out[i] = r;
+}
+
+// A22: od_compute_dist (src/encode.c:940-1058, HVS-QM branch) for nblk pairs of
+// n x n blocks (n = 8, 16, 32).  One thread per pair; the 8x8 sub-block sums are
+// accumulated sequentially in raster order like the reference.  mag2: the 64
+// squared weights for this block size (reference tables, passed in as data).
+// pow(., -1/6) comes from OCML: the value is within a few ulp of the reference's
+// (DESIGN.md section 5); everything else is exact.
+__device__ inline int dist_var_4x4(const int32_t *x, int stride) {
+  int sum = 0, s2 = 0;
+  for (int i = 0; i < 4; i++) {
+    for (int j = 0; j < 4; j++) {
+      const int t = x[i*stride + j] >> 2;
+      sum += t;
+      s2 += t*t;
+    }
+  }
+  return s2 - (sum*sum >> 4);
+}
+
+__global__ void k_compute_dist_blocks(int n, int nblk, const int32_t *__restrict__ xa,
+                                      const int32_t *__restrict__ ya,
+                                      const double *__restrict__ mag2, int masking,
+                                      double *__restrict__ out) {
+  const long b = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const int32_t *x = xa + b*n*n, *y = ya + b*n*n;
+  double total = 0;
+  for (int bi = 0; bi < n; bi += 8) {
+    for (int bj = 0; bj < n; bj += 8) {
+      const int32_t *xs = x + bi*n + bj, *ys = y + bi*n + bj;
+      double mean_var = 0, vardist = 0;
+      int min_var = 2147483647;
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+          const int varx = dist_var_4x4(xs + 2*i*n + 2*j, n);
+          const int vary = dist_var_4x4(ys + 2*i*n + 2*j, n);
+          min_var = varx < min_var ? varx : min_var;
+          mean_var += 1./(1 + varx);
+          const double diff = sqrt((double)varx) - sqrt((double)vary);
+          vardist += diff*diff;
+        }
+      }
+      double calibration, var_stat;
+      if (masking) { calibration = 1.95; var_stat = 9./mean_var; }
+      else { calibration = 1.62; var_stat = min_var; }
+      const double activity = calibration*pow(.25 + var_stat/(1 << 2*4), -1./6);
+      // 8x8 fDCT of the error: columns into rows of z, then columns of z into rows
+      int32_t z[64], et[64];
+      for (int c = 0; c < 8; c++) {
+        int32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = xs[k*n + c] - ys[k*n + c];
+        LiftDct<8, false>::fwd(v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) z[c*8 + k] = v[k];
+      }
+      for (int c = 0; c < 8; c++) {
+        int32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = z[k*8 + c];
+        LiftDct<8, false>::fwd(v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) et[c*8 + k] = v[k];
+      }
+      double sum = 0;
+      for (int i = 0; i < 64; i++) sum += et[i]*(double)et[i]*mag2[i];
+      total += activity*activity*(sum + vardist);
+    }
+  }
+  out[b] = total*1.7;
 }

@@ -233,6 +233,14 @@ int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h,
  const unsigned char *bsize, int bstride, int bs, int nblk, const int32_t *bx,
  const int32_t *by, od_coeff *pred);
 
+/* od_compute_dist (src/encode.c:1032-1058, HVS quantisation matrix) for nblk pairs
+ * of dense n x n blocks (n = 4 << bs, bs = 1..3): the perceptual distortion the
+ * block-size RDO compares (src/encode.c:1631-1632).  mag2[64]: squared weights
+ * (16/OD_QM8_Q4_HVS[i][j] * OD_BASIS_MAG[0][bs][i<<(bs-1)] * ...[j<<(bs-1)])^2,
+ * src/encode.c:1018-1025, computed by the host from its tables. */
+int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coeff *y,
+ const double *mag2, int activity_masking, double *dist);
+
 /* Diagnostic: the device's pow/acos/sin/cos/sqrt/divide on n doubles, so tests can
  * quantify agreement with the host libm the reference uses.
  * fn: 0 pow(x,y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y. */

@@ -908,3 +908,60 @@ void orc_pvq_synthesis(coeff *xcoeff, const coeff *ypulse, const coeff *ref, int
   m = noref ? 0 : orc_compute_householder(r, n, gr, &s);
   orc_pvq_synthesis_partial(xcoeff, ypulse, r, n, noref, g, theta, m, s, qm_inv);
 }
+
+/* ------------------------------------------------------------------------ */
+/* A22: perceptual block distortion of the block-size RDO (reference
+   od_compute_var_4x4 / od_compute_dist_8x8 / od_compute_dist,
+   src/encode.c:940-1058; HVS quantisation matrix case).  mag2[64]: the squared
+   per-coefficient weights the reference derives from OD_QM8_Q4_HVS and
+   OD_BASIS_MAG for this block size (data, passed in). */
+static int var_4x4(const coeff *x, int stride) {
+  int sum = 0, s2 = 0, i, j;
+  for (i = 0; i < 4; i++)
+    for (j = 0; j < 4; j++) {
+      int t = x[i*stride + j] >> 2;
+      sum += t;
+      s2 += t*t;
+    }
+  return s2 - (sum*sum >> 4);
+}
+
+static double dist_8x8(const coeff *x, const coeff *y, int stride, const double *mag2,
+ int masking) {
+  coeff e[64], et[64];
+  double sum = 0, mean_var = 0, vardist = 0, var_stat, activity, calibration;
+  int min_var = 2147483647, i, j;
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 3; j++) {
+      int varx = var_4x4(x + 2*i*stride + 2*j, stride);
+      int vary = var_4x4(y + 2*i*stride + 2*j, stride);
+      double diff;
+      if (varx < min_var) min_var = varx;
+      mean_var += 1./(1 + varx);
+      diff = sqrt(varx) - sqrt(vary);
+      vardist += diff*diff;
+    }
+  if (masking) {
+    calibration = 1.95;
+    var_stat = 9./mean_var;
+  }
+  else {
+    calibration = 1.62;
+    var_stat = min_var;
+  }
+  activity = calibration*pow(.25 + var_stat/(1 << 2*4), -1./6);
+  for (i = 0; i < 8; i++)
+    for (j = 0; j < 8; j++) e[8*i + j] = x[i*stride + j] - y[i*stride + j];
+  orc_fdct_2d(8, et, 8, e, 8);
+  for (i = 0; i < 64; i++) sum += et[i]*(double)et[i]*mag2[i];
+  return activity*activity*(sum + vardist);
+}
+
+double orc_compute_dist(const coeff *x, const coeff *y, int n, const double *mag2,
+ int masking) {
+  double sum = 0;
+  int i, j;
+  for (i = 0; i < n; i += 8)
+    for (j = 0; j < n; j += 8) sum += dist_8x8(x + i*n + j, y + i*n + j, n, mag2, masking);
+  return sum*1.7;
+}

@@ -231,3 +231,31 @@ int probe_encoder_params(int quant, int masking, int *quantizer,
   daala_encode_free(enc);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* od_compute_dist (static, src/encode.c:1032-1058) on caller data, plus the
+   per-coefficient weight table it builds from OD_QM8_Q4_HVS and OD_BASIS_MAG
+   (src/encode.c:1018-1027) so that fixtures can carry it as data. */
+double probe_compute_dist(int masking, const od_coeff *x, const od_coeff *y, int n,
+ int bs) {
+  daala_enc_ctx *enc;
+  double d;
+  enc = make_encoder(64, 64, 20, 7, masking, 1);
+  if (enc == NULL) return -1;
+  d = od_compute_dist(enc, (od_coeff *)x, (od_coeff *)y, n, bs);
+  daala_encode_free(enc);
+  return d;
+}
+
+void probe_dist_weights(int bs, double *mag2) {
+  int i, j;
+  for (i = 0; i < 8; i++) {
+    for (j = 0; j < 8; j++) {
+      double mag;
+      mag = 16./OD_QM8_Q4_HVS[i*8 + j];
+      mag *= OD_BASIS_MAG[0][bs][i << (bs - 1)]*OD_BASIS_MAG[0][bs][j << (bs - 1)];
+      mag *= mag;
+      mag2[i*8 + j] = mag;
+    }
+  }
+}

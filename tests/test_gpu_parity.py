@@ -514,3 +514,16 @@ def test_hv_intra_pred_blocks(hip):
             e = np.zeros(n*n, np.int32)
             o.orc_hv_intra_pred(p32(e), p32(d), w, int(bx[i]), int(by[i]), pu8(bsz), w//8, bs)
             assert np.array_equal(pred[i], e)
+
+
+def test_compute_dist_blocks(hip):
+    """od_compute_dist on the device vs the reference values in the golden fixture.
+    Everything is exact except pow(., -1/6) (OCML vs glibc, <= 1 ulp each), which
+    enters squared: relative tolerance 8 ulp."""
+    g = golden('compute_dist.npz')
+    for bs in (1, 2, 3):
+        for m in (0, 1):
+            d = hip.od_compute_dist_blocks(bs, g['x_%d' % bs], g['y_%d' % bs], g['mag2_%d' % bs], m)
+            e = g['dist_%d_m%d' % (bs, m)]
+            assert np.all(np.abs(d - e) <= 8*np.spacing(np.abs(e)))
+            assert np.mean(d == e) > 0.3

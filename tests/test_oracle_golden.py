@@ -159,3 +159,16 @@ def test_pvq_theta_noref_golden_candidates_contain_decision():
         assert np.array_equal(out, g['out'][i][:n])
         hits += 1
     assert hits > 50
+
+
+def test_compute_dist_golden():
+    o = oracle()
+    o.orc_compute_dist.restype = ctypes.c_double
+    g = load('compute_dist.npz')
+    for bs in (1, 2, 3):
+        n = 4 << bs
+        for m in (0, 1):
+            for x, y, d in zip(g['x_%d' % bs], g['y_%d' % bs], g['dist_%d_m%d' % (bs, m)]):
+                got = o.orc_compute_dist(p32(np.ascontiguousarray(x)), p32(np.ascontiguousarray(y)), n,
+                                         pf64(np.ascontiguousarray(g['mag2_%d' % bs])), m)
+                assert got == d
