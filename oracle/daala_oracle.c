@@ -965,3 +965,251 @@ double orc_compute_dist(const coeff *x, const coeff *y, int n, const double *mag
     for (j = 0; j < n; j += 8) sum += dist_8x8(x + i*n + j, y + i*n + j, n, mag2, masking);
   return sum*1.7;
 }
+
+/* ======================================================================== */
+/* directional deringing, its threshold logic, and the
+   keyframe bilinear smoothing - the pixel-domain stages between the frame
+   post-filter and the 8-bit clamp (reference src/decode.c:1040-1155).         */
+
+#define DER_BSTRIDE 38                 /* OD_FILT_BSTRIDE = 32 + 2*OD_FILT_BORDER */
+#define DER_VERY_LARGE 30000           /* OD_DERING_VERY_LARGE, src/filter.c:1711 */
+
+/* (dy, dx) of the three taps of each direction: direction_offsets_table,
+   reference src/filter.c:132-141 (generated there as flat offsets). */
+static const int8_t DER_DIR[8][3][2] = {
+  {{-1, 1}, {-2, 2}, {-3, 3}}, {{0, 1}, {-1, 2}, {-1, 3}}, {{0, 1}, {0, 2}, {0, 3}},
+  {{0, 1}, {1, 2}, {1, 3}}, {{1, 1}, {2, 2}, {3, 3}}, {{1, 0}, {2, 1}, {3, 1}},
+  {{1, 0}, {2, 0}, {3, 0}}, {{1, 0}, {2, -1}, {3, -1}}};
+
+/* od_dir_find8 (src/filter.c:1655-1708).  OD_DIVU_SMALL(x, d) is an exact
+   unsigned division for the small divisors used here (src/internal.h:227). */
+int orc_dir_find8(const int16_t *img, int stride, int32_t *var) {
+  int cost[8] = {0}, partial[8][15], best_cost = 0, best_dir = 0, i, j;
+  memset(partial, 0, sizeof(partial));
+  for (i = 0; i < 8; i++)
+    for (j = 0; j < 8; j++) {
+      int x = img[i*stride + j] >> 4;
+      partial[0][i + j] += x;
+      partial[1][i + j/2] += x;
+      partial[2][i] += x;
+      partial[3][3 + i - j/2] += x;
+      partial[4][7 + i - j] += x;
+      partial[5][3 - i/2 + j] += x;
+      partial[6][j] += x;
+      partial[7][i/2 + j] += x;
+    }
+  for (i = 0; i < 8; i++) {
+    cost[2] += partial[2][i]*partial[2][i] >> 3;
+    cost[6] += partial[6][i]*partial[6][i] >> 3;
+  }
+  for (i = 0; i < 7; i++) {
+    cost[0] += (int)((uint32_t)(partial[0][i]*partial[0][i])/(uint32_t)(i + 1))
+     + (int)((uint32_t)(partial[0][14 - i]*partial[0][14 - i])/(uint32_t)(i + 1));
+    cost[4] += (int)((uint32_t)(partial[4][i]*partial[4][i])/(uint32_t)(i + 1))
+     + (int)((uint32_t)(partial[4][14 - i]*partial[4][14 - i])/(uint32_t)(i + 1));
+  }
+  cost[0] += partial[0][7]*partial[0][7] >> 3;
+  cost[4] += partial[4][7]*partial[4][7] >> 3;
+  for (i = 1; i < 8; i += 2) {
+    for (j = 0; j < 5; j++) cost[i] += partial[i][3 + j]*partial[i][3 + j] >> 3;
+    for (j = 0; j < 3; j++) {
+      cost[i] += (int)((uint32_t)(partial[i][j]*partial[i][j])/(uint32_t)(2*j + 2))
+       + (int)((uint32_t)(partial[i][10 - j]*partial[i][10 - j])/(uint32_t)(2*j + 2));
+    }
+  }
+  for (i = 0; i < 8; i++) {
+    if (cost[i] > best_cost) {
+      best_cost = cost[i];
+      best_dir = i;
+    }
+  }
+  *var = best_cost - cost[(best_dir + 4) & 7];
+  return best_dir;
+}
+
+/* od_filter_dering_direction_c / _orthogonal_c (src/filter.c:1714-1793); `in`
+   points into a DER_BSTRIDE-strided buffer with a 3-sample border. */
+void orc_dering_direction(int16_t *y, int ystride, const int16_t *in, int ln,
+ int threshold, int dir) {
+  static const int taps[3] = {3, 2, 2};
+  int i, j, k, n = 1 << ln;
+  for (i = 0; i < n; i++)
+    for (j = 0; j < n; j++) {
+      int xx = in[i*DER_BSTRIDE + j], sum = 0;
+      for (k = 0; k < 3; k++) {
+        int off = DER_DIR[dir][k][0]*DER_BSTRIDE + DER_DIR[dir][k][1];
+        int p0 = in[i*DER_BSTRIDE + j + off] - xx;
+        int p1 = in[i*DER_BSTRIDE + j - off] - xx;
+        if (abs(p0) < threshold) sum += taps[k]*p0;
+        if (abs(p1) < threshold) sum += taps[k]*p1;
+      }
+      y[i*ystride + j] = (int16_t)(xx + ((sum + 8) >> 4));
+    }
+}
+
+void orc_dering_orthogonal(int16_t *y, int ystride, const int16_t *in,
+ const int16_t *x, int xstride, int ln, int threshold, int dir) {
+  int i, j, n = 1 << ln, offset = dir <= 4 ? DER_BSTRIDE : 1;
+  for (i = 0; i < n; i++)
+    for (j = 0; j < n; j++) {
+      int yy = in[i*DER_BSTRIDE + j], sum = 0, p, athresh;
+      athresh = threshold/3 + abs(in[i*DER_BSTRIDE + j] - x[i*xstride + j]);
+      if (threshold < athresh) athresh = threshold;
+      p = in[i*DER_BSTRIDE + j + offset] - yy;
+      if (abs(p) < athresh) sum += p;
+      p = in[i*DER_BSTRIDE + j - offset] - yy;
+      if (abs(p) < athresh) sum += p;
+      p = in[i*DER_BSTRIDE + j + 2*offset] - yy;
+      if (abs(p) < athresh) sum += p;
+      p = in[i*DER_BSTRIDE + j - 2*offset] - yy;
+      if (abs(p) < athresh) sum += p;
+      y[i*ystride + j] = (int16_t)(yy + ((3*sum + 8) >> 4));
+    }
+}
+
+static int orc_ilog(uint32_t v) {
+  int r = 0;
+  while (v) { r++; v >>= 1; }
+  return r;
+}
+
+/* od_dering (src/filter.c:1835-1940) for one dering superblock of one plane.
+   threshold: (int)pow(q, 0.84182) computed by the caller (:1878).  dir: written
+   for luma, read for chroma.  bskip points at the superblock's first 4x4 unit. */
+void orc_dering_sb(int16_t *y, int ystride, const int16_t *x, int xstride, int ln,
+ int sbx, int sby, int nhsb, int nvsb, int threshold, int xdec, int dir[4][4],
+ int pli, const unsigned char *bskip, int skip_stride) {
+  static const int16_t thresh_q8[18] = {128, 134, 150, 168, 188, 210, 234, 262, 292,
+    327, 365, 408, 455, 509, 569, 635, 710, 768};
+  int16_t inbuf[DER_BSTRIDE*DER_BSTRIDE], *in = inbuf + 3*DER_BSTRIDE + 3;
+  int n = 1 << ln, bsize = 3 - xdec, nb = n >> bsize, i, j, bx, by, varsum = 0;
+  int32_t var[4][4];
+  int thresh[4][4];
+  for (i = 0; i < DER_BSTRIDE*DER_BSTRIDE; i++) inbuf[i] = DER_VERY_LARGE;
+  for (i = -3*(sby != 0); i < n + 3*(sby != nvsb - 1); i++)
+    for (j = -3*(sbx != 0); j < n + 3*(sbx != nhsb - 1); j++)
+      in[i*DER_BSTRIDE + j] = x[i*xstride + j];
+  if (pli == 0) {
+    for (by = 0; by < nb; by++)
+      for (bx = 0; bx < nb; bx++) {
+        dir[by][bx] = orc_dir_find8(x + 8*by*xstride + 8*bx, xstride, &var[by][bx]);
+        varsum += var[by][bx];
+      }
+    for (by = 0; by < nb; by++)
+      for (bx = 0; bx < nb; bx++) {
+        int v1 = var[by][bx] >> 6, v2 = varsum/1024, t;
+        if (v1 > 32767) v1 = 32767;
+        if (v2 > 32767) v2 = 32767;
+        t = orc_ilog((uint32_t)(v1*v2)) - 9;
+        t = t < 0 ? 0 : t > 17 ? 17 : t;
+        thresh[by][bx] = threshold*thresh_q8[t] >> 8;
+      }
+  }
+  else {
+    for (by = 0; by < nb; by++) for (bx = 0; bx < nb; bx++) thresh[by][bx] = threshold;
+  }
+  for (by = 0; by < nb; by++)
+    for (bx = 0; bx < nb; bx++) {
+      int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
+      int xend = (2 >> xdec) + (sbx != nhsb - 1), yend = (2 >> xdec) + (sby != nvsb - 1);
+      int skip = 1;
+      for (i = ystart; i < yend; i++)
+        for (j = xstart; j < xend; j++)
+          skip = skip && bskip[((by << 1 >> xdec) + i)*skip_stride + (bx << 1 >> xdec) + j];
+      if (skip) thresh[by][bx] = 0;
+    }
+  for (by = 0; by < nb; by++)
+    for (bx = 0; bx < nb; bx++)
+      orc_dering_direction(y + (by*ystride << bsize) + (bx << bsize), ystride,
+       in + (by*DER_BSTRIDE << bsize) + (bx << bsize), bsize, thresh[by][bx], dir[by][bx]);
+  for (i = 0; i < n; i++) for (j = 0; j < n; j++) in[i*DER_BSTRIDE + j] = y[i*ystride + j];
+  for (by = 0; by < nb; by++)
+    for (bx = 0; bx < nb; bx++)
+      orc_dering_orthogonal(y + (by*ystride << bsize) + (bx << bsize), ystride,
+       in + (by*DER_BSTRIDE << bsize) + (bx << bsize),
+       x + (by*xstride << bsize) + (bx << bsize), xstride, bsize, thresh[by][bx],
+       dir[by][bx]);
+}
+
+/* od_bilinear_smooth (src/filter.c:1952-2008). */
+void orc_bilinear_smooth(coeff *x, int ln, int stride, int q, int pli) {
+  static const int strength[4] = {5, 20, 20, 5};
+  coeff yb[32][32];
+  int n = 1 << ln, i, j, shift, w;
+  int32_t dist = 0;
+  coeff x00 = x[0], x01 = x[n - 1], x10 = x[(n - 1)*stride];
+  coeff x11 = x[(n - 1)*stride + (n - 1)];
+  coeff a00 = x00, a01 = x01 - x00, a10 = x10 - x00, a11 = x11 + x00 - x10 - x01;
+  a01 += (a01 + n/2) >> ln;
+  a10 += (a10 + n/2) >> ln;
+  a11 += (2*a10 + n/2) >> ln;
+  shift = 2*4 + 2*ln - 16;
+  if (shift < 0) shift = 0;
+  for (i = 0; i < n; i++) {
+    int32_t partial = 0;
+    for (j = 0; j < n; j++) {
+      yb[i][j] = a00 + ((j*a01 + i*a10 + (j*i*a11 >> ln) + n/2) >> ln);
+      partial += (yb[i][j] - x[i*stride + j])*(yb[i][j] - x[i*stride + j]);
+    }
+    dist += partial >> shift;
+  }
+  dist += n/2;
+  dist >>= 2*ln - shift;
+  w = strength[pli]*q*q/(1 + 12*dist);
+  if (w > 1024) w = 1024;
+  w = w*w >> 12;
+  for (i = 0; i < n; i++)
+    for (j = 0; j < n; j++)
+      x[i*stride + j] -= (w*(x[i*stride + j] - yb[i][j]) + 128) >> 8;
+}
+
+/* The decoder's pixel-domain tail for one frame (src/decode.c:1040-1155):
+   c[pli]: planes after the frame post-filter (int32, modified in place),
+   flags: one byte per 32x32 dering superblock (1 = filtered), bskip[pli]: skip
+   maps (1 byte per 4x4 of that plane, stride skip_stride), bsize: luma
+   block-size map (stride bstride), thr[pli] = (int)pow(quantizer[pli], 0.84182),
+   q[pli] = quantizer.  Writes the 8-bit planes. */
+void orc_decode_tail(coeff *const c[3], uint8_t *const rec[3], int nplanes, int fw,
+ int fh, const int *xdec, const unsigned char *flags, const unsigned char *const bskip[3],
+ int skip_stride, const unsigned char *bsize, int bstride, const int *thr,
+ const int *q, int is_keyframe) {
+  int nhdr = fw >> 5, nvdr = fh >> 5, pli, sbx, sby, i;
+  int16_t *e[3];
+  if (q[0] > 0) {
+    for (pli = 0; pli < nplanes; pli++) {
+      int sz = (fw >> xdec[pli])*(fh >> xdec[pli]);
+      e[pli] = (int16_t *)malloc(sizeof(int16_t)*sz);
+      for (i = 0; i < sz; i++) e[pli][i] = (int16_t)c[pli][i];
+    }
+    for (sby = 0; sby < nvdr; sby++)
+      for (sbx = 0; sbx < nhdr; sbx++) {
+        int dir[4][4];
+        if (!flags[sby*nhdr + sbx]) continue;
+        for (pli = 0; pli < nplanes; pli++) {
+          int d = xdec[pli], w = fw >> d, ln = 5 - d, n = 1 << ln, y, x;
+          int16_t buf[32*32];
+          orc_dering_sb(buf, n, e[pli] + (sby << ln)*w + (sbx << ln), w, ln, sbx, sby,
+           nhdr, nvdr, thr[pli], d, dir, pli,
+           bskip[pli] + (sby << (3 - d))*skip_stride + (sbx << (3 - d)), skip_stride);
+          for (y = 0; y < n; y++)
+            for (x = 0; x < n; x++) c[pli][((sby << ln) + y)*w + (sbx << ln) + x] = buf[y*n + x];
+        }
+      }
+    for (pli = 0; pli < nplanes; pli++) free(e[pli]);
+  }
+  for (pli = 0; pli < nplanes; pli++) {
+    int d = xdec[pli], w = fw >> d, h = fh >> d;
+    if (q[0] > 0 && is_keyframe) {
+      for (sby = 0; sby < nvdr; sby++)
+        for (sbx = 0; sbx < nhdr; sbx++) {
+          /* od_smooth_recursive with min_bs = OD_BLOCK_32X32: only whole-superblock
+             leaves are smoothed (src/filter.c:2010-2040) */
+          if (bsize[(sby*4)*bstride + sbx*4] == 3) {
+            int ln = 5 - d;
+            orc_bilinear_smooth(c[pli] + (sby << ln)*w + (sbx << ln), ln, w, q[pli], pli);
+          }
+        }
+    }
+    orc_coeff_to_ref_buf(rec[pli], w, c[pli], w, w, h, 4);
+  }
+}

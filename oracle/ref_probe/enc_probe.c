@@ -259,3 +259,17 @@ void probe_dist_weights(int bs, double *mag2) {
     }
   }
 }
+
+/* od_dering (src/filter.c:1835) needs an od_state for its vtable: borrow one
+   from a throw-away encoder context.  threshold is derived from q inside. */
+int probe_dering(int16_t *y, int ystride, int16_t *x, int xstride, int ln, int sbx,
+ int sby, int nhsb, int nvsb, int q, int xdec, int *dir, int pli,
+ unsigned char *bskip, int skip_stride) {
+  daala_enc_ctx *enc;
+  enc = make_encoder(64, 64, 20, 7, 1, 1);
+  if (enc == NULL) return -1;
+  od_dering(&enc->state, y, ystride, x, xstride, ln, sbx, sby, nhsb, nvsb, q, xdec,
+   (int (*)[OD_DERING_NBLOCKS])dir, pli, bskip, skip_stride);
+  daala_encode_free(enc);
+  return 0;
+}
