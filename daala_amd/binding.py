@@ -293,6 +293,23 @@ class DaalaHip(object):
                                           bands.ctypes.data_as(ctypes.c_void_p), _p32(y)))
         return bands, y
 
+    def set_decode_info(self, slot, dering_flags, bskip):
+        """dering_flags: [nvsb, nhsb] u8; bskip: per plane [fh/4, fw/4] u8 (dense)."""
+        fl = np.ascontiguousarray(dering_flags, dtype=np.uint8)
+        bs = [np.ascontiguousarray(b, dtype=np.uint8) for b in bskip]
+        ptrs = (U8P*len(bs))(*[b.ctypes.data_as(U8P) for b in bs])
+        self.lib.od_hip_set_decode_info.argtypes = [ctypes.c_void_p, c_int, U8P,
+                                                    ctypes.POINTER(U8P), c_int]
+        _chk(self.lib.od_hip_set_decode_info(self.ctx, slot, fl.ctypes.data_as(U8P), ptrs,
+                                             bs[0].shape[1]))
+
+    def decode_tail(self, threshold, quantizer, is_keyframe, slot0=0, nslots=None):
+        th = np.ascontiguousarray(threshold, dtype=np.int32)
+        q = np.ascontiguousarray(quantizer, dtype=np.int32)
+        self.lib.od_hip_decode_tail.argtypes = [ctypes.c_void_p, c_int, c_int, I32P, I32P, c_int]
+        _chk(self.lib.od_hip_decode_tail(self.ctx, slot0, nslots or self.nslots - slot0, _p32(th),
+                                         _p32(q), int(is_keyframe)))
+
     def sync(self):
         _chk(self.lib.od_hip_sync(self.ctx))
 

@@ -16,6 +16,7 @@
 #include "pvq_theta_kernels.hpp"
 #include "xform_kernels.hpp"
 #include "xform_rt_kernels.hpp"
+#include "tail_kernels.hpp"
 
 static_assert(sizeof(PvqBandRec) == sizeof(od_hip_pvq_band), "record layout");
 static_assert(sizeof(od_hip_pvq_band) == 72, "record layout");
@@ -136,6 +137,9 @@ struct od_hip_ctx {
   int32_t *c[OD_HIP_NPLANES_MAX];            // [slot][h][w]
   uint8_t *rec[OD_HIP_NPLANES_MAX];          // [slot][h][w]
   uint8_t *bsize;                            // [slot][nvsb*4][nhsb*4]
+  int32_t *p32[OD_HIP_NPLANES_MAX];          // [slot][h][w] post-filtered planes (decoder tail)
+  uint8_t *dflags;                           // [slot][nvsb*nhsb] dering flags
+  uint8_t *bskip[OD_HIP_NPLANES_MAX];        // [slot][(fh/4)*(fw/4)]
   size_t bsize_sz;
   uint16_t *tab[OD_HIP_NBSIZES];             // coding tables on device
   int16_t *qm_dev;                           // scratch QM (1024 int16)
@@ -349,6 +353,9 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   memset(ctx->d, 0, sizeof(ctx->d));
   memset(ctx->c, 0, sizeof(ctx->c));
   memset(ctx->rec, 0, sizeof(ctx->rec));
+  memset(ctx->p32, 0, sizeof(ctx->p32));
+  memset(ctx->bskip, 0, sizeof(ctx->bskip));
+  ctx->dflags = nullptr;
   memset(ctx->pvq, 0, sizeof(ctx->pvq));
   memset(ctx->pvq_alloc, 0, sizeof(ctx->pvq_alloc));
   memset(ctx->tab, 0, sizeof(ctx->tab));
@@ -406,6 +413,8 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
     if (ctx->d[p]) (void)hipFree(ctx->d[p]);
     if (ctx->c[p]) (void)hipFree(ctx->c[p]);
     if (ctx->rec[p]) (void)hipFree(ctx->rec[p]);
+    if (ctx->p32[p]) (void)hipFree(ctx->p32[p]);
+    if (ctx->bskip[p]) (void)hipFree(ctx->bskip[p]);
     for (int l = 0; l < 4; l++) {
       PvqSoA &o = ctx->pvq[p][l];
       void *ptrs[] = {o.cg, o.g, o.cos_dist, o.dist, o.qg, o.k, o.ncand, o.y};
@@ -414,6 +423,7 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
   }
   for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
   if (ctx->bsize) (void)hipFree(ctx->bsize);
+  if (ctx->dflags) (void)hipFree(ctx->dflags);
   if (ctx->qm_dev) (void)hipFree(ctx->qm_dev);
   if (ctx->rsq) (void)hipFree(ctx->rsq);
   for (auto &kv : ctx->spans) for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -571,6 +581,7 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
     PostArgs q;
     q.c = a.c; q.c_fstride = ctx->psz[p];
     q.rec = ctx->rec[p] + (size_t)slot0*ctx->psz[p]; q.rec_fstride = ctx->psz[p];
+    q.out32 = nullptr;
     q.w = a.w; q.h = a.h; q.nhsb = a.nhsb; q.nvsb = a.nvsb;
     dim3 grid(ctx->nhsb, ctx->nvsb, nslots), grid2(ctx->nhsb + 1, ctx->nvsb + 1, nslots);
     if (a.dec == 0) {
@@ -945,6 +956,105 @@ int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coe
                      activity_masking, (double *)g_out.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(dist, g_out.p, (size_t)nblk*8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+namespace {
+int ensure_tail_buffers(od_hip_ctx *ctx) {
+  if (ctx->dflags) return 0;
+  size_t ns = ctx->geo.nslots;
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    HIPCHK(hipMalloc((void **)&ctx->p32[p], ns*ctx->psz[p]*4));
+    HIPCHK(hipMalloc((void **)&ctx->bskip[p], ns*(size_t)(ctx->geo.frame_width/4)*(ctx->geo.frame_height/4)));
+    HIPCHK(hipMemset(ctx->bskip[p], 0, ns*(size_t)(ctx->geo.frame_width/4)*(ctx->geo.frame_height/4)));
+  }
+  HIPCHK(hipMalloc((void **)&ctx->dflags, ns*ctx->nhsb*ctx->nvsb));
+  HIPCHK(hipMemset(ctx->dflags, 0, ns*ctx->nhsb*ctx->nvsb));
+  return 0;
+}
+}  // namespace
+
+int od_hip_set_decode_info(od_hip_ctx *ctx, int slot, const unsigned char *dering_flags,
+                           const unsigned char *const bskip[], int skip_stride) {
+  if (int rc = check_slots(ctx, slot, 1)) return rc;
+  if (!dering_flags || !bskip) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = ensure_tail_buffers(ctx)) return rc;
+  int fw4 = ctx->geo.frame_width/4, fh4 = ctx->geo.frame_height/4;
+  size_t nsb = (size_t)ctx->nhsb*ctx->nvsb;
+  HIPCHK(hipMemcpyAsync(ctx->dflags + slot*nsb, dering_flags, nsb, hipMemcpyHostToDevice, ctx->stream));
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    if (!bskip[p] || skip_stride < (fw4 >> ctx->geo.xdec[p])) return fail(OD_HIP_EINVAL, "bad skip map");
+    int pw4 = fw4 >> ctx->geo.xdec[p], ph4 = fh4 >> ctx->geo.xdec[p];
+    HIPCHK(hipMemcpy2DAsync(ctx->bskip[p] + (size_t)slot*fw4*fh4, fw4, bskip[p], skip_stride, pw4, ph4,
+                            hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int od_hip_decode_tail(od_hip_ctx *ctx, int slot0, int nslots, const int32_t *threshold,
+                       const int32_t *quantizer, int is_keyframe) {
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  if (!threshold || !quantizer) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = ensure_tail_buffers(ctx)) return rc;
+  // 1. iDCT + split post-filters (k_inverse_rt) -> c; 2. frame post-filter -> p32
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    InvArgs a;
+    a.d = ctx->d[p] + (size_t)slot0*ctx->psz[p];
+    a.c = ctx->c[p] + (size_t)slot0*ctx->psz[p];
+    a.fstride = ctx->psz[p];
+    a.bsize = ctx->bsize + (size_t)slot0*ctx->bsize_sz;
+    a.bsize_fstride = ctx->bsize_sz;
+    a.bstride = ctx->nhsb*4;
+    a.w = ctx->pw[p]; a.h = ctx->ph[p]; a.nhsb = ctx->nhsb; a.nvsb = ctx->nvsb;
+    a.pic_w = ctx->geo.pic_width; a.pic_h = ctx->geo.pic_height;
+    a.dec = ctx->geo.xdec[p];
+    PostArgs q;
+    q.c = a.c; q.c_fstride = ctx->psz[p];
+    q.rec = nullptr; q.rec_fstride = ctx->psz[p];
+    q.out32 = ctx->p32[p] + (size_t)slot0*ctx->psz[p];
+    q.w = a.w; q.h = a.h; q.nhsb = a.nhsb; q.nvsb = a.nvsb;
+    dim3 grid2(ctx->nhsb + 1, ctx->nvsb + 1, nslots);
+    if (a.dec == 0) {
+      { Timed tm(ctx, "k_inverse_sb_luma");
+        hipLaunchKernelGGL((k_inverse_rt<32, 4>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots), dim3(64), 0, ctx->stream, a); }
+      { Timed tm(ctx, "k_postfilter_i32_luma");
+        hipLaunchKernelGGL((k_postfilter_clamp<32, false>), grid2, dim3(256), 0, ctx->stream, q); }
+    }
+    else {
+      { Timed tm(ctx, "k_inverse_sb_chroma");
+        hipLaunchKernelGGL((k_inverse_rt<16, 3>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots), dim3(64), 0, ctx->stream, a); }
+      { Timed tm(ctx, "k_postfilter_i32_chroma");
+        hipLaunchKernelGGL((k_postfilter_clamp<16, false>), grid2, dim3(64), 0, ctx->stream, q); }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  // 3. dering + smoothing + clamp
+  TailArgs t;
+  size_t fw4 = ctx->geo.frame_width/4, fh4 = ctx->geo.frame_height/4;
+  for (int p = 0; p < 3; p++) {
+    bool on = p < ctx->geo.nplanes;
+    t.p[p] = on ? ctx->p32[p] + (size_t)slot0*ctx->psz[p] : nullptr;
+    t.rec[p] = on ? ctx->rec[p] + (size_t)slot0*ctx->psz[p] : nullptr;
+    t.fstride[p] = on ? ctx->psz[p] : 0;
+    t.bskip[p] = on ? ctx->bskip[p] + (size_t)slot0*fw4*fh4 : nullptr;
+    t.xdec[p] = on ? ctx->geo.xdec[p] : 0;
+    t.thr[p] = on ? threshold[p] : 0;
+    t.q[p] = on ? quantizer[p] : 0;
+  }
+  t.flags = ctx->dflags + (size_t)slot0*ctx->nhsb*ctx->nvsb;
+  t.bskip_fstride = fw4*fh4;
+  t.bsize = ctx->bsize + (size_t)slot0*ctx->bsize_sz;
+  t.bsize_fstride = ctx->bsize_sz;
+  t.bstride = ctx->nhsb*4;
+  t.fw = ctx->geo.frame_width; t.fh = ctx->geo.frame_height;
+  t.nhsb = ctx->nhsb; t.nvsb = ctx->nvsb; t.nplanes = ctx->geo.nplanes;
+  t.is_keyframe = is_keyframe;
+  {
+    Timed tm(ctx, "k_decode_tail");
+    hipLaunchKernelGGL(k_decode_tail, dim3(ctx->nhsb, ctx->nvsb, nslots), dim3(256), 0, ctx->stream, t);
+  }
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

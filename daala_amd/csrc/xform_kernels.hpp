@@ -415,6 +415,7 @@ struct PostArgs {
   size_t c_fstride;
   uint8_t *rec;
   size_t rec_fstride;
+  int32_t *out32;            // CLAMP == false: post-filtered plane (same strides as c)
   int w, h, nhsb, nvsb;
 };
 
@@ -423,7 +424,7 @@ struct PostArgs {
 // (bx*SB, by*SB), i.e. [bx*SB - SB/2, +SB): every SB boundary tap it needs lies
 // inside that region, so no halo and no inter-workgroup dependency.  Vertical
 // boundaries (row taps) first, then horizontal boundaries (column taps).
-template <int SB>
+template <int SB, bool CLAMP = true>
 __global__ __launch_bounds__(SB*SB/4) void k_postfilter_clamp(PostArgs a) {
   using T = SbTile<SB>;
   __shared__ int32_t X[SB*T::LD];
@@ -459,7 +460,13 @@ __global__ __launch_bounds__(SB*SB/4) void k_postfilter_clamp(PostArgs a) {
     }
   }
   __syncthreads();
-  if (inside) {
+  if (inside && !CLAMP) {
+    // decoder flow: deringing / smoothing still follow (tail_kernels.hpp)
+    int32_t *o = a.out32 + (size_t)f*a.c_fstride + (size_t)gy*a.w + gx;
+    *reinterpret_cast<int4 *>(o) = make_int4(X[r*T::LD + c4], X[r*T::LD + c4 + 1],
+                                             X[r*T::LD + c4 + 2], X[r*T::LD + c4 + 3]);
+  }
+  if (inside && CLAMP) {
     uint32_t pk = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {

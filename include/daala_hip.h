@@ -142,6 +142,21 @@ int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe);
  * output: 8-bit reconstruction planes in HBM. */
 int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots);
 
+/* Decoder reconstruction, the whole pixel-domain stage of od_decode_coefficients
+ * after the symbol parse (src/decode.c:1010-1155): iDCT + split post-filters +
+ * frame post-filter, then per 32x32 deringing superblock od_dering
+ * (src/filter.c:1835) where the decoded flag says so, od_bilinear_smooth
+ * (src/filter.c:1952) on keyframe 32x32 blocks, and the 8-bit clamp.
+ * od_hip_set_decode_info uploads what the parse produced for the slot:
+ * dering_flags (1 byte per superblock, raster, state.dering_flags) and the
+ * skip maps state.bskip[pli] (1 byte per 4x4, rows of skip_stride bytes).
+ * threshold[pli] = (int)pow(quantizer[pli], 0.84182) (src/filter.c:1878, computed
+ * by the host's libm), quantizer[pli] = state.quantizer[pli]. */
+int od_hip_set_decode_info(od_hip_ctx *ctx, int slot, const unsigned char *dering_flags,
+ const unsigned char *const bskip[], int skip_stride);
+int od_hip_decode_tail(od_hip_ctx *ctx, int slot0, int nslots, const int32_t *threshold,
+ const int32_t *quantizer, int is_keyframe);
+
 /* Host access to device-resident results (row-dense, stride = plane width). */
 int od_hip_download_level(od_hip_ctx *ctx, int slot, int pli, int level,
  od_coeff *dst);
