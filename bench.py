@@ -233,6 +233,28 @@ def main():
             kernels[name] = {'launches': n, 'avg_ms': ms/n}
             if name in alg_bytes:
                 kernels[name]['GBps'] = alg_bytes[name]/(ms/n*1e-3)/1e9
+    # Extra (not part of `value`): the decoder's pixel-domain tail on the same 30 frames
+    # (iDCT + post-filters + deringing on every superblock + smoothing + clamp).
+    decode_extra = None
+    if world == 1:
+        q0 = [int(v) for v in prm['quantizer_' + tag]]
+        thr = [int(1.0*pow(q, 0.84182)) for q in q0]
+        flags = np.ones((FH//32, FW//32), np.uint8)
+        bsk = [np.zeros((FH//4, FW//4), np.uint8) for _ in range(3)]
+        for f in range(FRAMES):
+            ctx.set_decode_info(f, flags, bsk)
+        ctx.decode_tail(thr, q0, 1, 0, FRAMES)
+        ctx.sync()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ctx.decode_tail(thr, q0, 1, 0, FRAMES)
+        ctx.sync()
+        dt = (time.perf_counter() - t1)/reps
+        decode_extra = {'Mpixels_per_s': round(FRAMES*PIC_W*PIC_H/dt/1e6, 1),
+                        'ms_per_30_frames': round(dt*1e3, 3),
+                        'what': 'od_hip_decode_tail: coefficients -> 8-bit picture, deringing '
+                                'forced on for every superblock (worst case)'}
     if rank == 0:
         px = world*FRAMES*PIC_W*PIC_H*args.steps
         value = px/elapsed/1e6
@@ -272,6 +294,8 @@ def main():
                            'bands_per_frame': bands,
                            'share_of_device_time': round(
                                tot_ms/sum(v['avg_ms']*v['launches'] for v in kernels.values()), 4)}
+        if decode_extra:
+            line['decode_tail'] = decode_extra
         if world == 1 and not args.no_cpu_baseline:
             nf = 3
             v, dt = cpu_port_baseline(frames, bmaps, prm, tag, nf)
