@@ -39,7 +39,8 @@ PVQ_BAND_DTYPE = np.dtype([('cg', 'f8'), ('g', 'f8'), ('cos_dist', 'f8', 2), ('d
 
 
 def lib_path():
-    return os.path.join(_HERE, 'libdaala_hip.so')
+    # OD_HIP_LIB: A/B builds of the same library (tuning only)
+    return os.environ.get('OD_HIP_LIB') or os.path.join(_HERE, 'libdaala_hip.so')
 
 
 _lib = None

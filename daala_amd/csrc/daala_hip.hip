@@ -204,7 +204,7 @@ namespace {
 template <int N>
 void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk, int nslots, hipStream_t s,
                 int impl, const double *rsq) {
-  if (impl == 2 || (impl == 3 && N == 32)) {   // N = 32: the LDS variant is faster (VGPR pressure)
+  if (impl == 2 || (impl == 3 && N == 32 && PVQ_G32 == 1)) {   // N = 32, one lane per band: the LDS variant is faster
     dim3 grid((unsigned)((nblk + 63)/64), nlist, nslots);
     hipLaunchKernelGGL(k_pvq_noref<N>, grid, dim3(64), 0, s, a);
   }

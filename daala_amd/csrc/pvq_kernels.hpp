@@ -414,9 +414,18 @@ __device__ __forceinline__ double pvq_rsqrt_tab(const double *tab, int i) {
   return pvq_rsqrt_slow(i);
 }
 
+#ifndef PVQ_G128
+#define PVQ_G128 4            /* lanes per 128-coefficient band */
+#endif
+#ifndef PVQ_G32
+#define PVQ_G32 1             /* lanes per 31/32-coefficient band (1: use the LDS kernel) */
+#endif
+#ifndef PVQ_G16
+#define PVQ_G16 1             /* lanes per 7..15-coefficient band */
+#endif
 template <int N>
 struct PvqGeom {
-  static constexpr int G = N > 32 ? 4 : 1;
+  static constexpr int G = N > 32 ? PVQ_G128 : N > 16 ? PVQ_G32 : PVQ_G16;
   static constexpr int NL = (N + G - 1)/G;
   static constexpr int BPW = 64/G;               // bands per wave
 };
@@ -489,9 +498,10 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
     int s2 = 0, s1 = 0;
 #pragma unroll
     for (int j = 0; j < NL; j++) { s2 += y[j]*y[j]; s1 += y[j]; }
-    if (G > 1) {
-      s2 += __shfl_xor(s2, 1, 64); s1 += __shfl_xor(s1, 1, 64);
-      s2 += __shfl_xor(s2, 2, 64); s1 += __shfl_xor(s1, 2, 64);
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+      s2 += __shfl_xor(s2, o, 64);
+      s1 += __shfl_xor(s1, o, 64);
     }
     // yy accumulates exact integers in double (< 2^53): any order is exact.
     // NOTE: the reference adds ypulse[j]*ypulse[j] as int products one by one;
@@ -665,7 +675,7 @@ template <int N>
 __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelArgs3 aa) {
   const PvqLevelArgs &a = aa.a;
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
-  __shared__ int32_t Yst[BPW*N + 1 + BPW*(G + 1)];
+  __shared__ int32_t Yst[BPW*(N + G + 2) + 1];      // >= BPW*N (output) and >= BPW*LDSN (staging)
   __shared__ int32_t Org[64];
   const int lane = threadIdx.x;
   const int g = lane%G, inst = lane/G;
@@ -688,7 +698,6 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
   // then picks up its own chunk.
   constexpr int CH = NL + 1;                       // padded chunk stride in LDS
   constexpr int LDSN = (G*CH) | 1;                 // odd per-band stride
-  static_assert(BPW*LDSN <= BPW*N + 1 + BPW*(G + 1), "staging fits");
   int32_t cf[NL];
   int qi[NL];
   constexpr bool STAGE = N > 32;   // measured: pays for the 128-coefficient bands only

@@ -203,6 +203,29 @@ def e2e_anchors():
     print('\n'.join(lines))
 
 
+def compute_dist_vectors():
+    """od_compute_dist (static, src/encode.c:1032) through enc_probe, plus the
+    per-coefficient weights it derives from the reference tables."""
+    ep.probe_compute_dist.restype = ctypes.c_double
+    r2 = np.random.default_rng(77)
+    out = {}
+    for bs in (1, 2, 3):
+        n = 4 << bs
+        mag = np.zeros(64)
+        ep.probe_dist_weights(bs, pf64(mag))
+        out['mag2_%d' % bs] = mag
+        x = r2.integers(-2000, 2001, size=(24, n, n), dtype=np.int32)
+        y = (x + r2.integers(-80, 81, size=x.shape)).astype(np.int32)
+        y[:4] = x[:4]
+        for m in (0, 1):
+            out['dist_%d_m%d' % (bs, m)] = np.array([
+                ep.probe_compute_dist(m, p32(np.ascontiguousarray(x[i])),
+                                      p32(np.ascontiguousarray(y[i])), n, bs) for i in range(len(x))])
+        out['x_%d' % bs] = x
+        out['y_%d' % bs] = y
+    np.savez_compressed(os.path.join(G, 'compute_dist.npz'), **out)
+
+
 def dcttest_md5():
     out = subprocess.run([os.path.join(ROOT, 'oracle', '_ref', 'dcttest')], capture_output=True)
     assert out.returncode == 0
@@ -221,6 +244,7 @@ if __name__ == '__main__':
     encoder_params()
     pvq_theta_decisions()
     e2e_anchors()
+    compute_dist_vectors()
     if '--dcttest' in sys.argv:
         dcttest_md5()
     print('golden fixtures written to', G)
