@@ -415,10 +415,10 @@ __device__ __forceinline__ double pvq_rsqrt_tab(const double *tab, int i) {
 }
 
 #ifndef PVQ_G128
-#define PVQ_G128 4            /* lanes per 128-coefficient band */
+#define PVQ_G128 8            /* lanes per 128-coefficient band (A/B on MI355X: 4 -> 8.5 ms, 8 -> 4.6, 16 -> 5.9) */
 #endif
 #ifndef PVQ_G32
-#define PVQ_G32 1             /* lanes per 31/32-coefficient band (1: use the LDS kernel) */
+#define PVQ_G32 4             /* lanes per 31/32-coefficient band (1: LDS kernel 3.05 ms, 2 -> 2.84, 4 -> 2.30, 8 -> 3.18) */
 #endif
 #ifndef PVQ_G16
 #define PVQ_G16 1             /* lanes per 7..15-coefficient band */
@@ -669,7 +669,7 @@ struct PvqLevelArgs3 {
 // No-reference candidates (state-free part of pvq_theta, src/pvq_encoder.c:352-357,
 // :452-481) of the bands of size N of one pyramid level, register-resident.
 #ifndef PVQ_V3_WAVES
-#define PVQ_V3_WAVES(N) ((N) <= 15 ? 4 : (N) <= 32 ? 3 : 2)
+#define PVQ_V3_WAVES(N) 3     /* min waves/SIMD: 3 measured best for every N (4+ spills, 1-2 starves) */
 #endif
 template <int N>
 __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelArgs3 aa) {
