@@ -145,7 +145,6 @@ struct od_hip_ctx {
   int16_t *qm_dev;                           // scratch QM (1024 int16)
   double *rsq;                               // 1/sqrt(i) table (pvq_rsqrt_tab)
   int pvq_impl = 3;                          // 3 = register-resident, 2 = LDS-resident
-  int xform_impl = 2;                        // 2 = row-tile (one wave per 64xSB tile), 1 = one WG per SB
   // PVQ results per (plane, level)
   PvqSoA pvq[OD_HIP_NPLANES_MAX][4];         // device SoA, all slots
   bool pvq_alloc[OD_HIP_NPLANES_MAX][4];
@@ -386,7 +385,6 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
     ok = hipGetLastError() == hipSuccess;
   }
   if (const char *e = getenv("OD_HIP_PVQ_IMPL")) ctx->pvq_impl = atoi(e);
-  if (const char *e = getenv("OD_HIP_XFORM_IMPL")) ctx->xform_impl = atoi(e);
   const uint16_t *tabs[4] = {CODING_TO_RASTER_4, CODING_TO_RASTER_8, CODING_TO_RASTER_16,
                              CODING_TO_RASTER_32};
   const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
@@ -515,23 +513,16 @@ static FwdArgs fwd_args(od_hip_ctx *ctx, int p, int slot0, bool known, int keyfr
 
 int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
-  dim3 grid(ctx->nhsb, ctx->nvsb, nslots);
   for (int p = 0; p < ctx->geo.nplanes; p++) {
     FwdArgs a = fwd_args(ctx, p, slot0, false, 0);
     if (a.dec == 0) {
       Timed tm(ctx, "k_forward_pyramid_luma");
-      if (ctx->xform_impl == 1)
-        hipLaunchKernelGGL((k_forward<32, 4, false>), grid, dim3(256), 0, ctx->stream, a);
-      else
-        hipLaunchKernelGGL((k_forward_rt<32, 4, false>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+      hipLaunchKernelGGL((k_forward_rt<32, 4, false>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
                            dim3(128), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_pyramid_chroma");
-      if (ctx->xform_impl == 1)
-        hipLaunchKernelGGL((k_forward<16, 3, false>), grid, dim3(64), 0, ctx->stream, a);
-      else
-        hipLaunchKernelGGL((k_forward_rt<16, 3, false>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+      hipLaunchKernelGGL((k_forward_rt<16, 3, false>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
                            dim3(128), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
@@ -541,23 +532,16 @@ int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
 
 int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe) {
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
-  dim3 grid(ctx->nhsb, ctx->nvsb, nslots);
   for (int p = 0; p < ctx->geo.nplanes; p++) {
     FwdArgs a = fwd_args(ctx, p, slot0, true, keyframe);
     if (a.dec == 0) {
       Timed tm(ctx, "k_forward_known_luma");
-      if (ctx->xform_impl == 1)
-        hipLaunchKernelGGL((k_forward<32, 4, true>), grid, dim3(256), 0, ctx->stream, a);
-      else
-        hipLaunchKernelGGL((k_forward_rt<32, 4, true>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+      hipLaunchKernelGGL((k_forward_rt<32, 4, true>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
                            dim3(128), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_known_chroma");
-      if (ctx->xform_impl == 1)
-        hipLaunchKernelGGL((k_forward<16, 3, true>), grid, dim3(64), 0, ctx->stream, a);
-      else
-        hipLaunchKernelGGL((k_forward_rt<16, 3, true>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+      hipLaunchKernelGGL((k_forward_rt<16, 3, true>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
                            dim3(128), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
@@ -583,13 +567,10 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
     q.rec = ctx->rec[p] + (size_t)slot0*ctx->psz[p]; q.rec_fstride = ctx->psz[p];
     q.out32 = nullptr;
     q.w = a.w; q.h = a.h; q.nhsb = a.nhsb; q.nvsb = a.nvsb;
-    dim3 grid(ctx->nhsb, ctx->nvsb, nslots), grid2(ctx->nhsb + 1, ctx->nvsb + 1, nslots);
+    dim3 grid2(ctx->nhsb + 1, ctx->nvsb + 1, nslots);
     if (a.dec == 0) {
       { Timed tm(ctx, "k_inverse_sb_luma");
-        if (ctx->xform_impl == 1)
-          hipLaunchKernelGGL((k_inverse_sb<32, 4>), grid, dim3(256), 0, ctx->stream, a);
-        else
-          hipLaunchKernelGGL((k_inverse_rt<32, 4>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+        hipLaunchKernelGGL((k_inverse_rt<32, 4>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
                              dim3(64), 0, ctx->stream, a); }
       HIPCHK(hipGetLastError());
       { Timed tm(ctx, "k_postfilter_clamp_luma");
@@ -597,10 +578,7 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
     }
     else {
       { Timed tm(ctx, "k_inverse_sb_chroma");
-        if (ctx->xform_impl == 1)
-          hipLaunchKernelGGL((k_inverse_sb<16, 3>), grid, dim3(64), 0, ctx->stream, a);
-        else
-          hipLaunchKernelGGL((k_inverse_rt<16, 3>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+        hipLaunchKernelGGL((k_inverse_rt<16, 3>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
                              dim3(64), 0, ctx->stream, a); }
       HIPCHK(hipGetLastError());
       { Timed tm(ctx, "k_postfilter_clamp_chroma");

@@ -1,11 +1,8 @@
-// HIP kernels of the transform path (gfx950, wave64).
-//
-// Work decomposition: one workgroup owns one superblock of
-// one plane of one frame; the SB tile lives in LDS for the whole pipeline, every
-// lane runs one 1-D lifting transform with all N samples in VGPRs, and the
-// separable passes exchange data through a padded (stride SB+1) LDS tile so that
-// both the column reads and the transposed row writes are bank-conflict free.
-// HBM is touched once per input sample (u8) and once per output coefficient.
+// HIP kernels of the transform path (gfx950, wave64): dense block batches, the
+// corner-centred frame post-filter, small helpers and the argument structs.  The
+// frame pipeline's forward / inverse kernels live in xform_rt_kernels.hpp
+// (the first, one-workgroup-per-superblock versions are in the git history:
+// 0.44 ms vs 0.30 ms per 30-frame luma pyramid).
 #pragma once
 #include "xform_device.hpp"
 
@@ -126,80 +123,11 @@ __global__ void k_filter4_vectors(int32_t *__restrict__ out, const int32_t *__re
 }
 
 // ---------------------------------------------------------------------------
-// Shared per-superblock machinery.
+// Tile geometry of the corner-centred post-filter kernel below.
 template <int SB> struct SbTile {
   static constexpr int TH = SB*SB/4;        // threads per workgroup
   static constexpr int LD = SB + 1;         // padded LDS stride
-  static constexpr int HA = SB + 4;         // tile + 2-sample halo each side
-  static constexpr int LDA = SB + 5;
 };
-
-// One separable forward transform level: every N x N block of the SB tile for
-// which pred(byi, bxi) holds.  A is the (halo'd) lapped tile, result -> Y.
-template <int SB, int N, typename Pred>
-__device__ __forceinline__ void sb_fdct_level(const int32_t *A, int32_t *Z, int32_t *Y,
-                                              Pred pred) {
-  using T = SbTile<SB>;
-  constexpr int NB = SB/N;
-  const int t = threadIdx.x;
-  const bool active = t < SB*NB;
-  const int byi = t/SB, col = t%SB, bxi = col/N, i = col%N;
-  const bool go = active && pred(byi, bxi);
-  int32_t v[N];
-  if (go) {
-#pragma unroll
-    for (int k = 0; k < N; k++) v[k] = A[(2 + byi*N + k)*T::LDA + 2 + col];
-    LiftDct<N>::fwd(v);
-#pragma unroll
-    for (int k = 0; k < N; k++) Z[(byi*N + i)*T::LD + bxi*N + k] = v[k];
-  }
-  __syncthreads();
-  if (go) {
-#pragma unroll
-    for (int k = 0; k < N; k++) v[k] = Z[(byi*N + k)*T::LD + col];
-    LiftDct<N>::fwd(v);
-#pragma unroll
-    for (int k = 0; k < N; k++) Y[(byi*N + i)*T::LD + bxi*N + k] = v[k];
-  }
-  __syncthreads();
-}
-
-// Lapping on the internal cross of every N x N block with pred(byi,bxi) that is
-// about to be split (src/filter.c:1486-1510): first the taps across the
-// horizontal centre line (gated by hf), then across the vertical one (vf).
-template <int SB, int N, typename Pred, typename PredH, typename PredV>
-__device__ __forceinline__ void sb_split_pre(int32_t *A, Pred pred, PredH hf, PredV vf) {
-  using T = SbTile<SB>;
-  constexpr int NB = SB/N;
-  const int t = threadIdx.x;
-  if (t < SB*NB) {
-    const int byi = t/SB, col = t%SB, bxi = col/N;
-    if (pred(byi, bxi) && hf(byi, bxi)) {
-      int32_t *p = A + (2 + byi*N + N/2 - 2)*T::LDA + 2 + col;
-      lap4_pre(p[0], p[T::LDA], p[2*T::LDA], p[3*T::LDA]);
-    }
-  }
-  __syncthreads();
-  if (t < SB*NB) {
-    const int row = t/NB, bxi = t%NB, byi = row/N;
-    if (pred(byi, bxi) && vf(byi, bxi)) {
-      int32_t *p = A + (2 + row)*T::LDA + 2 + bxi*N + N/2 - 2;
-      lap4_pre(p[0], p[1], p[2], p[3]);
-    }
-  }
-  __syncthreads();
-}
-
-template <int SB>
-__device__ __forceinline__ void sb_store_tile(int32_t *__restrict__ dst, int w,
-                                              const int32_t *Y) {
-  using T = SbTile<SB>;
-  const int t = threadIdx.x;
-  const int r = t/(SB/4), c = (t%(SB/4))*4;
-  int4 v = make_int4(Y[r*T::LD + c], Y[r*T::LD + c + 1], Y[r*T::LD + c + 2],
-                     Y[r*T::LD + c + 3]);
-  *reinterpret_cast<int4 *>(dst + (size_t)r*w + c) = v;
-}
 
 struct FwdArgs {
   const uint8_t *pix;      // padded 8-bit plane, frame 0
@@ -217,105 +145,6 @@ struct FwdArgs {
   int keyframe;
 };
 
-// Forward path of one superblock: A1 (u8 -> coeff), A4 (frame lapping on the SB
-// edges, computed from a 2-sample halo), then per level A5 (split lapping) and
-// A6 (fDCT).  PYRAMID: every block of every level is transformed and stored
-// (level planes).  KNOWN: only the leaves of the given quadtree, plus the
-// keyframe Haar merge of child DCs (od_compute_dcts, src/encode.c:1286-1343).
-template <int SB, int NLEV, bool KNOWN>
-__global__ __launch_bounds__(SB*SB/4) void k_forward(FwdArgs a) {
-  using T = SbTile<SB>;
-  __shared__ int32_t A[T::HA*T::LDA];
-  __shared__ int32_t Z[SB*T::LD];
-  __shared__ int32_t Y[SB*T::LD];
-  __shared__ uint8_t bsz[16];
-  const int t = threadIdx.x;
-  const int sbx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
-  const int x0 = sbx*SB, y0 = sby*SB;
-  const uint8_t *pix = a.pix + (size_t)f*a.pix_fstride;
-  if (KNOWN && t < 16) {
-    bsz[t] = a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4 + (t >> 2))*a.bstride
-                     + sbx*4 + (t & 3)];
-  }
-  for (int e = t; e < T::HA*T::HA; e += T::TH) {
-    int ty = e/T::HA, tx = e%T::HA;
-    int gy = min(max(y0 - 2 + ty, 0), a.h - 1), gx = min(max(x0 - 2 + tx, 0), a.w - 1);
-    A[ty*T::LDA + tx] = ((int32_t)pix[(size_t)gy*a.pstride + gx] - 128) << 4;
-  }
-  __syncthreads();
-  // frame lapping, horizontal SB boundaries first (vertical taps, all columns
-  // of the halo'd tile), then vertical boundaries (src/filter.c:1566-1584).
-  if (t < T::HA) {
-    if (sby > 0) {
-      int32_t *p = A + t;
-      lap4_pre(p[0], p[T::LDA], p[2*T::LDA], p[3*T::LDA]);
-    }
-    if (sby < a.nvsb - 1) {
-      int32_t *p = A + SB*T::LDA + t;
-      lap4_pre(p[0], p[T::LDA], p[2*T::LDA], p[3*T::LDA]);
-    }
-  }
-  __syncthreads();
-  if (t < SB) {
-    if (sbx > 0) {
-      int32_t *p = A + (2 + t)*T::LDA;
-      lap4_pre(p[0], p[1], p[2], p[3]);
-    }
-    if (sbx < a.nhsb - 1) {
-      int32_t *p = A + (2 + t)*T::LDA + SB;
-      lap4_pre(p[0], p[1], p[2], p[3]);
-    }
-  }
-  __syncthreads();
-  const int dec = a.dec;
-  auto cell = [&](int byi, int bxi, int n) -> int {     // max(obs, dec) of a block
-    int nl = n << dec;
-    int o = bsz[((byi*nl) >> 3)*4 + ((bxi*nl) >> 3)];
-    return o > dec ? o : dec;
-  };
-  int32_t *out = a.out + (size_t)f*a.out_fstride + (size_t)y0*a.w + x0;
-#define FWD_LEVEL(K)                                                                   \
-  if constexpr (K < NLEV) {                                                            \
-    constexpr int N = SB >> K;                                                         \
-    constexpr int NB = SB/N;                                                           \
-    auto leaf = [&](int byi, int bxi) { return !KNOWN || cell(byi, bxi, N) == 3 - K; };\
-    auto split = [&](int byi, int bxi) { return !KNOWN || cell(byi, bxi, N) < 3 - K; };\
-    auto hf = [&](int byi, int bxi) { return (sbx*NB + bxi + 1)*N <= a.pic_w; };       \
-    auto vf = [&](int byi, int bxi) { return (sby*NB + byi + 1)*N <= a.pic_h; };       \
-    sb_fdct_level<SB, N>(A, Z, Y, leaf);                                               \
-    if (!KNOWN) {                                                                      \
-      sb_store_tile<SB>(out + (size_t)K*a.out_lstride, a.w, Y);                        \
-      __syncthreads();                                                                 \
-    }                                                                                  \
-    if (K + 1 < NLEV) sb_split_pre<SB, N>(A, split, hf, vf);                           \
-  }
-  FWD_LEVEL(0)
-  FWD_LEVEL(1)
-  FWD_LEVEL(2)
-  FWD_LEVEL(3)
-#undef FWD_LEVEL
-  if (KNOWN) {
-    if (a.keyframe) {
-      // Haar merge of the four child DCs of every split block, finest first.
-      for (int k = NLEV - 2; k >= 0; k--) {
-        int n = SB >> k, nb = SB/n, hh = n/2;
-        if (t < nb*nb) {
-          int byi = t/nb, bxi = t%nb;
-          if (cell(byi, bxi, n) < 3 - k) {
-            int32_t *p = Y + (byi*n)*T::LD + bxi*n;
-            int32_t q0 = p[0], q1 = p[hh], q2 = p[hh*T::LD], q3 = p[hh*T::LD + hh];
-            haar2x2(q0, q2, q1, q3);
-            p[0] = q0; p[hh] = q1; p[hh*T::LD] = q2; p[hh*T::LD + hh] = q3;
-          }
-        }
-        __syncthreads();
-      }
-    }
-    sb_store_tile<SB>(out, a.w, Y);
-  }
-}
-
-// ---------------------------------------------------------------------------
 struct InvArgs {
   const int32_t *d;        // coefficient plane, frame 0
   int32_t *c;              // work plane (spatial, lapped domain)
@@ -327,88 +156,6 @@ struct InvArgs {
   int pic_w, pic_h;
   int dec;
 };
-
-// Inverse path of one superblock: iDCT of every leaf, then the split
-// post-filters from the finest level up (src/decode.c:843-866,
-// src/filter.c:1512-1554: vertical-line taps first, then horizontal-line taps).
-template <int SB, int NLEV>
-__global__ __launch_bounds__(SB*SB/4) void k_inverse_sb(InvArgs a) {
-  using T = SbTile<SB>;
-  __shared__ int32_t Y[SB*T::LD];
-  __shared__ int32_t Z[SB*T::LD];
-  __shared__ int32_t X[SB*T::LD];
-  __shared__ uint8_t bsz[16];
-  const int t = threadIdx.x;
-  const int sbx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
-  const int x0 = sbx*SB, y0 = sby*SB;
-  const int dec = a.dec;
-  if (t < 16) {
-    bsz[t] = a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4 + (t >> 2))*a.bstride
-                     + sbx*4 + (t & 3)];
-  }
-  {
-    const int32_t *src = a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
-    const int r = t/(SB/4), c = (t%(SB/4))*4;
-    int4 v = *reinterpret_cast<const int4 *>(src + (size_t)r*a.w + c);
-    Y[r*T::LD + c] = v.x; Y[r*T::LD + c + 1] = v.y;
-    Y[r*T::LD + c + 2] = v.z; Y[r*T::LD + c + 3] = v.w;
-  }
-  __syncthreads();
-  auto cell = [&](int byi, int bxi, int n) -> int {
-    int nl = n << dec;
-    int o = bsz[((byi*nl) >> 3)*4 + ((bxi*nl) >> 3)];
-    return o > dec ? o : dec;
-  };
-#define INV_LEVEL(K)                                                                   \
-  if constexpr (K < NLEV) {                                                            \
-    constexpr int N = SB >> K;                                                         \
-    constexpr int NB = SB/N;                                                           \
-    const bool act = t < SB*NB;                                                        \
-    const int row = t/NB, bxi = t%NB, byi = row/N, i = row%N;                          \
-    const bool go = act && cell(byi, bxi, N) == 3 - K;                                 \
-    int32_t v[N];                                                                      \
-    if (go) {                                                                          \
-      _Pragma("unroll") for (int k = 0; k < N; k++) v[k] = Y[row*T::LD + bxi*N + k];   \
-      LiftDct<N>::inv(v);                                                              \
-      _Pragma("unroll") for (int k = 0; k < N; k++)                                    \
-        Z[(byi*N + k)*T::LD + bxi*N + i] = v[k];                                       \
-    }                                                                                  \
-    __syncthreads();                                                                   \
-    if (go) {                                                                          \
-      _Pragma("unroll") for (int k = 0; k < N; k++) v[k] = Z[row*T::LD + bxi*N + k];   \
-      LiftDct<N>::inv(v);                                                              \
-      _Pragma("unroll") for (int k = 0; k < N; k++)                                    \
-        X[(byi*N + k)*T::LD + bxi*N + i] = v[k];                                       \
-    }                                                                                  \
-    __syncthreads();                                                                   \
-  }
-  INV_LEVEL(0)
-  INV_LEVEL(1)
-  INV_LEVEL(2)
-  INV_LEVEL(3)
-#undef INV_LEVEL
-  // split post-filters, finest split first
-  for (int k = NLEV - 2; k >= 0; k--) {
-    const int n = SB >> k, nb = SB/n;
-    if (t < SB*nb) {            // taps across the vertical centre line (rows)
-      const int row = t/nb, bxi = t%nb, byi = row/n;
-      if (cell(byi, bxi, n) < 3 - k && (sby*nb + byi + 1)*n <= a.pic_h) {
-        int32_t *p = X + row*T::LD + bxi*n + n/2 - 2;
-        lap4_post(p[0], p[1], p[2], p[3]);
-      }
-    }
-    __syncthreads();
-    if (t < SB*nb) {            // taps across the horizontal centre line (columns)
-      const int byi = t/SB, col = t%SB, bxi = col/n;
-      if (cell(byi, bxi, n) < 3 - k && (sbx*nb + bxi + 1)*n <= a.pic_w) {
-        int32_t *p = X + (byi*n + n/2 - 2)*T::LD + col;
-        lap4_post(p[0], p[T::LD], p[2*T::LD], p[3*T::LD]);
-      }
-    }
-    __syncthreads();
-  }
-  sb_store_tile<SB>(a.c + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, X);
-}
 
 struct PostArgs {
   const int32_t *c;

@@ -527,3 +527,31 @@ def test_compute_dist_blocks(hip):
             e = g['dist_%d_m%d' % (bs, m)]
             assert np.all(np.abs(d - e) <= 8*np.spacing(np.abs(e)))
             assert np.mean(d == e) > 0.3
+
+
+def test_pvq_lds_variant_matches_register_variant(hip, monkeypatch):
+    """OD_HIP_PVQ_IMPL=2 selects the LDS-resident search kernels (kept as the
+    alternative implementation): identical records and pulses to the default."""
+    prm = golden('encoder_params.npz')
+    pic_w, pic_h, fw, fh = 150, 100, 192, 128
+    planes = [synth_plane(fw, fh, 11), synth_plane(fw//2, fh//2, 11, 1)]
+    res = []
+    for impl in ('3', '2'):
+        monkeypatch.setenv('OD_HIP_PVQ_IMPL', impl)
+        ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nplanes=2, xdec=(0, 1), nslots=1)
+        ctx.upload_planes(0, planes)
+        ctx.forward_pyramid()
+        out = []
+        for pli in (0, 1):
+            for level in range(ctx.nlevels(pli)):
+                n = (32 >> pli) >> level
+                bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+                off, q, beta, qm = level_params(prm, 'q20_m1', pli, bs, pli)
+                ctx.pvq_noref_search(pli, level, qm, q, beta)
+                out.append(ctx.pvq_download(0, pli, level))
+        ctx.close()
+        res.append(out)
+    for (b3, y3), (b2, y2) in zip(*res):
+        assert np.array_equal(y3, y2)
+        for f in ('cg', 'g', 'cos_dist', 'dist', 'qg', 'k', 'ncand'):
+            assert np.array_equal(b3[f], b2[f]), f
