@@ -55,6 +55,12 @@ int probe_decode_dump(int w, int h, int quant, int masking, const unsigned char 
   daala_encode_ctl(enc, OD_SET_QUANT, &quant, sizeof(quant));
   daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
   daala_encode_ctl(enc, OD_SET_ACTIVITY_MASKING, &masking, sizeof(masking));
+  {
+    /* never initialised by daala_encode_create; the reference CLI sets it to 1
+       (examples/encoder_example.c:675,900) */
+    int use_dering = 1;
+    daala_encode_ctl(enc, OD_SET_DERING, &use_dering, sizeof(use_dering));
+  }
   daala_comment_init(&dc);
   daala_info_init(&di2);
   daala_comment_init(&dc2);

@@ -92,6 +92,14 @@ static daala_enc_ctx *make_encoder(int w, int h, int quant, int complexity,
   daala_encode_ctl(enc, OD_SET_QUANT, &quant, sizeof(quant));
   daala_encode_ctl(enc, OD_SET_COMPLEXITY, &complexity, sizeof(complexity));
   daala_encode_ctl(enc, OD_SET_ACTIVITY_MASKING, &masking, sizeof(masking));
+  {
+    /* enc->use_dering is never initialised by daala_encode_create (it is only
+       written by this ctl, src/encode.c:527); the reference CLI always sets it,
+       default 1 (examples/encoder_example.c:675,900).  Do the same, or the
+       deringing decisions depend on heap garbage. */
+    int use_dering = 1;
+    daala_encode_ctl(enc, OD_SET_DERING, &use_dering, sizeof(use_dering));
+  }
   return enc;
 }
 
