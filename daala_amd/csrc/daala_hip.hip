@@ -1109,3 +1109,5 @@ int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches, double
 }
 
 }  // extern "C"
+
+#include "enc_feed.hpp"

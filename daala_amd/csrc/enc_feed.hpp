@@ -1,0 +1,152 @@
+// Encoder feed (include/daala_hip.h section 4b): batch launch of the state-free
+// keyframe-luma work + asynchronous hand-over to pinned host memory, one event per
+// frame slot so that host workers start on a frame as soon as its records landed.
+// Included at the end of daala_hip.hip (needs od_hip_ctx internals).
+#pragma once
+
+struct od_hip_enc_feed {
+  od_hip_ctx *ctx = nullptr;
+  hipStream_t copy = nullptr;
+  hipEvent_t computed = nullptr;
+  std::vector<hipEvent_t> ready;          // one per slot
+  std::vector<char> pending;              // slot has a copy in flight / landed
+  struct Lev {
+    int n, bs, nb, nblk, nbx, off[11];
+    size_t nrec, ny;
+    bool set = false;
+    std::vector<int16_t> qm;
+    int32_t q[11];
+    double beta[11];
+    // pinned host mirrors, all slots: [slot][...]
+    int32_t *ncand = nullptr, *k = nullptr, *qg = nullptr, *y = nullptr;
+    double *cos_dist = nullptr, *cg = nullptr;
+  } lev[4];
+};
+
+extern "C" {
+
+void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
+  if (!f) return;
+  (void)hipSetDevice(f->ctx->device);
+  if (f->copy) (void)hipStreamSynchronize(f->copy);
+  for (auto &l : f->lev) {
+    if (l.ncand) (void)hipHostFree(l.ncand);
+    if (l.k) (void)hipHostFree(l.k);
+    if (l.qg) (void)hipHostFree(l.qg);
+    if (l.cg) (void)hipHostFree(l.cg);
+    if (l.y) (void)hipHostFree(l.y);
+    if (l.cos_dist) (void)hipHostFree(l.cos_dist);
+  }
+  for (auto e : f->ready) if (e) (void)hipEventDestroy(e);
+  if (f->computed) (void)hipEventDestroy(f->computed);
+  if (f->copy) (void)hipStreamDestroy(f->copy);
+  delete f;
+}
+
+od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
+  if (!ctx) { fail(OD_HIP_EFAULT, "null context"); return nullptr; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { fail(OD_HIP_ENODEV, "hipSetDevice failed"); return nullptr; }
+  od_hip_enc_feed *f = new od_hip_enc_feed();
+  f->ctx = ctx;
+  size_t ns = ctx->geo.nslots;
+  bool ok = hipStreamCreateWithFlags(&f->copy, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&f->computed, hipEventDisableTiming) == hipSuccess;
+  f->ready.assign(ns, nullptr);
+  f->pending.assign(ns, 0);
+  for (size_t s = 0; ok && s < ns; s++)
+    ok = hipEventCreateWithFlags(&f->ready[s], hipEventDisableTiming) == hipSuccess;
+  for (int l = 0; ok && l < 4; l++) {
+    auto &L = f->lev[l];
+    L.n = 32 >> l;
+    L.bs = 3 - l;
+    L.nb = od_hip_band_offsets(L.bs, L.off);
+    L.nbx = ctx->pw[0]/L.n;
+    L.nblk = L.nbx*(ctx->ph[0]/L.n);
+    int ncoded = L.n*L.n < 512 ? L.n*L.n : 512;
+    L.nrec = (size_t)L.nb*L.nblk;
+    L.ny = (size_t)2*L.nblk*(ncoded - 1);
+    ok = ok && hipHostMalloc((void **)&L.ncand, ns*L.nrec*4) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.k, ns*2*L.nrec*4) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.qg, ns*2*L.nrec*4) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.cg, ns*L.nrec*8) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.cos_dist, ns*2*L.nrec*8) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.y, ns*L.ny*4) == hipSuccess;
+  }
+  if (!ok) {
+    fail(OD_HIP_ENODEV, "encoder feed allocation failed");
+    od_hip_enc_feed_destroy(f);
+    return nullptr;
+  }
+  return f;
+}
+
+int od_hip_enc_feed_set_level(od_hip_enc_feed *f, int level, const int16_t *qm,
+                              const int32_t *q, const double *beta) {
+  if (!f || !qm || !q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
+  if (level < 0 || level > 3) return fail(OD_HIP_EINVAL, "level out of range");
+  auto &L = f->lev[level];
+  L.qm.assign(qm, qm + L.n*L.n);
+  for (int b = 0; b < L.nb; b++) { L.q[b] = q[b]; L.beta[b] = beta[b]; }
+  L.set = true;
+  return 0;
+}
+
+int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
+  if (!f) return fail(OD_HIP_EFAULT, "null feed");
+  od_hip_ctx *ctx = f->ctx;
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  for (auto &L : f->lev) if (!L.set) return fail(OD_HIP_EINVAL, "feed level parameters not set");
+  // a slot's host mirror must not be overwritten while a previous copy is in flight
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    if (f->pending[s]) HIPCHK(hipEventSynchronize(f->ready[s]));
+  }
+  if (int rc = od_hip_forward_pyramid(ctx, slot0, nslots)) return rc;
+  for (int l = 0; l < 4; l++) {
+    auto &L = f->lev[l];
+    if (int rc = od_hip_pvq_noref_search(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
+  }
+  HIPCHK(hipEventRecord(f->computed, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    for (int l = 0; l < 4; l++) {
+      auto &L = f->lev[l];
+      PvqSoA &o = ctx->pvq[0][l];
+      HIPCHK(hipMemcpyAsync(L.ncand + s*L.nrec, o.ncand + s*L.nrec, L.nrec*4, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(L.cg + s*L.nrec, o.cg + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(L.qg + s*2*L.nrec, o.qg + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(L.k + s*2*L.nrec, o.k + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(L.cos_dist + s*2*L.nrec, o.cos_dist + s*2*L.nrec, 2*L.nrec*8, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(L.y + s*L.ny, o.y + s*L.ny, L.ny*4, hipMemcpyDeviceToHost, f->copy));
+    }
+    HIPCHK(hipEventRecord(f->ready[s], f->copy));
+    f->pending[s] = 1;
+  }
+  return 0;
+}
+
+int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4]) {
+  if (!f || !lev) return fail(OD_HIP_EFAULT, "null pointer");
+  if (slot < 0 || slot >= f->ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
+  if (!f->pending[slot]) return fail(OD_HIP_EINVAL, "no feed run covers this slot");
+  HIPCHK(hipSetDevice(f->ctx->device));       // callers are host worker threads
+  HIPCHK(hipEventSynchronize(f->ready[slot]));
+  for (int l = 0; l < 4; l++) {
+    auto &L = f->lev[l];
+    od_hip_feed_level &v = lev[l];
+    v.n = L.n;
+    v.nbands = L.nb;
+    v.nblk = L.nblk;
+    v.nbx = L.nbx;
+    for (int i = 0; i < 11; i++) v.off[i] = i <= L.nb ? L.off[i] : 0;
+    v.pad = 0;
+    v.ncand = L.ncand + slot*L.nrec;
+    v.k = L.k + slot*2*L.nrec;
+    v.qg = L.qg + slot*2*L.nrec;
+    v.cg = L.cg + slot*L.nrec;
+    v.cos_dist = L.cos_dist + slot*2*L.nrec;
+    v.y = L.y + slot*L.ny;
+  }
+  return 0;
+}
+
+}  // extern "C"

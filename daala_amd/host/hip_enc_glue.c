@@ -1,0 +1,559 @@
+/* hip_enc_glue.c - reference-side binding of the batched frame seam
+ * (INTEGRATION.md seam 2; header hip_enc_glue.h).
+ *
+ * Compiled into a build of the reference encoder (oracle/Makefile target
+ * _ref/libdaala_hipenc.so): it includes the reference's internal headers and
+ * provides the two symbols that build leaves open,
+ *
+ *   pvq_search_rdo_double()   the call sites of src/pvq_encoder.c:426,463 - the
+ *                             reference's own definition (:121) is kept under the
+ *                             name pvq_search_rdo_double_cpu by the build recipe;
+ *   od_pvq_encode()           called by od_block_encode (src/encode.c:1173) - the
+ *                             reference's definition (src/pvq_encoder.c:645) is
+ *                             kept as od_pvq_encode_cpu;
+ *
+ * so that every keyframe-luma no-reference search (src/pvq_encoder.c:452-481, the
+ * state-free half of pvq_theta) is answered from the device feed
+ * (include/daala_hip.h section 4b) while with-reference and chroma searches, whose
+ * inputs depend on the serial reconstruction, stay the reference's C code.
+ * No reference text lives in this file. */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "encint.h"
+#include "pvq.h"
+#include "pvq_encoder.h"
+#include "partition.h"
+
+#include "hip_enc_glue.h"
+
+/* kept reference definitions (see oracle/Makefile, pvq_hook_tail.c, encode_tu.c) */
+double od_ref_pvq_search_rdo_double_cpu(const double *xcoeff, int n, int k,
+ od_coeff *ypulse, double g2);
+int od_pvq_encode_cpu(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
+ od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,
+ int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
+ const int16_t *qm_inv);
+void od_hipenc_copy_pad(daala_enc_ctx *enc, od_img *img);
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9*ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Per-thread state: which frame's feed this worker consumes and where in the
+   call sequence of the current block it is. */
+typedef struct glue_tls {
+  const od_hip_feed_level *lev;   /* 4 views, or NULL: plain reference */
+  int active;                     /* inside od_pvq_encode of a keyframe luma block */
+  int level;
+  int blk;
+  int band;
+  int cand;
+  int check;
+  int time_cpu;
+  od_hipenc_stats st;
+} glue_tls;
+
+static __thread glue_tls T;
+
+static int is_noref_size(int n) {
+  return n == 15 || n == 8 || n == 32 || n == 128;
+}
+
+double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypulse,
+ double g2) {
+  double t0;
+  double r;
+  int from_feed;
+  from_feed = 0;
+  if (T.active && is_noref_size(n)) {
+    const od_hip_feed_level *L;
+    size_t nrec;
+    L = &T.lev[T.level];
+    nrec = (size_t)L->nbands*L->nblk;
+    /* The no-reference loop of pvq_theta runs for every band of a keyframe luma
+       block, bands in order, candidates i = max(1,floor(cg)) .. ceil(cg) in
+       order: the next call is the next candidate the device enumerated. */
+    while (T.band < L->nbands
+     && T.cand >= L->ncand[(size_t)T.band*L->nblk + T.blk]) {
+      T.band++;
+      T.cand = 0;
+    }
+    if (T.band < L->nbands) {
+      size_t rec;
+      int nb;
+      rec = (size_t)T.band*L->nblk + T.blk;
+      nb = L->off[T.band + 1] - L->off[T.band];
+      if (nb == n && L->k[T.cand*nrec + rec] == k) {
+        if ((double)L->qg[T.cand*nrec + rec]*L->cg[rec] == g2) {
+          const int32_t *src;
+          src = L->y + (size_t)2*L->nblk*(L->off[T.band] - 1)
+           + ((size_t)T.cand*L->nblk + T.blk)*nb;
+          if (T.check) {
+            od_coeff ytmp[128];
+            double rc;
+            rc = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ytmp, g2);
+            if (rc != L->cos_dist[T.cand*nrec + rec]
+             || memcmp(ytmp, src, sizeof(od_coeff)*n) != 0) {
+              T.st.check_fail++;
+            }
+          }
+          memcpy(ypulse, src, sizeof(od_coeff)*n);
+          r = L->cos_dist[T.cand*nrec + rec];
+          T.st.dev_hits++;
+          T.cand++;
+          return r;
+        }
+        /* Same candidate, but the host's cg differs from the device's in the last
+           place (beta = 1.5 goes through libm pow): the search must see the
+           host's g2, so run it here and stay in step. */
+        T.st.g2_mismatch++;
+        T.cand++;
+      }
+      else {
+        T.st.lost_sync++;
+        T.active = 0;
+      }
+    }
+    else {
+      T.st.lost_sync++;
+      T.active = 0;
+    }
+    from_feed = 1;
+  }
+  if (from_feed) T.st.cpu_noref_luma++;
+  else T.st.cpu_other++;
+  if (T.time_cpu) {
+    t0 = now_s();
+    r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
+    T.st.search_cpu_s += now_s() - t0;
+    return r;
+  }
+  return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
+}
+
+int od_pvq_encode(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out,
+ int q0, int pli, int bs, const double *beta, int robust, int is_keyframe,
+ int q_scaling, int bx, int by, const int16_t *qm, const int16_t *qm_inv) {
+  int ret;
+  T.active = 0;
+  if (T.lev != NULL && is_keyframe && pli == 0 && bs >= 0 && bs < 4) {
+    const od_hip_feed_level *L;
+    /* bx, by arrive in 4x4 units (src/encode.c:1101-1102) */
+    T.level = 3 - bs;
+    L = &T.lev[T.level];
+    T.blk = (by >> bs)*L->nbx + (bx >> bs);
+    T.band = 0;
+    T.cand = 0;
+    T.active = T.blk >= 0 && T.blk < L->nblk;
+  }
+  ret = od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust,
+   is_keyframe, q_scaling, bx, by, qm, qm_inv);
+  T.active = 0;
+  return ret;
+}
+
+/* ------------------------------------------------------------------------ */
+static daala_enc_ctx *make_encoder(const od_hipenc_params *p, int w, int h) {
+  daala_info di;
+  daala_enc_ctx *enc;
+  int v;
+  daala_info_init(&di);
+  di.pic_width = w;
+  di.pic_height = h;
+  di.nplanes = 3;
+  di.plane_info[0].xdec = di.plane_info[0].ydec = 0;
+  di.plane_info[1].xdec = di.plane_info[1].ydec = 1;
+  di.plane_info[2].xdec = di.plane_info[2].ydec = 1;
+  di.timebase_numerator = 30;
+  di.timebase_denominator = 1;
+  di.frame_duration = 1;
+  di.pixel_aspect_numerator = di.pixel_aspect_denominator = 1;
+  di.bitdepth_mode = OD_BITDEPTH_MODE_8;
+  di.keyframe_rate = 1;
+  enc = daala_encode_create(&di);
+  if (enc == NULL) return NULL;
+  v = p->quant;
+  daala_encode_ctl(enc, OD_SET_QUANT, &v, sizeof(v));
+  v = p->complexity;
+  daala_encode_ctl(enc, OD_SET_COMPLEXITY, &v, sizeof(v));
+  v = p->masking;
+  daala_encode_ctl(enc, OD_SET_ACTIVITY_MASKING, &v, sizeof(v));
+  /* use_dering has no default inside the library (only src/encode.c:527 writes
+     it); the reference CLI always sets 1 (examples/encoder_example.c:675,900). */
+  v = 1;
+  daala_encode_ctl(enc, OD_SET_DERING, &v, sizeof(v));
+  return enc;
+}
+
+static void fill_img(od_img *img, const unsigned char *base, int w, int h) {
+  int cw;
+  int ch;
+  int pli;
+  cw = (w + 1) >> 1;
+  ch = (h + 1) >> 1;
+  memset(img, 0, sizeof(*img));
+  img->nplanes = 3;
+  img->width = w;
+  img->height = h;
+  img->planes[0].data = (unsigned char *)base;
+  img->planes[1].data = (unsigned char *)base + (size_t)w*h;
+  img->planes[2].data = (unsigned char *)base + (size_t)w*h + (size_t)cw*ch;
+  for (pli = 0; pli < 3; pli++) {
+    img->planes[pli].xdec = img->planes[pli].ydec = pli > 0;
+    img->planes[pli].xstride = 1;
+    img->planes[pli].ystride = pli ? cw : w;
+    img->planes[pli].bitdepth = 8;
+  }
+}
+
+int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
+ int32_t q[4][11], double beta[4][11]) {
+  unsigned char frame[64*64 + 2*32*32];
+  daala_enc_ctx *enc;
+  daala_packet dp;
+  od_img img;
+  int left;
+  int l;
+  if (p == NULL) return OD_HIP_EFAULT;
+  /* state.qm / pvq_qm_q4 / quantizer are filled while the first frame is coded
+     (src/encode.c:3025-3050): code one flat 64x64 frame and read them back. */
+  memset(frame, 128, sizeof(frame));
+  enc = make_encoder(p, 64, 64);
+  if (enc == NULL) return OD_HIP_EINVAL;
+  fill_img(&img, frame, 64, 64);
+  if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) {
+    daala_encode_free(enc);
+    return OD_HIP_EINVAL;
+  }
+  while (daala_encode_packet_out(enc, 0, &dp) > 0);
+  for (l = 0; l < 4; l++) {
+    int bs;
+    int n;
+    int nb;
+    int b;
+    bs = 3 - l;
+    n = 4 << bs;
+    nb = OD_BAND_OFFSETS[bs][0];
+    memset(qm[l], 0, sizeof(qm[l]));
+    memcpy(qm[l], enc->state.qm + od_qm_offset(bs, 0), sizeof(int16_t)*n*n);
+    for (b = 0; b < 11; b++) {
+      q[l][b] = 1;
+      beta[l][b] = 1;
+    }
+    for (b = 0; b < nb; b++) {
+      /* src/pvq_encoder.c:712 */
+      q[l][b] = OD_MAXI(1, enc->state.quantizer[0]
+       *enc->state.pvq_qm_q4[0][od_qm_get_index(bs, b + 1)] >> 4);
+      beta[l][b] = OD_PVQ_BETA[enc->use_activity_masking][0][bs][b];
+    }
+  }
+  daala_encode_free(enc);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+typedef struct job {
+  const od_hipenc_params *p;
+  int nframes;
+  const unsigned char *frames;
+  size_t frame_bytes;
+  const od_hip_feed_level *views;
+  od_hip_ctx *ctx;
+  od_hip_enc_feed *feed;
+  int batch;
+  /* phases */
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int encoders_ready;
+  int go;               /* 1: upload phase open, 2: encode phase open */
+  int uploaded;         /* frames uploaded in the current batch */
+  int batch0;           /* first frame of the current device batch */
+  int batch_n;
+  int next_upload;
+  int next_encode;
+  int encoded;          /* frames completely coded */
+  int launched_upto;    /* frames [0, launched_upto) have a feed run enqueued */
+  int failed;
+  /* outputs */
+  unsigned char **pkt;
+  long *pkt_len;
+  od_hipenc_stats st;
+} job;
+
+static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
+  a->dev_hits += b->dev_hits;
+  a->cpu_noref_luma += b->cpu_noref_luma;
+  a->cpu_other += b->cpu_other;
+  a->g2_mismatch += b->g2_mismatch;
+  a->lost_sync += b->lost_sync;
+  a->check_fail += b->check_fail;
+  a->search_cpu_s += b->search_cpu_s;
+}
+
+static int upload_frame(job *J, daala_enc_ctx *enc, int f) {
+  od_img img;
+  od_img *pad;
+  const unsigned char *planes[3];
+  int ystride[3];
+  int pli;
+  fill_img(&img, J->frames + J->frame_bytes*f, J->p->pic_width, J->p->pic_height);
+  /* the reference's own padding (od_img_copy_pad, src/encode.c:1728) */
+  od_hipenc_copy_pad(enc, &img);
+  pad = &enc->input_img[0];
+  for (pli = 0; pli < 3; pli++) {
+    planes[pli] = pad->planes[pli].data;
+    ystride[pli] = pad->planes[pli].ystride;
+  }
+  return od_hip_upload_planes(J->ctx, f - J->batch0, planes, ystride);
+}
+
+static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
+  od_img img;
+  daala_packet dp;
+  int left;
+  od_hip_feed_level lev[4];
+  T.lev = NULL;
+  if (J->views != NULL) T.lev = J->views + 4*(size_t)f;
+  else if (J->feed != NULL) {
+    if (od_hip_enc_feed_view(J->feed, f - J->batch0, lev) != 0) return -1;
+    T.lev = lev;
+  }
+  /* Frame f of the stream on a context that did not code frames 0..f-1: the
+     only history a keyframe packet carries is the golden-frame flag
+     (ip_frame_count % OD_GOLDEN_FRAME_INTERVAL, forced on while no golden
+     reference exists; src/encode.c:2958-2963, :3023). */
+  enc->ip_frame_count = f;
+  if (f > 0 && enc->state.ref_imgi[OD_FRAME_GOLD] < 0) {
+    enc->state.ref_imgi[OD_FRAME_GOLD] = 0;
+    enc->state.ref_imgi[OD_FRAME_PREV] = 0;
+  }
+  fill_img(&img, J->frames + J->frame_bytes*f, J->p->pic_width, J->p->pic_height);
+  if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
+  J->pkt_len[f] = 0;
+  while (daala_encode_packet_out(enc, 0, &dp) > 0) {
+    unsigned char *q;
+    q = (unsigned char *)realloc(J->pkt[f], J->pkt_len[f] + 4 + dp.bytes);
+    if (q == NULL) return -3;
+    J->pkt[f] = q;
+    q += J->pkt_len[f];
+    q[0] = dp.bytes & 255;
+    q[1] = (dp.bytes >> 8) & 255;
+    q[2] = (dp.bytes >> 16) & 255;
+    q[3] = (dp.bytes >> 24) & 255;
+    memcpy(q + 4, dp.packet, dp.bytes);
+    J->pkt_len[f] += 4 + dp.bytes;
+  }
+  T.lev = NULL;
+  return 0;
+}
+
+static void *worker(void *arg) {
+  job *J;
+  daala_enc_ctx *enc;
+  J = (job *)arg;
+  memset(&T, 0, sizeof(T));
+  T.check = J->p->check;
+  T.time_cpu = 1;
+  enc = make_encoder(J->p, J->p->pic_width, J->p->pic_height);
+  pthread_mutex_lock(&J->mu);
+  if (enc == NULL) J->failed = 1;
+  J->encoders_ready++;
+  pthread_cond_broadcast(&J->cv);
+  for (;;) {
+    int f;
+    if (J->failed) break;
+    if (J->go >= 1 && J->ctx != NULL && J->next_upload < J->batch0 + J->batch_n) {
+      int rc;
+      f = J->next_upload++;
+      pthread_mutex_unlock(&J->mu);
+      rc = upload_frame(J, enc, f);
+      pthread_mutex_lock(&J->mu);
+      if (rc != 0) J->failed = 1;
+      J->uploaded++;
+      pthread_cond_broadcast(&J->cv);
+      continue;
+    }
+    if (J->go >= 1 && J->next_encode < J->launched_upto) {
+      int rc;
+      f = J->next_encode++;
+      pthread_mutex_unlock(&J->mu);
+      rc = encode_frame(J, enc, f);
+      pthread_mutex_lock(&J->mu);
+      if (rc != 0) J->failed = 1;
+      J->encoded++;
+      pthread_cond_broadcast(&J->cv);
+      continue;
+    }
+    if (J->go >= 1 && J->next_encode >= J->nframes) break;
+    pthread_cond_wait(&J->cv, &J->mu);
+  }
+  add_stats(&J->st, &T.st);
+  pthread_cond_broadcast(&J->cv);
+  pthread_mutex_unlock(&J->mu);
+  if (enc != NULL) daala_encode_free(enc);
+  return NULL;
+}
+
+long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
+ const unsigned char *frames, const od_hip_feed_level *views, int use_device,
+ int device, unsigned char *pkt_out, long pkt_cap, od_hipenc_stats *stats) {
+  job J;
+  pthread_t *th;
+  int nw;
+  int i;
+  int cw;
+  int ch;
+  long total;
+  long used;
+  double t_setup0;
+  double t0;
+  if (p == NULL || frames == NULL || nframes < 1) return OD_HIP_EFAULT;
+  nw = p->nworkers < 1 ? 1 : p->nworkers;
+  if (nw > nframes) nw = nframes;
+  memset(&J, 0, sizeof(J));
+  J.p = p;
+  J.nframes = nframes;
+  J.frames = frames;
+  cw = (p->pic_width + 1) >> 1;
+  ch = (p->pic_height + 1) >> 1;
+  J.frame_bytes = (size_t)p->pic_width*p->pic_height + 2*(size_t)cw*ch;
+  J.views = views;
+  J.batch = p->batch > 0 && p->batch < nframes ? p->batch : nframes;
+  J.pkt = (unsigned char **)calloc(nframes, sizeof(*J.pkt));
+  J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
+  th = (pthread_t *)calloc(nw, sizeof(*th));
+  if (J.pkt == NULL || J.pkt_len == NULL || th == NULL) return OD_HIP_EFAULT;
+  pthread_mutex_init(&J.mu, NULL);
+  pthread_cond_init(&J.cv, NULL);
+  t_setup0 = now_s();
+  if (use_device && views == NULL) {
+    /* No device, no encode: the product path does not fall back to the C search. */
+    od_hip_geometry g;
+    int16_t qm[4][1024];
+    int32_t q[4][11];
+    double beta[4][11];
+    int l;
+    memset(&g, 0, sizeof(g));
+    g.pic_width = p->pic_width;
+    g.pic_height = p->pic_height;
+    /* frame size as od_state_init pads it (src/state.c:372-375) */
+    g.frame_width = (p->pic_width + (2*OD_BSIZE_MAX - 1)) & ~(2*OD_BSIZE_MAX - 1);
+    g.frame_height = (p->pic_height + (2*OD_BSIZE_MAX - 1)) & ~(2*OD_BSIZE_MAX - 1);
+    g.nplanes = 3;
+    g.xdec[1] = g.xdec[2] = 1;
+    g.nslots = J.batch;
+    J.ctx = od_hip_ctx_create(device, &g);
+    if (J.ctx == NULL) return OD_HIP_ENODEV;
+    J.feed = od_hip_enc_feed_create(J.ctx);
+    if (J.feed == NULL) {
+      od_hip_ctx_destroy(J.ctx);
+      return OD_HIP_ENODEV;
+    }
+    if (od_hipenc_level_params(p, qm, q, beta) != 0) return OD_HIP_EINVAL;
+    for (l = 0; l < 4; l++) od_hip_enc_feed_set_level(J.feed, l, qm[l], q[l], beta[l]);
+  }
+  for (i = 0; i < nw; i++) pthread_create(&th[i], NULL, worker, &J);
+  pthread_mutex_lock(&J.mu);
+  while (J.encoders_ready < nw) pthread_cond_wait(&J.cv, &J.mu);
+  t0 = now_s();
+  J.st.t_setup_s = t0 - t_setup0;
+  if (J.ctx == NULL) {
+    /* host-only modes: everything is encodable at once */
+    J.launched_upto = nframes;
+    J.go = 2;
+    pthread_cond_broadcast(&J.cv);
+  }
+  else {
+    int b0;
+    for (b0 = 0; b0 < nframes && !J.failed; b0 += J.batch) {
+      double ta;
+      double tb;
+      /* the previous batch's slots and host mirrors are reused: wait until all
+         of its frames are completely coded */
+      while (!J.failed && J.encoded < b0) pthread_cond_wait(&J.cv, &J.mu);
+      J.batch0 = b0;
+      J.batch_n = nframes - b0 < J.batch ? nframes - b0 : J.batch;
+      J.uploaded = 0;
+      J.next_upload = b0;
+      J.go = 1;
+      ta = now_s();
+      pthread_cond_broadcast(&J.cv);
+      while (!J.failed && J.uploaded < J.batch_n) pthread_cond_wait(&J.cv, &J.mu);
+      tb = now_s();
+      J.st.t_upload_s += tb - ta;
+      if (J.failed) break;
+      if (od_hip_enc_feed_run(J.feed, 0, J.batch_n) != 0) {
+        J.failed = 1;
+        break;
+      }
+      J.st.t_launch_s += now_s() - tb;
+      J.launched_upto = b0 + J.batch_n;
+      pthread_cond_broadcast(&J.cv);
+    }
+    pthread_cond_broadcast(&J.cv);
+  }
+  pthread_mutex_unlock(&J.mu);
+  for (i = 0; i < nw; i++) pthread_join(th[i], NULL);
+  J.st.t_total_s = now_s() - t0;
+  total = 0;
+  used = 0;
+  for (i = 0; i < nframes; i++) {
+    if (J.pkt[i] != NULL) {
+      total += J.pkt_len[i] - 4;
+      if (pkt_out != NULL && used + J.pkt_len[i] <= pkt_cap) {
+        memcpy(pkt_out + used, J.pkt[i], J.pkt_len[i]);
+        used += J.pkt_len[i];
+      }
+      free(J.pkt[i]);
+    }
+  }
+  if (J.feed != NULL) od_hip_enc_feed_destroy(J.feed);
+  if (J.ctx != NULL) od_hip_ctx_destroy(J.ctx);
+  free(J.pkt);
+  free(J.pkt_len);
+  free(th);
+  pthread_mutex_destroy(&J.mu);
+  pthread_cond_destroy(&J.cv);
+  if (stats != NULL) *stats = J.st;
+  return J.failed ? OD_HIP_EINVAL : total;
+}
+
+/* The padded input planes daala_encode_img_in() codes for one frame (the
+   reference's od_img_copy_pad through a throw-away context): dense
+   frame_width x frame_height luma and half-size chroma.  For tests and tools that
+   need the device's input outside od_hipenc_encode_frames. */
+int od_hipenc_pad_frame(const od_hipenc_params *p, const unsigned char *frame,
+ unsigned char *const planes[3], int *frame_width, int *frame_height) {
+  daala_enc_ctx *enc;
+  od_img img;
+  int pli;
+  if (p == NULL || frame == NULL) return OD_HIP_EFAULT;
+  enc = make_encoder(p, p->pic_width, p->pic_height);
+  if (enc == NULL) return OD_HIP_EINVAL;
+  if (frame_width != NULL) *frame_width = enc->state.frame_width;
+  if (frame_height != NULL) *frame_height = enc->state.frame_height;
+  if (planes != NULL) {
+    fill_img(&img, frame, p->pic_width, p->pic_height);
+    od_hipenc_copy_pad(enc, &img);
+    for (pli = 0; pli < 3; pli++) {
+      int w;
+      int h;
+      int y;
+      w = enc->state.frame_width >> (pli > 0);
+      h = enc->state.frame_height >> (pli > 0);
+      for (y = 0; y < h; y++) {
+        memcpy(planes[pli] + (size_t)y*w, enc->input_img[0].planes[pli].data
+         + (size_t)y*enc->input_img[0].planes[pli].ystride, w);
+      }
+    }
+  }
+  daala_encode_free(enc);
+  return 0;
+}

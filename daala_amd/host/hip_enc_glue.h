@@ -1,0 +1,68 @@
+/* hip_enc_glue.h - reference-side binding of the batched frame seam
+ * (seam 2).  The glue is C that is compiled INTO a build of the
+ * reference encoder (it includes the reference's internal headers); together with
+ * libdaala_hip.so it turns daala_encode_img_in() into "device does the state-free
+ * keyframe-luma PVQ searches for a batch of frames, N host workers run the serial
+ * entropy/RDO stage".  Plain C ABI. */
+#ifndef HIP_ENC_GLUE_H
+#define HIP_ENC_GLUE_H
+
+#include <stdint.h>
+#include "../../include/daala_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct od_hipenc_params {
+  int32_t pic_width, pic_height;   /* 4:2:0, 8 bit */
+  int32_t quant;                   /* OD_SET_QUANT */
+  int32_t complexity;              /* OD_SET_COMPLEXITY */
+  int32_t masking;                 /* OD_SET_ACTIVITY_MASKING */
+  int32_t nworkers;                /* host threads, one reference encoder context each */
+  int32_t check;                   /* OD_CHECKGPU: run the C search as well and compare */
+  int32_t batch;                   /* frames resident on the device at once (0: all) */
+} od_hipenc_params;
+
+typedef struct od_hipenc_stats {
+  int64_t dev_hits;        /* pvq_search_rdo_double calls answered from the device feed */
+  int64_t cpu_noref_luma;  /* keyframe-luma no-reference searches that ran on the host anyway */
+  int64_t cpu_other;       /* with-reference and chroma searches (serial-state dependent) */
+  int64_t g2_mismatch;     /* candidate present but host g2 != device qg*cg (libm pow, 1 ulp) */
+  int64_t lost_sync;       /* blocks whose call sequence did not match the feed */
+  int64_t check_fail;      /* check mode: device answer != C answer (must be 0) */
+  double search_cpu_s;     /* seconds inside the C pvq_search_rdo_double, all workers */
+  double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
+  double t_upload_s;       /* pad + upload phase, wall */
+  double t_launch_s;       /* enqueue of the device batch, wall */
+  double t_total_s;        /* wall: first frame in -> last packet out */
+} od_hipenc_stats;
+
+/* Encodes nframes dense 4:2:0 frames (Y then U then V, picture size) as
+ * independent keyframes (keyframe_rate 1), bit-identical to one reference encoder
+ * fed the frames in order.  Packets are written to pkt_out in frame order, each
+ * prefixed by its 4-byte little-endian length.  views: NULL, or
+ * [nframes][4] host-fabricated feed views (tests); use_device: take the feed from
+ * the HIP device `device` (fails loudly when there is none); neither: the plain
+ * reference search on nworkers threads.  Returns total packet bytes or < 0. */
+long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
+ const unsigned char *frames, const od_hip_feed_level *views, int use_device,
+ int device, unsigned char *pkt_out, long pkt_cap, od_hipenc_stats *stats);
+
+/* The per-level PVQ parameters the device needs, read from a live reference
+ * encoder context of these settings (what bench/tests pass to
+ * od_hip_enc_feed_set_level): for level l (block size 32 >> l) qm[l][1024],
+ * q[l][11], beta[l][11]. */
+int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
+ int32_t q[4][11], double beta[4][11]);
+
+/* Padded input planes of one frame exactly as daala_encode_img_in() codes them
+ * (od_img_copy_pad, src/encode.c:1728): planes[pli] receives frame_width x
+ * frame_height (chroma half size) dense bytes; planes may be NULL to query the size. */
+int od_hipenc_pad_frame(const od_hipenc_params *p, const unsigned char *frame,
+ unsigned char *const planes[3], int *frame_width, int *frame_height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

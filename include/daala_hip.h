@@ -205,6 +205,48 @@ int od_hip_pvq_nblocks(od_hip_ctx *ctx, int pli, int level);
 int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
  od_hip_pvq_band *bands, int32_t *y);
 
+/* ---------------------------------------------------------------------------
+ * 4b. Encoder feed: hands the state-free luma work of a batch of keyframes to
+ *    the host's serial stage.  For keyframe luma pvq_theta ALWAYS runs its
+ *    no-reference search (src/pvq_encoder.c:452 `is_keyframe && pli == 0`), on
+ *    inputs that depend only on the picture (the block's fDCT at that level), so
+ *    every pvq_search_rdo_double(x1, n, k, y_tmp, qcg*cg) call of :463 made by the
+ *    block-size RDO pass and by the final pass is known before the entropy coder
+ *    starts.  od_hip_enc_feed_run = od_hip_forward_pyramid + od_hip_pvq_noref_search
+ *    of the 4 luma levels for the slots, then asynchronous copies of the results
+ *    into pinned host memory on a second stream, one completion event per slot;
+ *    od_hip_enc_feed_view blocks until that slot has landed and returns host
+ *    pointers in the device's own band-major layout (no repacking):
+ *      record r = band*nblk + block (blocks in raster order of the level)
+ *      cg[r], ncand[r], qg[c*nrec + r], k[c*nrec + r], cos_dist[c*nrec + r]
+ *                                                          c = candidate 0/1
+ *      y of band b: y + 2*nblk*(off[b]-1) + (c*nblk + block)*(off[b+1]-off[b])
+ *    level l holds the (32 >> l)-sized luma blocks. */
+typedef struct od_hip_enc_feed od_hip_enc_feed;
+
+typedef struct od_hip_feed_level {
+  int32_t n;                /* block size 32 >> level */
+  int32_t nbands;
+  int32_t nblk;             /* blocks of this level in one frame */
+  int32_t nbx;              /* blocks per row */
+  int32_t off[11];          /* band boundaries in coding order */
+  int32_t pad;
+  const double *cg;         /* [nbands*nblk] companded gain of the band */
+  const int32_t *ncand;     /* [nbands*nblk] 0..2 */
+  const int32_t *qg;        /* [2][nbands*nblk] gain index i; the search's g2 = qg*cg */
+  const int32_t *k;         /* [2][nbands*nblk] */
+  const double *cos_dist;   /* [2][nbands*nblk] return value of the search */
+  const int32_t *y;         /* pulses, see above */
+} od_hip_feed_level;
+
+od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx);
+void od_hip_enc_feed_destroy(od_hip_enc_feed *feed);
+/* Per-level PVQ parameters (as od_hip_pvq_noref_search), set once per stream. */
+int od_hip_enc_feed_set_level(od_hip_enc_feed *feed, int level, const int16_t *qm,
+ const int32_t *q, const double *beta);
+int od_hip_enc_feed_run(od_hip_enc_feed *feed, int slot0, int nslots);
+int od_hip_enc_feed_view(od_hip_enc_feed *feed, int slot, od_hip_feed_level lev[4]);
+
 /* Stand-alone batched pieces for parity tests (host memory):
  * nvec band vectors of length n. */
 int od_hip_pvq_search_vectors(int n, int nvec, const double *x, const int32_t *k,

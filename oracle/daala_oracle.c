@@ -1213,3 +1213,42 @@ void orc_decode_tail(coeff *const c[3], uint8_t *const rec[3], int nplanes, int 
     orc_coeff_to_ref_buf(rec[pli], w, c[pli], w, w, h, 4);
   }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Encoder feed of one luma pyramid level in the layout of include/daala_hip.h
+   section 4b (what od_hip_enc_feed_view hands to the host workers), computed
+   with the oracle: the checker for the device feed and the stand-in producer
+   for the CPU tests of the reference-side glue (tests/ only).
+   lev: level plane (w x h, blocks of n x n); qm: the n*n QM of this block size;
+   q, beta: per band.  Arrays sized as the header says. */
+void orc_feed_level(const coeff *lev, int w, int h, int n, const int16_t *qm,
+ const int *q, const double *beta, double *cg, int32_t *ncand, int32_t *qg,
+ int32_t *k, double *cos_dist, int32_t *y) {
+  int off[11], nb = orc_band_offsets(n, off), nbx = w/n, nby = h/n, nblk = nbx*nby;
+  int bx, by, b, c;
+  size_t nrec = (size_t)nb*nblk;
+  for (by = 0; by < nby; by++) {
+    for (bx = 0; bx < nbx; bx++) {
+      coeff co[1024];
+      int blk = by*nbx + bx;
+      orc_raster_to_coding_order(co, n, lev + (size_t)(by*n)*w + bx*n, w);
+      for (b = 0; b < nb; b++) {
+        int nn = off[b + 1] - off[b], cqg[2], ck[2], nc;
+        double g, cd[2], dist[2];
+        coeff yy[2*128];
+        size_t r = (size_t)b*nblk + blk;
+        nc = orc_pvq_noref_candidates(co + off[b], nn, q[b], beta[b], qm + off[b], 1,
+         &cg[r], &g, cqg, ck, cd, dist, yy);
+        ncand[r] = nc;
+        for (c = 0; c < 2; c++) {
+          int32_t *dst = y + (size_t)2*nblk*(off[b] - 1) + ((size_t)c*nblk + blk)*nn;
+          qg[c*nrec + r] = c < nc ? cqg[c] : 0;
+          k[c*nrec + r] = c < nc ? ck[c] : 0;
+          cos_dist[c*nrec + r] = c < nc ? cd[c] : 0;
+          if (c < nc) memcpy(dst, yy + c*nn, sizeof(coeff)*nn);
+          else memset(dst, 0, sizeof(coeff)*nn);
+        }
+      }
+    }
+  }
+}
