@@ -107,6 +107,55 @@ def cpu_reference_encoder(frames, nframes):
             'what': 'full reference encoder incl. entropy coding + RDO (oracle/_ref)'}
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: the cgroup quota when there is one
+    (the GPU boxes expose 256 logical CPUs but cap a job at 16)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota)//int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def e2e_encode(frames, device, ref_mpix):
+    """END-TO-END bit-exact intra encode through the batched frame seam
+    (INTEGRATION.md seam 2, daala_amd/host/hip_enc_glue.c): the device feed answers
+    every keyframe-luma no-reference PVQ search, N host workers run the reference
+    encoder's serial entropy/RDO stage (oracle/_ref/libdaala_hipenc.so = the reference
+    compiled in the dev container + our glue).  Reported beside `value`, not as it."""
+    try:
+        import hipenc_lib as H
+    except ImportError:
+        return None
+    if not H.have_hipenc():
+        return None
+    nw = min(16, host_cpu_budget(), len(frames))
+    buf = H.pack_frames(frames, PIC_W, PIC_H)
+    prm = H.Params(PIC_W, PIC_H, 20, 7, 1, nw, 0, 0)
+    n, pk, st = H.encode(prm, buf, len(frames), use_device=1, device=device)
+    if n < 0:
+        return {'error': int(n)}
+    # bit-exactness of the first two packets against the plain reference search
+    p1 = H.Params(PIC_W, PIC_H, 20, 7, 1, 2, 0, 0)
+    n0, pk0, st0 = H.encode(p1, buf, 2)
+    mp = len(frames)*PIC_W*PIC_H/st.t_total_s/1e6
+    out = {'Mpixels_per_s': round(mp, 3), 'frames': len(frames), 'host_workers': nw,
+           'seconds': round(st.t_total_s, 3), 'packet_bytes': int(n),
+           'bit_exact_vs_reference_packets': bool(pk[:2] == pk0),
+           'searches_from_device': int(st.dev_hits),
+           'searches_on_host': int(st.cpu_other + st.cpu_noref_luma),
+           'g2_mismatch_host_recomputed': int(st.g2_mismatch), 'lost_sync': int(st.lost_sync),
+           'host_search_seconds_all_workers': round(st.search_cpu_s, 3),
+           'what': 'daala_encode_img_in/packet_out of 30 keyframes, device feed + host workers; '
+                   'time from first frame in to last packet out (context creation excluded)'}
+    if ref_mpix:
+        out['x_single_thread_reference'] = round(mp/ref_mpix, 2)
+    return out
+
+
 KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel name
     'k_forward_pyramid_luma': 'k_forward_rt<32, 4, false>',
     'k_forward_pyramid_chroma': 'k_forward_rt<16, 3, false>',
@@ -306,6 +355,10 @@ def main():
             refenc = cpu_reference_encoder(frames, 3)
             if refenc:
                 line['cpu_reference_encoder'] = refenc
+            ctx.close()          # free the HBM slots before the end-to-end run
+            e2e = e2e_encode(frames, local_rank, refenc['value'] if refenc else None)
+            if e2e:
+                line['e2e_encode'] = e2e
         if args.skip_pvq:
             line['INVALID'] = 'profiling run with --skip-pvq'
         print(json.dumps(line))

@@ -34,6 +34,14 @@ class PvqBand(ctypes.Structure):
                 ('ncand', ctypes.c_int32), ('pad', ctypes.c_int32)]
 
 
+class FeedLevel(ctypes.Structure):
+    """od_hip_feed_level (include/daala_hip.h section 4b)."""
+    _fields_ = [('n', ctypes.c_int32), ('nbands', ctypes.c_int32), ('nblk', ctypes.c_int32),
+                ('nbx', ctypes.c_int32), ('off', ctypes.c_int32*11), ('pad', ctypes.c_int32),
+                ('cg', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P), ('cos_dist', F64P),
+                ('y', I32P)]
+
+
 PVQ_BAND_DTYPE = np.dtype([('cg', 'f8'), ('g', 'f8'), ('cos_dist', 'f8', 2), ('dist', 'f8', 2),
                            ('qg', 'i4', 2), ('k', 'i4', 2), ('ncand', 'i4'), ('pad', 'i4')])
 
@@ -215,6 +223,9 @@ class DaalaHip(object):
             raise HipError('od_hip_ctx_create failed: %s' % self.lib.od_hip_last_error().decode())
 
     def close(self):
+        if getattr(self, 'feed', None):
+            self.lib.od_hip_enc_feed_destroy(self.feed)
+            self.feed = None
         if getattr(self, 'ctx', None):
             self.lib.od_hip_ctx_destroy(self.ctx)
             self.ctx = None
@@ -293,6 +304,47 @@ class DaalaHip(object):
         _chk(self.lib.od_hip_pvq_download(self.ctx, slot, pli, level,
                                           bands.ctypes.data_as(ctypes.c_void_p), _p32(y)))
         return bands, y
+
+    # -- encoder feed (header section 4b) -----------------------------------------
+    def enc_feed_create(self, qm, q, beta):
+        """qm [4][1024] int16, q [4][11] int32, beta [4][11] f64: per luma level."""
+        lib = self.lib
+        lib.od_hip_enc_feed_create.restype = ctypes.c_void_p
+        lib.od_hip_enc_feed_create.argtypes = [ctypes.c_void_p]
+        lib.od_hip_enc_feed_destroy.argtypes = [ctypes.c_void_p]
+        lib.od_hip_enc_feed_set_level.argtypes = [ctypes.c_void_p, c_int, I16P, I32P, F64P]
+        lib.od_hip_enc_feed_run.argtypes = [ctypes.c_void_p, c_int, c_int]
+        lib.od_hip_enc_feed_view.argtypes = [ctypes.c_void_p, c_int, ctypes.POINTER(FeedLevel)]
+        self.feed = lib.od_hip_enc_feed_create(self.ctx)
+        if not self.feed:
+            raise HipError('od_hip_enc_feed_create: %s' % lib.od_hip_last_error().decode())
+        for l in range(4):
+            qm_l = np.ascontiguousarray(qm[l], dtype=np.int16)
+            q_l = np.ascontiguousarray(q[l], dtype=np.int32)
+            b_l = np.ascontiguousarray(beta[l], dtype=np.float64)
+            _chk(lib.od_hip_enc_feed_set_level(self.feed, l, qm_l.ctypes.data_as(I16P), _p32(q_l),
+                                               b_l.ctypes.data_as(F64P)))
+
+    def enc_feed_run(self, slot0=0, nslots=None):
+        _chk(self.lib.od_hip_enc_feed_run(self.feed, slot0, nslots or self.nslots - slot0))
+
+    def enc_feed_view(self, slot):
+        """Host arrays (copies) of one slot: list of 4 dicts cg/ncand/qg/k/cos_dist/y."""
+        lev = (FeedLevel*4)()
+        _chk(self.lib.od_hip_enc_feed_view(self.feed, slot, lev))
+        out = []
+        for v in lev:
+            nrec = v.nbands*v.nblk
+            ny = 2*v.nblk*(min(v.n*v.n, 512) - 1)
+            out.append({'n': v.n, 'nbands': v.nbands, 'nblk': v.nblk, 'nbx': v.nbx,
+                        'off': list(v.off)[:v.nbands + 1],
+                        'cg': np.ctypeslib.as_array(v.cg, (nrec,)).copy(),
+                        'ncand': np.ctypeslib.as_array(v.ncand, (nrec,)).copy(),
+                        'qg': np.ctypeslib.as_array(v.qg, (2*nrec,)).copy(),
+                        'k': np.ctypeslib.as_array(v.k, (2*nrec,)).copy(),
+                        'cos_dist': np.ctypeslib.as_array(v.cos_dist, (2*nrec,)).copy(),
+                        'y': np.ctypeslib.as_array(v.y, (ny,)).copy()})
+        return out
 
     def set_decode_info(self, slot, dering_flags, bskip):
         """dering_flags: [nvsb, nhsb] u8; bskip: per plane [fh/4, fw/4] u8 (dense)."""

@@ -57,6 +57,7 @@ typedef struct glue_tls {
   int cand;
   int check;
   int time_cpu;
+  int pli;                        /* plane of the block being coded */
   od_hipenc_stats st;
 } glue_tls;
 
@@ -130,9 +131,12 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
   if (from_feed) T.st.cpu_noref_luma++;
   else T.st.cpu_other++;
   if (T.time_cpu) {
+    double dt;
     t0 = now_s();
     r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
-    T.st.search_cpu_s += now_s() - t0;
+    dt = now_s() - t0;
+    T.st.search_cpu_s += dt;
+    T.st.search_class_s[(T.pli != 0)*2 + !is_noref_size(n)] += dt;
     return r;
   }
   return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
@@ -143,6 +147,7 @@ int od_pvq_encode(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out
  int q_scaling, int bx, int by, const int16_t *qm, const int16_t *qm_inv) {
   int ret;
   T.active = 0;
+  T.pli = pli;
   if (T.lev != NULL && is_keyframe && pli == 0 && bs >= 0 && bs < 4) {
     const od_hip_feed_level *L;
     /* bx, by arrive in 4x4 units (src/encode.c:1101-1102) */
@@ -295,6 +300,7 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->lost_sync += b->lost_sync;
   a->check_fail += b->check_fail;
   a->search_cpu_s += b->search_cpu_s;
+  for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
 static int upload_frame(job *J, daala_enc_ctx *enc, int f) {

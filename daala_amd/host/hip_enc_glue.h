@@ -32,6 +32,7 @@ typedef struct od_hipenc_stats {
   int64_t lost_sync;       /* blocks whose call sequence did not match the feed */
   int64_t check_fail;      /* check mode: device answer != C answer (must be 0) */
   double search_cpu_s;     /* seconds inside the C pvq_search_rdo_double, all workers */
+  double search_class_s[4];/* ... split: luma no-ref, luma with-ref, chroma no-ref, chroma with-ref */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* enqueue of the device batch, wall */

@@ -22,12 +22,14 @@ class Stats(ctypes.Structure):
     _fields_ = [('dev_hits', ctypes.c_int64), ('cpu_noref_luma', ctypes.c_int64),
                 ('cpu_other', ctypes.c_int64), ('g2_mismatch', ctypes.c_int64),
                 ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
-                ('search_cpu_s', ctypes.c_double), ('t_setup_s', ctypes.c_double),
+                ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
+                ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_total_s', ctypes.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k == 'search_class_s' else getattr(self, k))
+                for k, _ in self._fields_}
 
 
 class FeedLevel(ctypes.Structure):

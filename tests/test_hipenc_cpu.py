@@ -1,0 +1,80 @@
+"""CPU tests of the reference-side glue (daala_amd/host/hip_enc_glue.c) with the
+oracle standing in for the device feed: the call-sequence logic that maps
+pvq_search_rdo_double calls to feed candidates, the multi-worker driver and the
+frame-index priming must reproduce the sequential reference encoder byte for byte."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from testlib import synth_plane, ref, pu8
+import hipenc_lib as H
+
+pytestmark = pytest.mark.skipif(not H.have_hipenc(), reason='oracle/_ref/libdaala_hipenc.so not built')
+
+
+def setup_frames(w, h, seeds):
+    fr = [[synth_plane(w, h, s), synth_plane(w//2, h//2, s, 1), synth_plane(w//2, h//2, s + 1, 1)]
+          for s in seeds]
+    return H.pack_frames(fr, w, h)
+
+
+def reference_packets(buf, w, h, nf, masking):
+    lib = ref('enc_probe')
+    lib.probe_encode_frames.restype = ctypes.c_long
+    out = np.zeros(1 << 22, np.uint8)
+    fnv, sec = ctypes.c_uint(), ctypes.c_double()
+    n = lib.probe_encode_frames(w, h, nf, 20, 7, masking, 1, pu8(buf), ctypes.byref(fnv),
+                                ctypes.byref(sec), pu8(out), out.size)
+    assert n > 0
+    return H.split_packets(out, nf)
+
+
+def test_workers_reproduce_sequential_stream():
+    """12 frames on 3 independent contexts == one context fed in order (covers the
+    golden-frame flag at frame 10)."""
+    w, h, nf = 64, 64, 12
+    buf = setup_frames(w, h, range(1, nf + 1))
+    want = reference_packets(buf, w, h, nf, 1)
+    prm = H.Params(w, h, 20, 7, 1, 3, 0, 0)
+    n, got, st = H.encode(prm, buf, nf)
+    assert got == want and st.dev_hits == 0
+
+
+@pytest.mark.parametrize('masking', [1, 0])
+def test_oracle_feed_gives_identical_packets(masking):
+    w, h, nf = 352, 288, 2
+    buf = setup_frames(w, h, [3, 4])
+    want = reference_packets(buf, w, h, nf, masking)
+    prm = H.Params(w, h, 20, 7, masking, 2, 1, 0)
+    lp = H.level_params(prm)
+    fb = w*h*3//2
+    views = [H.OracleFeed(prm, H.pad_frame(prm, buf[f*fb:(f + 1)*fb])[0], lp) for f in range(nf)]
+    n, got, st = H.encode(prm, buf, nf, views)
+    assert got == want
+    assert st.check_fail == 0 and st.lost_sync == 0 and st.g2_mismatch == 0
+    assert st.dev_hits > 50000
+
+
+def test_corrupt_feed_is_detected_not_trusted():
+    """A feed whose K does not match the call falls out of step: the glue must run the
+    C search for that block (packets stay identical) and count it."""
+    w, h = 352, 288
+    buf = setup_frames(w, h, [3])
+    want = reference_packets(buf, w, h, 1, 0)
+    prm = H.Params(w, h, 20, 7, 0, 1, 0, 0)
+    view = H.OracleFeed(prm, H.pad_frame(prm, buf)[0])
+    view.keep[1]['k'][::7] += 1
+    n, got, st = H.encode(prm, buf, 1, [view])
+    assert got == want and st.lost_sync > 0
+
+
+def test_no_device_is_loud():
+    import daala_amd.binding as b
+    if b.load().od_hip_device_count() > 0:
+        pytest.skip('a HIP device is present')
+    w, h = 64, 64
+    buf = setup_frames(w, h, [1])
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
+    n, got, st = H.encode(prm, buf, 1, use_device=1)
+    assert n == -30 and got is None

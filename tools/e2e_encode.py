@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""End-to-end intra encode of BASELINE configs[1] through the batched frame seam:
+30 synthetic 1080p 4:2:0 frames, device feed + N host workers running the reference
+encoder's serial stage (oracle/_ref/libdaala_hipenc.so).  Prints one JSON object.
+  python tools/e2e_encode.py [--frames 30] [--workers 16] [--ref-frames 2] [--no-verify]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=30)
+    ap.add_argument('--workers', type=int, default=16)
+    ap.add_argument('--ref-frames', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--masking', type=int, default=1)
+    ap.add_argument('--host-only', action='store_true', help='same driver, plain C search (no device)')
+    ap.add_argument('--verify', type=int, default=2, help='frames compared with the sequential reference')
+    args = ap.parse_args()
+    import hipenc_lib as H
+    from bench import make_frames, PIC_W, PIC_H
+    frames = make_frames(args.frames, seed0=1)
+    buf = H.pack_frames(frames, PIC_W, PIC_H)
+    res = {'frames': args.frames, 'workers': args.workers, 'pic': [PIC_W, PIC_H]}
+    px = PIC_W*PIC_H
+    # single-thread reference on the first frames (same driver, 1 worker, plain C search)
+    p1 = H.Params(PIC_W, PIC_H, 20, 7, args.masking, 1, 0, 0)
+    n0, pk0, st0 = H.encode(p1, buf, args.ref_frames)
+    res['reference_1thread'] = {'Mpixels_per_s': round(args.ref_frames*px/st0.t_total_s/1e6, 3),
+                                'frames': args.ref_frames, 's': round(st0.t_total_s, 3),
+                                'search_share': round(st0.search_cpu_s/st0.t_total_s, 3)}
+    prm = H.Params(PIC_W, PIC_H, 20, 7, args.masking, args.workers, 0, args.batch)
+    t0 = time.perf_counter()
+    n, pk, st = H.encode(prm, buf, args.frames, use_device=0 if args.host_only else 1)
+    wall = time.perf_counter() - t0
+    if n < 0:
+        raise SystemExit('encode failed: %d' % n)
+    res['hip'] = {'Mpixels_per_s': round(args.frames*px/st.t_total_s/1e6, 3),
+                  'packet_bytes': int(n), 'wall_incl_setup_s': round(wall, 3), **{
+                      k: (round(v, 4) if isinstance(v, float) else [round(x, 3) for x in v] if isinstance(v, list) else v)
+                      for k, v in st.as_dict().items()}}
+    res['bit_exact_vs_reference'] = pk[:args.ref_frames] == pk0
+    res['speedup_vs_1thread'] = round(res['hip']['Mpixels_per_s']/res['reference_1thread']['Mpixels_per_s'], 2)
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()
