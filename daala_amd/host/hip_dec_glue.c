@@ -1,0 +1,360 @@
+/* hip_dec_glue.c - reference-side binding of the batched frame seam, decoder
+ * (INTEGRATION.md seam 2; header hip_enc_glue.h).
+ *
+ * Compiled into oracle/_ref/libdaala_hipenc.so next to the reference decoder.  The
+ * decoder's symbol parse (serial range decoder + PVQ synthesis into dtmp) stays the
+ * reference's C code; its whole pixel-domain stage of a keyframe -
+ *   idct_2d per block           src/decode.c:637  (vtable, src/state.h:106)
+ *   od_postfilter_split         src/decode.c:864  (src/filter.c:1512)
+ *   od_apply_postfilter_frame_sbs src/decode.c:1037 (src/filter.c:1588)
+ *   od_dering per flagged SB    src/decode.c:1117 (src/filter.c:1835)
+ *   od_smooth_recursive         src/decode.c:1146 (src/filter.c:2010)
+ *   od_coeff_to_ref_plane       src/decode.c:1154 (src/state.c:1320)
+ * - is replaced by ONE device pass per frame (od_hip_decode_tail) issued when the
+ * decoder reaches od_coeff_to_ref_plane for plane 0: by then dtmp holds every
+ * dequantised coefficient, bsize/bskip/dering_flags are final.  The five extern
+ * functions above are bound here (the build renames the reference's definitions to
+ * *_cpu with objcopy --redefine-sym, no source is touched); outside a device decode
+ * (encoder threads, inter/lossless frames) they forward to the reference's code.
+ * No reference text lives in this file. */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "decint.h"
+#include "filter.h"
+#include "state.h"
+
+#include "hip_enc_glue.h"
+
+/* the reference's definitions, renamed by the build (oracle/Makefile) */
+void od_postfilter_split_cpu(od_coeff *c0, int stride, int bs, int f, int q,
+ unsigned char *skip, int skip_stride, int hfilter, int vfilter);
+void od_apply_postfilter_frame_sbs_cpu(od_coeff *c0, int stride, int nhsb, int nvsb,
+ int xdec, int ydec, int q, unsigned char *skip, int skip_stride);
+void od_dering_cpu(od_state *state, int16_t *y, int ystride, int16_t *x, int xstride,
+ int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
+ int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
+ int skip_stride);
+void od_smooth_recursive_cpu(od_coeff *c, unsigned char *bsize, int bstride, int bx,
+ int by, int bsi, int w, int xdec, int ydec, int min_bs, int quantizer, int pli);
+void od_coeff_to_ref_plane_cpu(od_state *state, od_img *dst, int pli, od_coeff *src,
+ int lossless_p);
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9*ts.tv_nsec;
+}
+
+typedef struct dec_tls {
+  od_dec_ctx *dec;          /* decoder whose packet this thread is decoding */
+  od_hip_ctx *ctx;          /* one-slot device context of this worker, or NULL */
+  od_dct_func_2d idct_cpu[OD_NBSIZES];
+  unsigned char *rec[3];    /* device output of the current frame */
+  long idct_skipped;
+  int failed;
+  double t_device;
+} dec_tls;
+
+static __thread dec_tls D;
+
+/* Device decode applies to DCT keyframes only (what the stage was verified for):
+   frame type and quantizers are known before the first block is parsed
+   (src/decode.c:1195, :989-993). */
+static int on_device(void) {
+  return D.ctx != NULL && D.dec != NULL && D.dec->state.frame_type == OD_I_FRAME
+   && D.dec->state.quantizer[0] > 0;
+}
+
+#define IDCT_HOOK(name, bs) \
+  static void name(od_coeff *x, int xstride, const od_coeff *y, int ystride) { \
+    if (on_device()) { \
+      D.idct_skipped++; \
+      return; \
+    } \
+    (*D.idct_cpu[bs])(x, xstride, y, ystride); \
+  }
+IDCT_HOOK(hook_idct4, 0)
+IDCT_HOOK(hook_idct8, 1)
+IDCT_HOOK(hook_idct16, 2)
+IDCT_HOOK(hook_idct32, 3)
+
+void od_postfilter_split(od_coeff *c0, int stride, int bs, int f, int q,
+ unsigned char *skip, int skip_stride, int hfilter, int vfilter) {
+  if (on_device()) return;
+  od_postfilter_split_cpu(c0, stride, bs, f, q, skip, skip_stride, hfilter, vfilter);
+}
+
+void od_apply_postfilter_frame_sbs(od_coeff *c0, int stride, int nhsb, int nvsb,
+ int xdec, int ydec, int q, unsigned char *skip, int skip_stride) {
+  if (on_device()) return;
+  od_apply_postfilter_frame_sbs_cpu(c0, stride, nhsb, nvsb, xdec, ydec, q, skip,
+   skip_stride);
+}
+
+void od_dering(od_state *state, int16_t *y, int ystride, int16_t *x, int xstride,
+ int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
+ int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
+ int skip_stride) {
+  if (on_device()) return;
+  od_dering_cpu(state, y, ystride, x, xstride, ln, sbx, sby, nhsb, nvsb, q, xdec, dir,
+   pli, bskip, skip_stride);
+}
+
+void od_smooth_recursive(od_coeff *c, unsigned char *bsize, int bstride, int bx,
+ int by, int bsi, int w, int xdec, int ydec, int min_bs, int quantizer, int pli) {
+  if (on_device()) return;
+  od_smooth_recursive_cpu(c, bsize, bstride, bx, by, bsi, w, xdec, ydec, min_bs,
+   quantizer, pli);
+}
+
+static int device_frame(od_state *state) {
+  const unsigned char *bskip[3];
+  int32_t thr[3];
+  int32_t quant[3];
+  int pli;
+  int nplanes;
+  double t0;
+  t0 = now_s();
+  nplanes = state->info.nplanes;
+  if (od_hip_set_bsize(D.ctx, 0, state->bsize, state->bstride) != 0) return -1;
+  for (pli = 0; pli < nplanes; pli++) {
+    if (od_hip_upload_coeffs(D.ctx, 0, pli, state->dtmp[pli]) != 0) return -2;
+    bskip[pli] = state->bskip[pli];
+    quant[pli] = state->quantizer[pli];
+    /* od_dering's threshold (src/filter.c:1876), host libm as in the reference */
+    thr[pli] = (int32_t)(1.0*pow(state->quantizer[pli], 0.84182));
+  }
+  if (od_hip_set_decode_info(D.ctx, 0, state->dering_flags, bskip,
+   state->skip_stride) != 0) return -3;
+  if (od_hip_decode_tail(D.ctx, 0, 1, thr, quant, 1) != 0) return -4;
+  for (pli = 0; pli < nplanes; pli++) {
+    if (od_hip_download_recon(D.ctx, 0, pli, D.rec[pli]) != 0) return -5;
+  }
+  D.t_device += now_s() - t0;
+  return 0;
+}
+
+void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
+ int lossless_p) {
+  od_img_plane *ip;
+  int w;
+  int h;
+  int y;
+  if (!on_device() || lossless_p) {
+    od_coeff_to_ref_plane_cpu(state, dst, pli, src, lossless_p);
+    return;
+  }
+  if (pli == 0) {
+    if (D.idct_skipped == 0 || device_frame(state) != 0) {
+      /* A frame that never reached the DCT path (Haar) or a device failure: there
+         is no C fallback for a half-skipped frame, fail loudly. */
+      fprintf(stderr, "hip_dec_glue: device decode failed: %s\n", od_hip_last_error());
+      D.failed = 1;
+      abort();
+    }
+    D.idct_skipped = 0;
+  }
+  ip = dst->planes + pli;
+  w = state->frame_width >> ip->xdec;
+  h = state->frame_height >> ip->ydec;
+  for (y = 0; y < h; y++) {
+    memcpy(ip->data + (size_t)y*ip->ystride, D.rec[pli] + (size_t)y*w, w);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+typedef struct djob {
+  const od_hipenc_params *p;
+  int nframes;
+  const unsigned char *hdr;
+  long hdr_bytes;
+  const unsigned char **pkt;     /* per frame: pointer to the packet bytes */
+  long *pkt_len;
+  unsigned char *out;
+  size_t frame_bytes;
+  int use_device;
+  int device;
+  pthread_mutex_t mu;
+  int next;
+  int failed;
+  double t_device;
+  double t0;
+  double t_end;
+  int ready;
+  pthread_cond_t cv;
+  int go;
+} djob;
+
+static daala_dec_ctx *make_decoder(const djob *J) {
+  daala_info di;
+  daala_comment dc;
+  daala_setup_info *dsi;
+  daala_dec_ctx *dec;
+  long o;
+  dsi = NULL;
+  daala_info_init(&di);
+  daala_comment_init(&dc);
+  o = 0;
+  while (o + 4 <= J->hdr_bytes) {
+    daala_packet dp;
+    long n;
+    n = J->hdr[o] | J->hdr[o + 1] << 8 | J->hdr[o + 2] << 16 | (long)J->hdr[o + 3] << 24;
+    memset(&dp, 0, sizeof(dp));
+    dp.packet = (unsigned char *)J->hdr + o + 4;
+    dp.bytes = n;
+    dp.b_o_s = o == 0;
+    if (daala_decode_header_in(&di, &dc, &dsi, &dp) < 0) return NULL;
+    o += 4 + n;
+  }
+  dec = daala_decode_create(&di, dsi);
+  daala_setup_free(dsi);
+  daala_comment_clear(&dc);
+  return dec;
+}
+
+static void *dworker(void *arg) {
+  djob *J;
+  daala_dec_ctx *dec;
+  od_state *st;
+  int pli;
+  int i;
+  static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_idct4, hook_idct8, hook_idct16,
+   hook_idct32};
+  J = (djob *)arg;
+  memset(&D, 0, sizeof(D));
+  dec = make_decoder(J);
+  st = dec != NULL ? &((od_dec_ctx *)dec)->state : NULL;
+  if (dec != NULL && J->use_device) {
+    od_hip_geometry g;
+    memset(&g, 0, sizeof(g));
+    g.pic_width = st->info.pic_width;
+    g.pic_height = st->info.pic_height;
+    g.frame_width = st->frame_width;
+    g.frame_height = st->frame_height;
+    g.nplanes = 3;
+    g.xdec[1] = g.xdec[2] = 1;
+    g.nslots = 1;
+    D.ctx = od_hip_ctx_create(J->device, &g);
+    for (pli = 0; pli < 3; pli++) {
+      D.rec[pli] = (unsigned char *)malloc((size_t)(st->frame_width >> (pli > 0))
+       *(st->frame_height >> (pli > 0)));
+    }
+    for (i = 0; i < OD_NBSIZES; i++) {
+      D.idct_cpu[i] = st->opt_vtbl.idct_2d[i];
+      st->opt_vtbl.idct_2d[i] = hooks[i];
+    }
+  }
+  pthread_mutex_lock(&J->mu);
+  if (dec == NULL || (J->use_device && D.ctx == NULL)) J->failed = 1;
+  J->ready++;
+  pthread_cond_broadcast(&J->cv);
+  while (!J->go) pthread_cond_wait(&J->cv, &J->mu);
+  while (!J->failed && J->next < J->nframes) {
+    daala_packet dp;
+    od_img img;
+    od_img *o;
+    int f;
+    int rc;
+    f = J->next++;
+    pthread_mutex_unlock(&J->mu);
+    memset(&dp, 0, sizeof(dp));
+    dp.packet = (unsigned char *)J->pkt[f];
+    dp.bytes = J->pkt_len[f];
+    D.dec = (od_dec_ctx *)dec;
+    rc = daala_decode_packet_in(dec, &dp);
+    D.dec = NULL;
+    if (rc >= 0) {
+      /* this frame's picture (src/decode.c:1268); img_out only drains the queue */
+      o = ((od_dec_ctx *)dec)->output_img + ((od_dec_ctx *)dec)->curr_dec_frame;
+      unsigned char *dst = J->out + J->frame_bytes*f;
+      for (pli = 0; pli < 3; pli++) {
+        int pw;
+        int ph;
+        int y;
+        pw = (J->p->pic_width + (pli > 0)) >> (pli > 0);
+        ph = (J->p->pic_height + (pli > 0)) >> (pli > 0);
+        for (y = 0; y < ph; y++) {
+          memcpy(dst, o->planes[pli].data + (size_t)y*o->planes[pli].ystride, pw);
+          dst += pw;
+        }
+      }
+      while (daala_decode_img_out(dec, &img) > 0);
+    }
+    pthread_mutex_lock(&J->mu);
+    if (rc < 0) J->failed = 1;
+  }
+  J->t_device += D.t_device;
+  {
+    double t;
+    t = now_s();
+    if (t > J->t_end) J->t_end = t;
+  }
+  pthread_mutex_unlock(&J->mu);
+  if (D.ctx != NULL) od_hip_ctx_destroy(D.ctx);
+  for (pli = 0; pli < 3; pli++) free(D.rec[pli]);
+  if (dec != NULL) daala_decode_free(dec);
+  return NULL;
+}
+
+long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr,
+ long hdr_bytes, int nframes, const unsigned char *pkts, long pkt_bytes,
+ int use_device, int device, unsigned char *frames_out, double *seconds,
+ double *device_seconds) {
+  djob J;
+  pthread_t *th;
+  int nw;
+  int i;
+  long o;
+  if (p == NULL || hdr == NULL || pkts == NULL || frames_out == NULL || nframes < 1) {
+    return OD_HIP_EFAULT;
+  }
+  if (use_device && od_hip_device_count() <= device) return OD_HIP_ENODEV;
+  memset(&J, 0, sizeof(J));
+  J.p = p;
+  J.nframes = nframes;
+  J.hdr = hdr;
+  J.hdr_bytes = hdr_bytes;
+  J.out = frames_out;
+  J.frame_bytes = (size_t)p->pic_width*p->pic_height
+   + 2*(size_t)((p->pic_width + 1) >> 1)*((p->pic_height + 1) >> 1);
+  J.use_device = use_device;
+  J.device = device;
+  J.pkt = (const unsigned char **)calloc(nframes, sizeof(*J.pkt));
+  J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
+  o = 0;
+  for (i = 0; i < nframes; i++) {
+    long n;
+    if (o + 4 > pkt_bytes) return OD_HIP_EINVAL;
+    n = pkts[o] | pkts[o + 1] << 8 | pkts[o + 2] << 16 | (long)pkts[o + 3] << 24;
+    J.pkt[i] = pkts + o + 4;
+    J.pkt_len[i] = n;
+    o += 4 + n;
+  }
+  nw = p->nworkers < 1 ? 1 : p->nworkers;
+  if (nw > nframes) nw = nframes;
+  th = (pthread_t *)calloc(nw, sizeof(*th));
+  pthread_mutex_init(&J.mu, NULL);
+  pthread_cond_init(&J.cv, NULL);
+  for (i = 0; i < nw; i++) pthread_create(&th[i], NULL, dworker, &J);
+  pthread_mutex_lock(&J.mu);
+  while (J.ready < nw) pthread_cond_wait(&J.cv, &J.mu);
+  J.t0 = now_s();
+  J.go = 1;
+  pthread_cond_broadcast(&J.cv);
+  pthread_mutex_unlock(&J.mu);
+  for (i = 0; i < nw; i++) pthread_join(th[i], NULL);
+  if (seconds != NULL) *seconds = J.t_end - J.t0;
+  if (device_seconds != NULL) *device_seconds = J.t_device;
+  free(J.pkt);
+  free(J.pkt_len);
+  free(th);
+  pthread_mutex_destroy(&J.mu);
+  pthread_cond_destroy(&J.cv);
+  return J.failed ? OD_HIP_EINVAL : nframes;
+}

@@ -563,3 +563,32 @@ int od_hipenc_pad_frame(const od_hipenc_params *p, const unsigned char *frame,
   daala_encode_free(enc);
   return 0;
 }
+
+/* The stream's three header packets (daala_encode_flush_header), 4-byte length
+   prefixed like the video packets: what a decoder needs before od_hipdec_decode_frames. */
+long od_hipenc_headers(const od_hipenc_params *p, unsigned char *out, long cap) {
+  daala_enc_ctx *enc;
+  daala_comment dc;
+  daala_packet dp;
+  long used;
+  if (p == NULL || out == NULL) return OD_HIP_EFAULT;
+  enc = make_encoder(p, p->pic_width, p->pic_height);
+  if (enc == NULL) return OD_HIP_EINVAL;
+  daala_comment_init(&dc);
+  used = 0;
+  while (daala_encode_flush_header(enc, &dc, &dp) > 0) {
+    if (used + 4 + dp.bytes > cap) {
+      used = OD_HIP_EINVAL;
+      break;
+    }
+    out[used] = dp.bytes & 255;
+    out[used + 1] = (dp.bytes >> 8) & 255;
+    out[used + 2] = (dp.bytes >> 16) & 255;
+    out[used + 3] = (dp.bytes >> 24) & 255;
+    memcpy(out + used + 4, dp.packet, dp.bytes);
+    used += 4 + dp.bytes;
+  }
+  daala_comment_clear(&dc);
+  daala_encode_free(enc);
+  return used;
+}

@@ -63,6 +63,22 @@ int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
 int od_hipenc_pad_frame(const od_hipenc_params *p, const unsigned char *frame,
  unsigned char *const planes[3], int *frame_width, int *frame_height);
 
+/* Header packets of a stream with these settings (length-prefixed, 3 packets). */
+long od_hipenc_headers(const od_hipenc_params *p, unsigned char *out, long cap);
+
+/* Decoder side of the seam (hip_dec_glue.c): decodes nframes keyframe packets
+ * (length-prefixed, as written by od_hipenc_encode_frames) on p->nworkers threads,
+ * one reference decoder context each.  use_device: the symbol parse stays the
+ * reference's C code, the whole pixel-domain stage of every frame (iDCT, split and
+ * frame post-filters, deringing, bilinear smoothing, 8-bit clamp) is one
+ * od_hip_decode_tail pass per frame; otherwise the plain reference decoder.
+ * frames_out: nframes dense 4:2:0 pictures.  Returns nframes or < 0; fails with
+ * OD_HIP_ENODEV when use_device is set and there is no device. */
+long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr,
+ long hdr_bytes, int nframes, const unsigned char *pkts, long pkt_bytes,
+ int use_device, int device, unsigned char *frames_out, double *seconds,
+ double *device_seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,3 +158,34 @@ def encode(prm, frames_buf, nframes, views=None, use_device=0, device=0):
     if n < 0:
         return n, None, st
     return n, split_packets(out, nframes), st
+
+
+def headers(prm):
+    lib = hipenc()
+    lib.od_hipenc_headers.restype = ctypes.c_long
+    lib.od_hipenc_headers.argtypes = [ctypes.POINTER(Params), U8P, ctypes.c_long]
+    out = np.zeros(1 << 16, np.uint8)
+    n = lib.od_hipenc_headers(ctypes.byref(prm), pu8(out), out.size)
+    assert n > 0, n
+    return out[:n].copy()
+
+
+def join_packets(packets):
+    return np.frombuffer(b''.join(len(p).to_bytes(4, 'little') + p for p in packets), np.uint8).copy()
+
+
+def decode(prm, hdr, packets, use_device=0, device=0):
+    """Decodes keyframe packets -> (frames [nframes, frame_bytes] u8, seconds, device_seconds)."""
+    lib = hipenc()
+    lib.od_hipdec_decode_frames.restype = ctypes.c_long
+    lib.od_hipdec_decode_frames.argtypes = [ctypes.POINTER(Params), U8P, ctypes.c_long, c_int, U8P,
+                                            ctypes.c_long, c_int, c_int, U8P, F64P, F64P]
+    w, h = prm.pic_width, prm.pic_height
+    fb = w*h + 2*((w + 1)//2)*((h + 1)//2)
+    buf = join_packets(packets)
+    out = np.zeros((len(packets), fb), np.uint8)
+    sec, dsec = ctypes.c_double(), ctypes.c_double()
+    n = lib.od_hipdec_decode_frames(ctypes.byref(prm), pu8(hdr), hdr.size, len(packets), pu8(buf),
+                                    buf.size, use_device, device, pu8(out), ctypes.byref(sec),
+                                    ctypes.byref(dsec))
+    return n, out, sec.value, dsec.value

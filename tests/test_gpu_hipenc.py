@@ -99,3 +99,34 @@ def test_hip_encoder_packets_identical_1080p():
     print('1080p x%d: reference %.2fs, device feed %.2fs; hits %d, host searches %d, g2 %d'
           % (nf, st0.t_total_s, st.t_total_s, st.dev_hits, st.cpu_other + st.cpu_noref_luma,
              st.g2_mismatch))
+
+
+@pytest.mark.parametrize('w,h,quant,masking', [(352, 288, 20, 1), (176, 112, 8, 0), (416, 240, 35, 1)])
+def test_hip_decoder_pictures_identical(w, h, quant, masking):
+    """daala_decode_packet_in with the pixel-domain stage on the device == the plain
+    reference decoder, every output picture byte for byte (3 workers)."""
+    nf = 4
+    buf = H.pack_frames(frames_of(w, h, [11, 12, 13, 14]), w, h)
+    prm = H.Params(w, h, quant, 7, masking, 3, 0, 0)
+    n, pk, st = H.encode(prm, buf, nf)
+    assert n > 0
+    hdr = H.headers(prm)
+    n0, want, s0, _ = H.decode(prm, hdr, pk, use_device=0)
+    n1, got, s1, ds = H.decode(prm, hdr, pk, use_device=1)
+    assert n0 == nf and n1 == nf
+    assert np.array_equal(got, want)
+    assert ds > 0
+
+
+def test_hip_decoder_1080p():
+    w, h, nf = 1920, 1080, 4
+    buf = H.pack_frames(frames_of(w, h, [21, 22, 23, 24]), w, h)
+    prm = H.Params(w, h, 20, 7, 1, 4, 0, 0)
+    n, pk, st = H.encode(prm, buf, nf, use_device=1)
+    assert n > 0
+    hdr = H.headers(prm)
+    n0, want, s0, _ = H.decode(prm, hdr, pk, use_device=0)
+    n1, got, s1, ds = H.decode(prm, hdr, pk, use_device=1)
+    assert np.array_equal(got, want)
+    print('1080p decode x%d, 4 workers: reference %.3fs, device tail %.3fs (device calls %.3fs)'
+          % (nf, s0, s1, ds))

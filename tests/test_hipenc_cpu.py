@@ -78,3 +78,37 @@ def test_no_device_is_loud():
     prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
     n, got, st = H.encode(prm, buf, 1, use_device=1)
     assert n == -30 and got is None
+
+
+def test_decoder_driver_host_path_matches_encoder_reconstruction():
+    """od_hipdec_decode_frames without a device is the plain reference decoder on N
+    workers: its last picture must equal the encoder's own reconstruction (the
+    invariant of the reference's OD_ENCODER_CHECK), and the pixel-stage entry points
+    bound by hip_dec_glue.c must forward to the reference's code on encoder threads
+    (the packet tests above run through them)."""
+    w, h, nf = 176, 144, 3
+    buf = setup_frames(w, h, [5, 6, 7])
+    prm = H.Params(w, h, 20, 7, 1, 2, 0, 0)
+    n, pk, st = H.encode(prm, buf, nf)
+    assert pk == reference_packets(buf, w, h, nf, 1)
+    nd, out, sec, dsec = H.decode(prm, H.headers(prm), pk)
+    assert nd == nf and dsec == 0
+    lib = ref('enc_probe')
+    lib.probe_encode_frames_vtbl.restype = ctypes.c_long
+    rec = np.zeros(w*h*3//2, np.uint8)
+    fnv, s = ctypes.c_uint(), ctypes.c_double()
+    lib.probe_encode_frames_vtbl(w, h, nf, 20, 7, 1, 1, pu8(buf), ctypes.byref(fnv),
+                                 ctypes.byref(s), None, 0, None, None, pu8(rec))
+    assert np.array_equal(out[-1], rec)
+
+
+def test_decoder_no_device_is_loud():
+    import daala_amd.binding as b
+    if b.load().od_hip_device_count() > 0:
+        pytest.skip('a HIP device is present')
+    w, h = 64, 64
+    buf = setup_frames(w, h, [1])
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
+    n, pk, st = H.encode(prm, buf, 1)
+    nd, out, sec, dsec = H.decode(prm, H.headers(prm), pk, use_device=1)
+    assert nd == -30
