@@ -153,6 +153,21 @@ def e2e_encode(frames, device, ref_mpix):
                    'time from first frame in to last packet out (context creation excluded)'}
     if ref_mpix:
         out['x_single_thread_reference'] = round(mp/ref_mpix, 2)
+    # decoder side of the seam on the packets just produced: reference parse on the host
+    # workers + od_hip_decode_tail per frame, against the plain reference decoder
+    hdr = H.headers(prm)
+    nd, pics, sec, dsec = H.decode(prm, hdr, pk, use_device=1, device=device)
+    p1.nworkers = 1
+    n1, want, sec1, _ = H.decode(p1, hdr, pk[:4])
+    if nd == len(pk) and n1 == 4:
+        out['decode'] = {'Mpixels_per_s': round(len(pk)*PIC_W*PIC_H/sec/1e6, 2),
+                         'host_workers': nw, 'seconds': round(sec, 3),
+                         'device_call_seconds_all_workers': round(dsec, 3),
+                         'pictures_identical_to_reference_decoder': bool(np.array_equal(pics[:4], want)),
+                         'reference_decoder_1thread_Mpixels_per_s': round(4*PIC_W*PIC_H/sec1/1e6, 2),
+                         'what': 'daala_decode_packet_in of the 30 packets; symbol parse on host '
+                                 'workers, pixel-domain stage (iDCT, post-filters, deringing, '
+                                 'smoothing, clamp) = one od_hip_decode_tail per frame'}
     return out
 
 
@@ -304,6 +319,25 @@ def main():
                         'ms_per_30_frames': round(dt*1e3, 3),
                         'what': 'od_hip_decode_tail: coefficients -> 8-bit picture, deringing '
                                 'forced on for every superblock (worst case)'}
+    # Extra: lossless configuration (BASELINE configs[4]) - whole-superblock Haar planes,
+    # forward (u8 -> int32) and inverse (int32 -> u8), 5 B/sample algorithmic each.
+    lossless_extra = None
+    if world == 1:
+        ctx.timing_reset()
+        for _ in range(3):
+            ctx.forward_haar(0, FRAMES)
+            ctx.inverse_haar(0, FRAMES)
+        ctx.sync()
+        hk = {}
+        for nm, smp in (('k_haar_forward_luma', FW*FH), ('k_haar_forward_chroma', (FW//2)*(FH//2)),
+                        ('k_haar_inverse_luma', FW*FH), ('k_haar_inverse_chroma', (FW//2)*(FH//2))):
+            n, ms = ctx.timing_get(nm)
+            if n:
+                hk[nm] = {'avg_ms': round(ms/n, 4), 'GBps': round(FRAMES*smp*5/(ms/n*1e-3)/1e9, 1)}
+        tot = sum(v['avg_ms'] for k, v in hk.items() if 'luma' in k) + \
+            2*sum(v['avg_ms'] for k, v in hk.items() if 'chroma' in k)
+        lossless_extra = {'kernels': hk, 'Mpixels_per_s_fwd_plus_inv': round(FRAMES*PIC_W*PIC_H/(tot*1e-3)/1e6, 1),
+                          'what': 'od_hip_forward_haar + od_hip_inverse_haar of 30 frames (round trip exact)'}
     if rank == 0:
         px = world*FRAMES*PIC_W*PIC_H*args.steps
         value = px/elapsed/1e6
@@ -345,6 +379,8 @@ def main():
                                tot_ms/sum(v['avg_ms']*v['launches'] for v in kernels.values()), 4)}
         if decode_extra:
             line['decode_tail'] = decode_extra
+        if lossless_extra:
+            line['lossless_haar'] = lossless_extra
         if world == 1 and not args.no_cpu_baseline:
             nf = 3
             v, dt = cpu_port_baseline(frames, bmaps, prm, tag, nf)

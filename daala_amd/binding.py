@@ -305,6 +305,16 @@ class DaalaHip(object):
                                           bands.ctypes.data_as(ctypes.c_void_p), _p32(y)))
         return bands, y
 
+    def forward_haar(self, slot0=0, nslots=None):
+        """Lossless frames: od_haar of every superblock (pixels -> coefficient planes)."""
+        self.lib.od_hip_forward_haar.argtypes = [ctypes.c_void_p, c_int, c_int]
+        _chk(self.lib.od_hip_forward_haar(self.ctx, slot0, nslots or self.nslots - slot0))
+
+    def inverse_haar(self, slot0=0, nslots=None):
+        """Lossless frames: od_haar_inv + 8-bit store (coefficient planes -> recon)."""
+        self.lib.od_hip_inverse_haar.argtypes = [ctypes.c_void_p, c_int, c_int]
+        _chk(self.lib.od_hip_inverse_haar(self.ctx, slot0, nslots or self.nslots - slot0))
+
     # -- encoder feed (header section 4b) -----------------------------------------
     def enc_feed_create(self, qm, q, beta):
         """qm [4][1024] int16, q [4][11] int32, beta [4][11] f64: per luma level."""

@@ -17,6 +17,7 @@
 #include "xform_kernels.hpp"
 #include "xform_rt_kernels.hpp"
 #include "tail_kernels.hpp"
+#include "haar_kernels.hpp"
 
 static_assert(sizeof(PvqBandRec) == sizeof(od_hip_pvq_band), "record layout");
 static_assert(sizeof(od_hip_pvq_band) == 72, "record layout");
@@ -587,6 +588,40 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
     HIPCHK(hipGetLastError());
   }
   return 0;
+}
+
+// Lossless frames: whole-superblock Haar, no lapping, coefficient shift 0.
+static int haar_planes(od_hip_ctx *ctx, int slot0, int nslots, bool inverse) {
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  for (int p = 0; p < ctx->geo.nplanes; p++) {
+    HaarArgs a;
+    a.pix = (inverse ? ctx->rec[p] : ctx->pix[p]) + (size_t)slot0*ctx->psz[p];
+    a.d = ctx->d[p] + (size_t)slot0*ctx->psz[p];
+    a.fstride = ctx->psz[p];
+    a.w = ctx->pw[p];
+    dim3 grid(ctx->nhsb, ctx->nvsb, nslots);
+    const bool luma = ctx->geo.xdec[p] == 0;
+    Timed tm(ctx, inverse ? (luma ? "k_haar_inverse_luma" : "k_haar_inverse_chroma")
+                          : (luma ? "k_haar_forward_luma" : "k_haar_forward_chroma"));
+    if (luma) {
+      if (inverse) hipLaunchKernelGGL(k_haar_inverse_plane<32>, grid, dim3(64), 0, ctx->stream, a);
+      else hipLaunchKernelGGL(k_haar_forward_plane<32>, grid, dim3(64), 0, ctx->stream, a);
+    }
+    else {
+      if (inverse) hipLaunchKernelGGL(k_haar_inverse_plane<16>, grid, dim3(64), 0, ctx->stream, a);
+      else hipLaunchKernelGGL(k_haar_forward_plane<16>, grid, dim3(64), 0, ctx->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int od_hip_forward_haar(od_hip_ctx *ctx, int slot0, int nslots) {
+  return haar_planes(ctx, slot0, nslots, false);
+}
+
+int od_hip_inverse_haar(od_hip_ctx *ctx, int slot0, int nslots) {
+  return haar_planes(ctx, slot0, nslots, true);
 }
 
 static int check_plane(od_hip_ctx *ctx, int slot, int pli) {

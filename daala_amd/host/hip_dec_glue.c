@@ -270,7 +270,10 @@ static void *dworker(void *arg) {
     rc = daala_decode_packet_in(dec, &dp);
     D.dec = NULL;
     if (rc >= 0) {
-      /* this frame's picture (src/decode.c:1268); img_out only drains the queue */
+      /* This frame's picture (od_img_copy into output_img, src/decode.c:1268).
+         daala_decode_img_out is called once per packet, as the reference's player
+         does: it only advances the two-entry reorder queue (it may hand back the
+         previous picture, and repeats its last answer when called again). */
       o = ((od_dec_ctx *)dec)->output_img + ((od_dec_ctx *)dec)->curr_dec_frame;
       unsigned char *dst = J->out + J->frame_bytes*f;
       for (pli = 0; pli < 3; pli++) {
@@ -284,7 +287,7 @@ static void *dworker(void *arg) {
           dst += pw;
         }
       }
-      while (daala_decode_img_out(dec, &img) > 0);
+      (void)daala_decode_img_out(dec, &img);
     }
     pthread_mutex_lock(&J->mu);
     if (rc < 0) J->failed = 1;

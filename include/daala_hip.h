@@ -142,6 +142,15 @@ int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe);
  * output: 8-bit reconstruction planes in HBM. */
 int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots);
 
+/* Lossless frames (quantizer 0; src/encode.c:3002,3090-3092, src/decode.c:785,1036):
+ * no lapping, no DCT, coefficient shift 0 (od_ref_buf_to_coeff / od_coeff_to_ref_buf
+ * with lossless_p, src/state.c:1209,1274) and od_haar / od_haar_inv
+ * (src/dct.c:1960-2026) of every whole superblock - 32x32 luma, 16x16 4:2:0 chroma.
+ * Forward: the slot's input planes -> coefficient planes; inverse: coefficient planes
+ * -> 8-bit reconstruction planes.  inverse(forward(x)) == x. */
+int od_hip_forward_haar(od_hip_ctx *ctx, int slot0, int nslots);
+int od_hip_inverse_haar(od_hip_ctx *ctx, int slot0, int nslots);
+
 /* Decoder reconstruction, the whole pixel-domain stage of od_decode_coefficients
  * after the symbol parse (src/decode.c:1010-1155): iDCT + split post-filters +
  * frame post-filter, then per 32x32 deringing superblock od_dering

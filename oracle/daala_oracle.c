@@ -1252,3 +1252,25 @@ void orc_feed_level(const coeff *lev, int w, int h, int n, const int16_t *qm,
     }
   }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Lossless frames (reference src/encode.c:3002,3090-3092; src/decode.c:785,1036):
+   coefficient shift 0, no lapping, od_haar / od_haar_inv of every whole superblock
+   (sb = 32 luma, 16 for 4:2:0 chroma). */
+void orc_haar_forward_plane(coeff *d, const uint8_t *pix, int w, int h, int sb) {
+  coeff *c = (coeff *)malloc(sizeof(coeff)*w*h);
+  int ln = sb == 32 ? 5 : 4, x, y;
+  orc_ref_buf_to_coeff(c, w, pix, w, w, h, 0);
+  for (y = 0; y < h; y += sb)
+    for (x = 0; x < w; x += sb) orc_haar(d + (size_t)y*w + x, w, c + (size_t)y*w + x, w, ln);
+  free(c);
+}
+
+void orc_haar_inverse_plane(uint8_t *pix, const coeff *d, int w, int h, int sb) {
+  coeff *c = (coeff *)malloc(sizeof(coeff)*w*h);
+  int ln = sb == 32 ? 5 : 4, x, y;
+  for (y = 0; y < h; y += sb)
+    for (x = 0; x < w; x += sb) orc_haar_inv(c + (size_t)y*w + x, w, d + (size_t)y*w + x, w, ln);
+  orc_coeff_to_ref_buf(pix, w, c, w, w, h, 0);
+  free(c);
+}

@@ -112,3 +112,21 @@ def test_decoder_no_device_is_loud():
     n, pk, st = H.encode(prm, buf, 1)
     nd, out, sec, dsec = H.decode(prm, H.headers(prm), pk, use_device=1)
     assert nd == -30
+
+
+@pytest.mark.timeout(120)
+def test_decoder_driver_many_frames_per_worker():
+    """One context decoding many keyframes in a row (the reference's two-entry output
+    queue must be advanced exactly once per packet) == frames spread over 4 contexts."""
+    w, h, nf = 96, 64, 9
+    buf = setup_frames(w, h, range(nf))
+    prm = H.Params(w, h, 20, 7, 1, 3, 0, 0)
+    n, pk, st = H.encode(prm, buf, nf)
+    hdr = H.headers(prm)
+    outs = []
+    for nw in (1, 4):
+        prm.nworkers = nw
+        nd, out, sec, dsec = H.decode(prm, hdr, pk)
+        assert nd == nf
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])

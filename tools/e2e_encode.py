@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--masking', type=int, default=1)
     ap.add_argument('--host-only', action='store_true', help='same driver, plain C search (no device)')
-    ap.add_argument('--verify', type=int, default=2, help='frames compared with the sequential reference')
+    ap.add_argument('--decode', action='store_true', help='also decode the packets (device tail vs reference)')
     args = ap.parse_args()
     import hipenc_lib as H
     from bench import make_frames, PIC_W, PIC_H
@@ -50,6 +50,19 @@ def main():
                       for k, v in st.as_dict().items()}}
     res['bit_exact_vs_reference'] = pk[:args.ref_frames] == pk0
     res['speedup_vs_1thread'] = round(res['hip']['Mpixels_per_s']/res['reference_1thread']['Mpixels_per_s'], 2)
+    if args.decode:
+        sys.stderr.write('decode: headers\n'); sys.stderr.flush()
+        hdr = H.headers(prm)
+        p1.nworkers = 1
+        sys.stderr.write('decode: reference 1 thread\n'); sys.stderr.flush()
+        n1, want, s1, _ = H.decode(p1, hdr, pk[:4])
+        sys.stderr.write('decode: device %d workers\n' % args.workers); sys.stderr.flush()
+        nd, pics, sd, dsec = H.decode(prm, hdr, pk, use_device=0 if args.host_only else 1)
+        sys.stderr.write('decode: done\n'); sys.stderr.flush()
+        res['decode'] = {'reference_1thread_Mpixels_per_s': round(4*px/s1/1e6, 2),
+                         'hip_Mpixels_per_s': round(args.frames*px/sd/1e6, 2), 'seconds': round(sd, 3),
+                         'device_call_seconds': round(dsec, 3),
+                         'identical': bool(nd == args.frames and np.array_equal(pics[:4], want))}
     print(json.dumps(res))
 
 
