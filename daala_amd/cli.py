@@ -1,0 +1,102 @@
+"""Command line front end of the MI355X Daala path (intra-only streams):
+
+  python -m daala_amd.cli encode in.y4m out.dhip [-v 20] [--workers N] [--no-device]
+  python -m daala_amd.cli decode out.dhip out.y4m [--workers N] [--no-device]
+
+encode: every frame is coded as a keyframe by the reference encoder's serial stage on
+N host workers with the device feed answering the state-free PVQ searches
+(daala_amd/host/hip_enc_glue.c); the packets are byte-identical to the reference
+encoder's.  decode: reference symbol parse on the host workers, pixel-domain stage on
+the device.  The reference's examples write Ogg; libogg is not part of this path, so
+the container is minimal: b"DHIP1\\n", then little-endian u32 fields (width, height,
+quant, masking, fps_n, fps_d, nframes, header bytes), the header-packet blob and the
+length-prefixed video packets.  --no-device runs the same drivers with the plain
+reference code (for comparison); without it a missing GPU is an error."""
+import argparse
+import struct
+import sys
+import time
+
+import numpy as np
+
+from . import hipenc as H
+from .y4m import Y4MReader, Y4MWriter
+
+MAGIC = b'DHIP1\n'
+
+
+def cmd_encode(a):
+    rd = Y4MReader(a.input)
+    frames = list(rd.frames(a.limit))
+    if not frames:
+        raise SystemExit('no frames in %s' % a.input)
+    buf = np.ascontiguousarray(np.concatenate(frames))
+    prm = H.Params(rd.width, rd.height, a.quant, 7, 0 if a.no_masking else 1, a.workers, 0, a.batch)
+    t0 = time.perf_counter()
+    n, pk, st = H.encode(prm, buf, len(frames), use_device=0 if a.no_device else 1, device=a.device)
+    if n < 0:
+        raise SystemExit('encode failed (%d)%s' % (n, ': no HIP device' if n == -30 else ''))
+    hdr = H.headers(prm)
+    with open(a.output, 'wb') as f:
+        f.write(MAGIC)
+        f.write(struct.pack('<8I', rd.width, rd.height, a.quant, 0 if a.no_masking else 1,
+                            rd.fps[0], rd.fps[1], len(frames), hdr.size))
+        f.write(hdr.tobytes())
+        f.write(H.join_packets(pk).tobytes())
+    px = rd.width*rd.height*len(frames)
+    sys.stderr.write('%d frames %dx%d -> %d bytes, %.2f Mpixels/s (%.2fs; searches: %d device, %d host)\n'
+                     % (len(frames), rd.width, rd.height, n, px/st.t_total_s/1e6,
+                        time.perf_counter() - t0, st.dev_hits, st.cpu_other + st.cpu_noref_luma))
+
+
+def read_container(path):
+    with open(path, 'rb') as f:
+        if f.read(len(MAGIC)) != MAGIC:
+            raise SystemExit('%s: not a DHIP1 stream' % path)
+        w, h, quant, masking, fn, fd, nf, hb = struct.unpack('<8I', f.read(32))
+        hdr = np.frombuffer(f.read(hb), np.uint8).copy()
+        rest = np.frombuffer(f.read(), np.uint8).copy()
+    return w, h, quant, masking, (fn, fd), nf, hdr, H.split_packets(rest, nf)
+
+
+def cmd_decode(a):
+    w, h, quant, masking, fps, nf, hdr, pk = read_container(a.input)
+    prm = H.Params(w, h, quant, 7, masking, a.workers, 0, 0)
+    n, pics, sec, dsec = H.decode(prm, hdr, pk, use_device=0 if a.no_device else 1, device=a.device)
+    if n < 0:
+        raise SystemExit('decode failed (%d)%s' % (n, ': no HIP device' if n == -30 else ''))
+    wr = Y4MWriter(a.output, w, h, fps)
+    for f in range(nf):
+        wr.write(pics[f])
+    wr.close()
+    sys.stderr.write('%d frames %dx%d decoded, %.2f Mpixels/s\n' % (nf, w, h, w*h*nf/sec/1e6))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog='daala_amd.cli', description=__doc__.split('\n')[0])
+    sub = ap.add_subparsers(dest='cmd', required=True)
+    e = sub.add_parser('encode')
+    e.add_argument('input')
+    e.add_argument('output')
+    e.add_argument('-v', '--quant', type=int, default=20, help='OD_SET_QUANT (0 = lossless is not on the device path)')
+    e.add_argument('--no-masking', action='store_true')
+    e.add_argument('--limit', type=int, default=None)
+    e.add_argument('--batch', type=int, default=0, help='frames resident on the device at once (0: all)')
+    d = sub.add_parser('decode')
+    d.add_argument('input')
+    d.add_argument('output')
+    for p in (e, d):
+        p.add_argument('--workers', type=int, default=16)
+        p.add_argument('--device', type=int, default=0)
+        p.add_argument('--no-device', action='store_true')
+    a = ap.parse_args(argv)
+    if a.cmd == 'encode':
+        if a.quant < 1:
+            raise SystemExit('quant must be >= 1 here (lossless frames use the Haar path: od_hip_forward_haar)')
+        cmd_encode(a)
+    else:
+        cmd_decode(a)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,106 +1,16 @@
-"""ctypes access to oracle/_ref/libdaala_hipenc.so (the reference encoder with the
-batched frame seam bound to libdaala_hip.so, daala_amd/host/hip_enc_glue.h) and an
-oracle-backed producer of encoder-feed views for the CPU tests.  Test infrastructure."""
+"""Test-side helpers on top of daala_amd/hipenc.py: an oracle-backed producer of
+encoder-feed views (stand-in for od_hip_enc_feed_view in CPU tests, checker of the
+device feed).  Test infrastructure."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
-from testlib import ORACLE_DIR, oracle, p32, p16, pu8, pf64, I32P, I16P, U8P, F64P
-
-c_int = ctypes.c_int
-c_int32 = ctypes.c_int32
-
-
-class Params(ctypes.Structure):
-    _fields_ = [('pic_width', c_int32), ('pic_height', c_int32), ('quant', c_int32),
-                ('complexity', c_int32), ('masking', c_int32), ('nworkers', c_int32),
-                ('check', c_int32), ('batch', c_int32)]
-
-
-class Stats(ctypes.Structure):
-    _fields_ = [('dev_hits', ctypes.c_int64), ('cpu_noref_luma', ctypes.c_int64),
-                ('cpu_other', ctypes.c_int64), ('g2_mismatch', ctypes.c_int64),
-                ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
-                ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
-                ('t_setup_s', ctypes.c_double),
-                ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
-                ('t_total_s', ctypes.c_double)]
-
-    def as_dict(self):
-        return {k: (list(getattr(self, k)) if k == 'search_class_s' else getattr(self, k))
-                for k, _ in self._fields_}
-
-
-class FeedLevel(ctypes.Structure):
-    """Mirror of od_hip_feed_level (include/daala_hip.h section 4b)."""
-    _fields_ = [('n', c_int32), ('nbands', c_int32), ('nblk', c_int32), ('nbx', c_int32),
-                ('off', c_int32*11), ('pad', c_int32),
-                ('cg', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P),
-                ('cos_dist', F64P), ('y', I32P)]
-
-
-_lib = None
-
-
-def have_hipenc():
-    return os.path.exists(os.path.join(ORACLE_DIR, '_ref', 'libdaala_hipenc.so'))
-
-
-def hipenc():
-    global _lib
-    if _lib is None:
-        lib = ctypes.CDLL(os.path.join(ORACLE_DIR, '_ref', 'libdaala_hipenc.so'))
-        lib.od_hipenc_encode_frames.restype = ctypes.c_long
-        lib.od_hipenc_encode_frames.argtypes = [ctypes.POINTER(Params), c_int, U8P,
-                                                ctypes.POINTER(FeedLevel), c_int, c_int, U8P,
-                                                ctypes.c_long, ctypes.POINTER(Stats)]
-        lib.od_hipenc_level_params.argtypes = [ctypes.POINTER(Params), I16P, I32P, F64P]
-        lib.od_hipenc_pad_frame.argtypes = [ctypes.POINTER(Params), U8P,
-                                            ctypes.POINTER(U8P), ctypes.POINTER(c_int),
-                                            ctypes.POINTER(c_int)]
-        _lib = lib
-    return _lib
-
-
-def pack_frames(frames, w, h):
-    """frames: list of [Y, U, V] arrays (at least picture size) -> dense 4:2:0 buffer."""
-    cw, ch = (w + 1)//2, (h + 1)//2
-    return np.ascontiguousarray(np.concatenate(
-        [np.concatenate([f[0][:h, :w].ravel(), f[1][:ch, :cw].ravel(), f[2][:ch, :cw].ravel()])
-         for f in frames]))
-
-
-def split_packets(buf, count):
-    out, o = [], 0
-    for _ in range(count):
-        n = int.from_bytes(buf[o:o + 4].tobytes(), 'little')
-        out.append(buf[o + 4:o + 4 + n].tobytes())
-        o += 4 + n
-    return out
-
-
-def level_params(prm):
-    qm = np.zeros((4, 1024), np.int16)
-    q = np.zeros((4, 11), np.int32)
-    beta = np.zeros((4, 11), np.float64)
-    rc = hipenc().od_hipenc_level_params(ctypes.byref(prm), p16(qm), p32(q), pf64(beta))
-    assert rc == 0
-    return qm, q, beta
-
-
-def pad_frame(prm, frame):
-    """The reference's padded input planes of one dense 4:2:0 frame."""
-    lib = hipenc()
-    fw, fh = c_int(), c_int()
-    assert lib.od_hipenc_pad_frame(ctypes.byref(prm), pu8(frame), None, ctypes.byref(fw),
-                                   ctypes.byref(fh)) == 0
-    fw, fh = fw.value, fh.value
-    planes = [np.zeros((fh, fw), np.uint8), np.zeros((fh//2, fw//2), np.uint8),
-              np.zeros((fh//2, fw//2), np.uint8)]
-    arr = (U8P*3)(*[pu8(p) for p in planes])
-    assert lib.od_hipenc_pad_frame(ctypes.byref(prm), pu8(frame), arr, None, None) == 0
-    return planes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from daala_amd.hipenc import *          # noqa: F401,F403
+from daala_amd.hipenc import FeedLevel, level_params, p32, p16, pu8, pf64, I32P
+from testlib import oracle
 
 
 class OracleFeed:
@@ -143,49 +53,3 @@ class OracleFeed:
             self.keep.append(a)
 
 
-def encode(prm, frames_buf, nframes, views=None, use_device=0, device=0):
-    lib = hipenc()
-    out = np.zeros(max(1 << 20, frames_buf.size), np.uint8)
-    st = Stats()
-    varr = None
-    if views is not None:
-        varr = (FeedLevel*(4*nframes))()
-        for f in range(nframes):
-            for l in range(4):
-                varr[4*f + l] = views[f].levels[l]
-    n = lib.od_hipenc_encode_frames(ctypes.byref(prm), nframes, pu8(frames_buf), varr,
-                                    use_device, device, pu8(out), out.size, ctypes.byref(st))
-    if n < 0:
-        return n, None, st
-    return n, split_packets(out, nframes), st
-
-
-def headers(prm):
-    lib = hipenc()
-    lib.od_hipenc_headers.restype = ctypes.c_long
-    lib.od_hipenc_headers.argtypes = [ctypes.POINTER(Params), U8P, ctypes.c_long]
-    out = np.zeros(1 << 16, np.uint8)
-    n = lib.od_hipenc_headers(ctypes.byref(prm), pu8(out), out.size)
-    assert n > 0, n
-    return out[:n].copy()
-
-
-def join_packets(packets):
-    return np.frombuffer(b''.join(len(p).to_bytes(4, 'little') + p for p in packets), np.uint8).copy()
-
-
-def decode(prm, hdr, packets, use_device=0, device=0):
-    """Decodes keyframe packets -> (frames [nframes, frame_bytes] u8, seconds, device_seconds)."""
-    lib = hipenc()
-    lib.od_hipdec_decode_frames.restype = ctypes.c_long
-    lib.od_hipdec_decode_frames.argtypes = [ctypes.POINTER(Params), U8P, ctypes.c_long, c_int, U8P,
-                                            ctypes.c_long, c_int, c_int, U8P, F64P, F64P]
-    w, h = prm.pic_width, prm.pic_height
-    fb = w*h + 2*((w + 1)//2)*((h + 1)//2)
-    buf = join_packets(packets)
-    out = np.zeros((len(packets), fb), np.uint8)
-    sec, dsec = ctypes.c_double(), ctypes.c_double()
-    n = lib.od_hipdec_decode_frames(ctypes.byref(prm), pu8(hdr), hdr.size, len(packets), pu8(buf),
-                                    buf.size, use_device, device, pu8(out), ctypes.byref(sec),
-                                    ctypes.byref(dsec))
-    return n, out, sec.value, dsec.value
