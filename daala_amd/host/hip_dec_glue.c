@@ -1,7 +1,7 @@
 /* hip_dec_glue.c - reference-side binding of the batched frame seam, decoder
  * (INTEGRATION.md seam 2; header hip_enc_glue.h).
  *
- * Compiled into oracle/_ref/libdaala_hipenc.so next to the reference decoder.  The
+ * Compiled into the integration library libdaala_hipenc.so next to the reference decoder.  The
  * decoder's symbol parse (serial range decoder + PVQ synthesis into dtmp) stays the
  * reference's C code; its whole pixel-domain stage of a keyframe -
  *   idct_2d per block           src/decode.c:637  (vtable, src/state.h:106)
@@ -31,7 +31,7 @@
 
 #include "hip_enc_glue.h"
 
-/* the reference's definitions, renamed by the build (oracle/Makefile) */
+/* the reference's definitions, renamed by the build (integration build recipe) */
 void od_postfilter_split_cpu(od_coeff *c0, int stride, int bs, int f, int q,
  unsigned char *skip, int skip_stride, int hfilter, int vfilter);
 void od_apply_postfilter_frame_sbs_cpu(od_coeff *c0, int stride, int nhsb, int nvsb,

@@ -1,8 +1,8 @@
 /* hip_enc_glue.c - reference-side binding of the batched frame seam
  * (INTEGRATION.md seam 2; header hip_enc_glue.h).
  *
- * Compiled into a build of the reference encoder (oracle/Makefile target
- * _ref/libdaala_hipenc.so): it includes the reference's internal headers and
+ * Compiled into a build of the reference encoder (the integration build, INTEGRATION.md
+ * "Seam 2, live": libdaala_hipenc.so): it includes the reference's internal headers and
  * provides the two symbols that build leaves open,
  *
  *   pvq_search_rdo_double()   the call sites of src/pvq_encoder.c:426,463 - the
@@ -30,7 +30,7 @@
 
 #include "hip_enc_glue.h"
 
-/* kept reference definitions (see oracle/Makefile, pvq_hook_tail.c, encode_tu.c) */
+/* kept reference definitions (see the integration build recipe, pvq_hook_tail.c, encode_tu.c) */
 double od_ref_pvq_search_rdo_double_cpu(const double *xcoeff, int n, int k,
  od_coeff *ypulse, double g2);
 int od_pvq_encode_cpu(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,

@@ -3,8 +3,9 @@ the batched frame seam bound to libdaala_hip.so (INTEGRATION.md seam 2).
 
 The shared library (libdaala_hipenc.so) contains the reference's own compiled code
 next to our glue, so it is built in the dev container by oracle/Makefile into
-oracle/_ref/ (git-ignored; travels to the GPU box as a binary).  Used by the CLI
-(daala_amd/cli.py), bench.py and the tests."""
+oracle/_ref/ (git-ignored; travels to the GPU box as a binary) and everything that
+loads it lives outside the product package: the tests, bench.py's `e2e_encode`
+integration measurement and tools/daala_hip_cli.py."""
 import ctypes
 import os
 

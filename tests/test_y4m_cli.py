@@ -9,7 +9,10 @@ import pytest
 
 from testlib import synth_plane, ref, pu8
 import hipenc_lib as H
-from daala_amd import cli
+import importlib.util
+_spec = importlib.util.spec_from_file_location('daala_hip_cli', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'daala_hip_cli.py'))
+cli = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(cli)
 from daala_amd.y4m import Y4MReader, Y4MWriter, Y4MError
 
 needs = pytest.mark.skipif(not H.have_hipenc(), reason='oracle/_ref/libdaala_hipenc.so not built')

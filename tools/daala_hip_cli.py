@@ -1,7 +1,11 @@
 """Command line front end of the MI355X Daala path (intra-only streams):
 
-  python -m daala_amd.cli encode in.y4m out.dhip [-v 20] [--workers N] [--no-device]
-  python -m daala_amd.cli decode out.dhip out.y4m [--workers N] [--no-device]
+  python tools/daala_hip_cli.py encode in.y4m out.dhip [-v 20] [--workers N] [--no-device]
+  python tools/daala_hip_cli.py decode out.dhip out.y4m [--workers N] [--no-device]
+
+(The drivers live in the reference-side integration library, which is built from the
+reference sources in the dev container - see INTEGRATION.md "Seam 2, live" - so this
+front end sits beside it in tools/, not in the product package.)
 
 encode: every frame is coded as a keyframe by the reference encoder's serial stage on
 N host workers with the device feed answering the state-free PVQ searches
@@ -17,10 +21,15 @@ import struct
 import sys
 import time
 
+import os
+
 import numpy as np
 
-from . import hipenc as H
-from .y4m import Y4MReader, Y4MWriter
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import hipenc_binding as H                              # noqa: E402
+from daala_amd.y4m import Y4MReader, Y4MWriter          # noqa: E402
 
 MAGIC = b'DHIP1\n'
 
@@ -73,7 +82,7 @@ def cmd_decode(a):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(prog='daala_amd.cli', description=__doc__.split('\n')[0])
+    ap = argparse.ArgumentParser(prog='daala_hip_cli', description=__doc__.split('\n')[0])
     sub = ap.add_subparsers(dest='cmd', required=True)
     e = sub.add_parser('encode')
     e.add_argument('input')
