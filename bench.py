@@ -127,7 +127,7 @@ def e2e_encode(frames, device, ref_mpix):
     encoder's serial entropy/RDO stage (oracle/_ref/libdaala_hipenc.so = the reference
     compiled in the dev container + our glue).  Reported beside `value`, not as it."""
     try:
-        import hipenc_lib as H
+        import hipenc_binding as H
     except ImportError:
         return None
     if not H.have_hipenc():

@@ -26,7 +26,7 @@ def main():
     ap.add_argument('--host-only', action='store_true', help='same driver, plain C search (no device)')
     ap.add_argument('--decode', action='store_true', help='also decode the packets (device tail vs reference)')
     args = ap.parse_args()
-    import hipenc_lib as H
+    import hipenc_binding as H
     from bench import make_frames, PIC_W, PIC_H
     frames = make_frames(args.frames, seed0=1)
     buf = H.pack_frames(frames, PIC_W, PIC_H)
