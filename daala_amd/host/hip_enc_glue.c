@@ -432,6 +432,16 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   J.frame_bytes = (size_t)p->pic_width*p->pic_height + 2*(size_t)cw*ch;
   J.views = views;
   J.batch = p->batch > 0 && p->batch < nframes ? p->batch : nframes;
+  if (p->batch <= 0) {
+    /* default: everything at once, but keep the pinned host mirror of the feed
+       (about 33 bytes per padded luma sample and frame) under ~6 GB */
+    double per_frame;
+    int cap;
+    per_frame = 33.*((p->pic_width + 63) & ~63)*((p->pic_height + 63) & ~63);
+    cap = (int)(6e9/per_frame);
+    if (cap < nw) cap = nw;
+    if (J.batch > cap) J.batch = cap;
+  }
   J.pkt = (unsigned char **)calloc(nframes, sizeof(*J.pkt));
   J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
   th = (pthread_t *)calloc(nw, sizeof(*th));

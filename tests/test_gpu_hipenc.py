@@ -130,3 +130,17 @@ def test_hip_decoder_1080p():
     assert np.array_equal(got, want)
     print('1080p decode x%d, 4 workers: reference %.3fs, device tail %.3fs (device calls %.3fs)'
           % (nf, s0, s1, ds))
+
+
+def test_hip_encoder_packets_identical_4k_geometry():
+    """BASELINE configs[2] geometry (3840x2160, padded 3840x2176): two frames, two
+    workers, batches of one frame (slot reuse across batches) - packets identical to the
+    plain reference search."""
+    w, h, nf = 3840, 2160, 2
+    buf = H.pack_frames(frames_of(w, h, [31, 32]), w, h)
+    prm = H.Params(w, h, 20, 7, 1, 2, 0, 1)
+    n0, want, st0 = H.encode(prm, buf, nf)
+    n, got, st = H.encode(prm, buf, nf, use_device=1)
+    assert n == n0 and got == want
+    assert st.dev_hits > 0 and st.lost_sync == 0
+    print('4K x%d: plain search %.2fs, device feed %.2fs' % (nf, st0.t_total_s, st.t_total_s))
