@@ -29,6 +29,35 @@ __device__ __forceinline__ void lap4_pre(int32_t &x0, int32_t &x1, int32_t &x2,
   x3 = s0 - d3;
 }
 
+// Same arithmetic with the 24-bit multiplier (full rate) for callers whose data is
+// known to be small: the row-tile forward kernels keep the lapped tile as int16
+// (|value| <= 6452, tools/range_analysis.py), so every product fits easily.  The
+// generic form above compiles its "a*C + 32" steps to v_mad_u64_u32 / v_mul_lo_u32,
+// both quarter rate.
+__device__ __forceinline__ void lap4_pre24(int32_t &x0, int32_t &x1, int32_t &x2,
+                                           int32_t &x3) {
+  int32_t d3 = x0 - x3;
+  int32_t d2 = x1 - x2;
+  int32_t s1 = x1 - (d2 >> 1);
+  int32_t s0 = x0 - (d3 >> 1);
+  d2 = lift_mul24<85>(d2) >> 6;
+  d2 += (d2 > 0);
+  d3 = lift_mul24<75>(d3) >> 6;
+  d3 += (d3 > 0);
+  int32_t t;
+  // multiplier and rounding term are inline constants: one v_mad_i32_i24 each
+  asm("v_mad_i32_i24 %0, %1, -15, 32" : "=v"(t) : "v"(d2));
+  d3 += t >> 6;
+  asm("v_mad_i32_i24 %0, %1, 33, 32" : "=v"(t) : "v"(d3));
+  d2 += t >> 6;
+  s0 += d3 >> 1;
+  s1 += d2 >> 1;
+  x0 = s0;
+  x1 = s1;
+  x2 = s1 - d2;
+  x3 = s0 - d3;
+}
+
 // Inverse lapping; undoes the scale with C truncating division
 // (src/filter.c:237-241).
 __device__ __forceinline__ void lap4_post(int32_t &x0, int32_t &x1, int32_t &x2,

@@ -28,7 +28,7 @@ __device__ __forceinline__ void rt_sync() {
 
 __device__ __forceinline__ void rt_lap4_pre16(int16_t *p, int stride) {
   int32_t x0 = p[0], x1 = p[stride], x2 = p[2*stride], x3 = p[3*stride];
-  lap4_pre(x0, x1, x2, x3);
+  lap4_pre24(x0, x1, x2, x3);      // int16 data: 24-bit products are exact
   p[0] = (int16_t)x0; p[stride] = (int16_t)x1; p[2*stride] = (int16_t)x2; p[3*stride] = (int16_t)x3;
 }
 
@@ -108,25 +108,36 @@ __device__ __forceinline__ void rt_store_rect(int32_t *__restrict__ dst, int w, 
   constexpr int RPI = 64/LPR;                   // rows per wave instruction
   const int rr = lane % RPI, c4 = col0 + (lane/RPI)*4;
   if (x0 + c4 < w) {
+    // one address per lane, then a uniform row step: the 64-bit multiply-add per store
+    // the plain form compiles to is quarter rate (v_mad_u64_u32)
+    int32_t *q = dst + (size_t)(unsigned)__umul24(row0 + rr, w) + c4;
+    const size_t step = (size_t)RPI*(unsigned)w;
 #pragma unroll
     for (int it = 0; it < (NR + RPI - 1)/RPI; it++) {
       const int r = row0 + it*RPI + rr;
       if (NR % RPI == 0 || it*RPI + rr < NR) {
         const int32_t *p = Z + r*T::LDZ + c4;
-        *reinterpret_cast<int4 *>(dst + (size_t)r*w + c4) = make_int4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<int4 *>(q) = make_int4(p[0], p[1], p[2], p[3]);
       }
+      q += step;
     }
   }
 }
 
 // Forward path of one row tile, TWO waves per tile.
-//   level 0 (block size SB): wave w owns the columns [32w, 32w+32) - for luma that
-//     is one whole 32x32 block, for chroma two 16x16 blocks - for both separable
-//     passes and for the level-0 split lapping: nothing crosses waves.
+//   level 0 (block size SB): the tile has exactly 64 column transforms and 64 row
+//     transforms per pass, so wave 0 runs the whole level with all 64 lanes busy while
+//     wave 1 waits at the barrier (splitting the level by columns issued the same
+//     instruction stream twice with half the lanes masked).
 //   levels >= 1: wave w owns the rows [w*SB/2, (w+1)*SB/2) of the tile at every
-//     level (blocks nest), again nothing crosses waves.
+//     level (blocks nest): nothing crosses waves.
 // So the only workgroup barriers are: after the load, between the two frame-lapping
 // phases, after them, and between level 0 and level 1.
+// PMC profile (rocprofv3 SQ_INSTS_VALU / SQ_WAVES): ~2800 VALU instructions per wave =
+// 0.28 ms of pure VALU issue for a 30-frame luma launch - this kernel is bound by VALU
+// issue about as much as by HBM, hence the instruction-count work: one-instruction
+// v_mad_i32_i24 lifting steps, 24-bit lapping, 24-bit index arithmetic, pointer stepping
+// instead of a 64-bit multiply-add per store.
 // PYRAMID: all blocks of all levels (one plane per level).  KNOWN: only the quadtree
 // leaves + keyframe DC merge (od_compute_dcts, src/encode.c:1286-1343).
 template <int SB, int NLEV, bool KNOWN>
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
   __shared__ int32_t Z[SB*T::LDZ];
   __shared__ uint8_t bsz[16*T::NSB];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
   int tx, sby, f;
   rt_tile_coords(tx, sby, f);
   const int x0 = tx*T::W, y0 = sby*SB;
@@ -157,11 +168,12 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
     // A1: 8-bit pixels -> (p - 128) << 4, dword loads starting 4 bytes left of the tile
     const uint8_t *pix = a.pix + (size_t)f*a.pix_fstride;
     constexpr int DW = T::HAW/4 + 1;                   // 18 dwords cover x0-4 .. x0+67
+    static_assert(DW == 18, "the division by DW below is spelled for 18");
     for (int e = tid; e < T::HAH*DW; e += 128) {
-      const int ty = e/DW, dx = e%DW;
+      const int ty = __umul24(e, 3641) >> 16, dx = e - ty*DW;       // e/18, exact for e < 5000
       const int gy = min(max(y0 - 2 + ty, 0), a.h - 1);
       const int gx = min(max(x0 - 4 + dx*4, 0), a.w - 4);
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(pix + (size_t)gy*a.pstride + gx);
+      const uint32_t v = *reinterpret_cast<const uint32_t *>(pix + ((unsigned)__umul24(gy, a.pstride) + gx));
 #pragma unroll
       for (int b = 0; b < 4; b++) {
         const int txx = dx*4 + b - 2;
@@ -199,10 +211,14 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
     constexpr int N = SB >> K;                                                         \
     constexpr int NBY = SB/N;                                                          \
     constexpr int BY_PER_WAVE = K == 0 ? 1 : NBY/2;                                    \
-    const int col = K == 0 ? wv*32 + (lane & 31) : lane;                               \
-    const bool lane_on = K == 0 ? lane < 32 : true;                                    \
+    const int col = lane;                                                              \
     const int bxt = col/N, i = col%N;                                                  \
-    const bool present = lane_on && (bxt*N)/SB < nsb;                                  \
+    const bool present = (bxt*N)/SB < nsb;                                             \
+    /* level 0 has only 64 column / 64 row transforms per pass: ONE wave runs it with  \
+       all 64 lanes busy, the other goes straight to the barrier (a wave split by      \
+       columns would issue the same instructions with half the lanes masked: the PMC   \
+       profile showed the kernel VALU-issue bound, not HBM bound) */                   \
+    if (K != 0 || wv == 0) {                                                           \
     for (int bb = 0; bb < BY_PER_WAVE; bb++) {                                         \
       const int byi = K == 0 ? 0 : wv*BY_PER_WAVE + bb;                                \
       const bool go = present && (!KNOWN || cell(byi, bxt, N) == 3 - K);               \
@@ -227,8 +243,7 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
       }                                                                                \
       rt_sync();                                                                       \
       if (!KNOWN) {                                                                    \
-        if (K == 0) rt_store_rect<SB, SB, 32>(out, a.w, x0, Z, 0, wv*32, lane);        \
-        else rt_store_rect<SB, N, 64>(out + (size_t)K*a.out_lstride, a.w, x0, Z, byi*N, 0, lane); \
+        rt_store_rect<SB, N, 64>(out + (size_t)K*a.out_lstride, a.w, x0, Z, byi*N, 0, lane); \
         rt_sync();                                                                     \
       }                                                                                \
       if constexpr (K + 1 < NLEV) {                                                    \
@@ -239,9 +254,9 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
           rt_lap4_pre16(A + (2 + byi*N + N/2 - 2)*T::LDA + 2 + col, T::LDA);           \
         }                                                                              \
         rt_sync();                                                                     \
-        constexpr int NBX = K == 0 ? 32/N : T::W/N;      /* blocks per wave row */     \
+        constexpr int NBX = T::W/N;                      /* blocks per tile row */     \
         for (int e = lane; e < N*NBX; e += 64) {                                       \
-          const int bx2 = (K == 0 ? wv*(32/N) : 0) + e/N, row = byi*N + e%N;           \
+          const int bx2 = e/N, row = byi*N + e%N;                                      \
           const bool sp2 = (bx2*N)/SB < nsb && (!KNOWN || cell(byi, bx2, N) < 3 - K);  \
           if (sp2 && (sby*NBY + byi + 1)*N <= a.pic_h) {                               \
             rt_lap4_pre16(A + (2 + row)*T::LDA + 2 + bx2*N + N/2 - 2, 1);              \
@@ -250,7 +265,8 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
         rt_sync();                                                                     \
       }                                                                                \
     }                                                                                  \
-    if (K == 0) rt_barrier();    /* level >= 1 regions mix both level-0 column halves */ \
+    }                                                                                  \
+    if (K == 0) rt_barrier();    /* level >= 1 regions mix the whole level-0 tile */   \
   }
   RT_FWD_LEVEL(0)
   RT_FWD_LEVEL(1)
