@@ -118,6 +118,15 @@ def _c32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def od_filter_vectors(n, vecs, inverse=False):
+    """od_pre_filter{n} (inverse=False) / od_post_filter{n} of [nvec, n] int32 vectors."""
+    x = _c32(vecs)
+    y = np.empty_like(x)
+    load().od_hip_filter_vectors.argtypes = [c_int, c_int, I32P, I32P, c_int]
+    _chk(load().od_hip_filter_vectors(n, int(inverse), _p32(y), _p32(x), x.shape[0]))
+    return y
+
+
 # -- section 1/2 of the header: stand-alone pieces --------------------------------
 def od_bin_fdct_blocks(bs, blocks):
     """blocks: [nblocks, n, n] int32 -> forward transform of each (od_bin_fdctNxN)."""

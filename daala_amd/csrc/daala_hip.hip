@@ -302,6 +302,29 @@ int od_hip_filter4_vectors(int inverse, od_coeff *out, const od_coeff *in, int n
   return 0;
 }
 
+int od_hip_filter_vectors(int n, int inverse, od_coeff *out, const od_coeff *in, int nvec) {
+  if (!out || !in) return fail(OD_HIP_EFAULT, "null pointer");
+  if (nvec < 0 || (n != 4 && n != 8 && n != 16 && n != 32)) return fail(OD_HIP_EINVAL, "bad n/nvec");
+  if (int rc = ensure_device()) return rc;
+  if (nvec == 0) return 0;
+  size_t bytes = (size_t)nvec*n*sizeof(int32_t);
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_out.reserve(bytes)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
+  dim3 grid((nvec + 63)/64), blk(64);
+  int32_t *o = (int32_t *)g_out.p;
+  const int32_t *i = (const int32_t *)g_in.p;
+  switch (n) {
+    case 4: hipLaunchKernelGGL(k_filter_vectors<4>, grid, blk, 0, 0, o, i, nvec, inverse); break;
+    case 8: hipLaunchKernelGGL(k_filter_vectors<8>, grid, blk, 0, 0, o, i, nvec, inverse); break;
+    case 16: hipLaunchKernelGGL(k_filter_vectors<16>, grid, blk, 0, 0, o, i, nvec, inverse); break;
+    default: hipLaunchKernelGGL(k_filter_vectors<32>, grid, blk, 0, 0, o, i, nvec, inverse); break;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, g_out.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int od_hip_resample_luma_420(od_coeff *pred, const od_coeff *luma, size_t luma_len,
                              int lstride, const int32_t *luma_off, int nblk, int bs,
                              int chroma_bs) {

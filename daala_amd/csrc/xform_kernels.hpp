@@ -113,6 +113,60 @@ __global__ void k_haar_blocks(int32_t *__restrict__ out, const int32_t *__restri
   }
 }
 
+// n-point lapping filters od_pre/post_filter{4,8,16,32} (src/filter.c:174-249, :306-440,
+// :546-808, :879-1380; TYPE3 rotation structure, tables in filter_params.h).  One lane per
+// vector; only the 4-point pair is on the codec's path, the others exist for parity
+// with the reference's transform test tools.  Generic int32 multiplies (arbitrary input).
+#include "filter_params.h"
+template <int N>
+__global__ void k_filter_vectors(int32_t *__restrict__ out, const int32_t *__restrict__ in,
+                                 int nvec, int inverse) {
+  constexpr int H = N/2;
+  constexpr int P4[] = LAP_PARAMS4, P8[] = LAP_PARAMS8, P16[] = LAP_PARAMS16, P32[] = LAP_PARAMS32;
+  const long v = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (v >= nvec) return;
+  auto P = [&](int i) -> int { return N == 4 ? P4[i] : N == 8 ? P8[i] : N == 16 ? P16[i] : P32[i]; };
+  int32_t x[N], t[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = in[v*N + i];
+#pragma unroll
+  for (int i = 0; i < H; i++) t[N - 1 - i] = x[i] - x[N - 1 - i];
+#pragma unroll
+  for (int i = 0; i < H; i++) t[i] = x[i] - (t[N - 1 - i] >> 1);
+  if (!inverse) {
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      if (P(i) != 64) {
+        t[H + i] = (t[H + i]*P(i)) >> 6;
+        t[H + i] += t[H + i] > 0;
+      }
+    }
+#pragma unroll
+    for (int j = N - 2; j >= H; j--) {
+      t[j + 1] += (t[j]*P(H + (j - H)) + 32) >> 6;
+      t[j] += (t[j + 1]*P(2*H - 1 + (j - H)) + 32) >> 6;
+    }
+  }
+  else {
+#pragma unroll
+    for (int j = H; j <= N - 2; j++) {
+      t[j] -= (t[j + 1]*P(2*H - 1 + (j - H)) + 32) >> 6;
+      t[j + 1] -= (t[j]*P(H + (j - H)) + 32) >> 6;
+    }
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      if (P(i) != 64) t[H + i] = (t[H + i]*64)/P(i);      // C truncating division
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < H; i++) t[i] += t[N - 1 - i] >> 1;
+#pragma unroll
+  for (int i = 0; i < H; i++) {
+    out[v*N + i] = t[i];
+    out[v*N + N - 1 - i] = t[i] - t[N - 1 - i];
+  }
+}
+
 __global__ void k_filter4_vectors(int32_t *__restrict__ out, const int32_t *__restrict__ in,
                                   int nvec, int inverse) {
   long v = (long)blockIdx.x*blockDim.x + threadIdx.x;

@@ -81,6 +81,13 @@ int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in,
 int od_hip_filter4_vectors(int inverse, od_coeff *out, const od_coeff *in,
  int nvec);
 
+/* The n-point variants od_pre_filter{4,8,16,32} / od_post_filter{4,8,16,32}
+ * (src/filter.c:174-249, :306-440, :546-808, :879-1380), nvec vectors of n samples.
+ * Only n = 4 is reachable in the codec (OD_FILT_SIZE() == 0, src/filter.h:99); the
+ * larger ones are what the reference's dcttest / filter tools exercise. */
+int od_hip_filter_vectors(int n, int inverse, od_coeff *out, const od_coeff *in,
+ int nvec);
+
 /* CfL luma resample, od_resample_luma_coeffs (src/intra.c:72-109) built on
  * od_tf_up_hv_lp (src/tf.c:82-108), 4:2:0 only: for each of nblk blocks reads
  * the luma coefficients at luma + luma_off[b] (stride lstride) and writes an

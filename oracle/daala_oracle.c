@@ -25,6 +25,7 @@
 #include <string.h>
 #include "gen_lift_oracle.h"
 #include "coding_order_tables.h"
+#include "filter_params.h"
 
 typedef int32_t coeff;
 
@@ -1273,4 +1274,60 @@ void orc_haar_inverse_plane(uint8_t *pix, const coeff *d, int w, int h, int sb) 
     for (x = 0; x < w; x += sb) orc_haar_inv(c + (size_t)y*w + x, w, d + (size_t)y*w + x, w, ln);
   orc_coeff_to_ref_buf(pix, w, c, w, w, h, 0);
   free(c);
+}
+
+/* ------------------------------------------------------------------------ */
+/* A3, all sizes: the n-point lapping pre/post filters od_pre_filter{4,8,16,32} /
+   od_post_filter{4,8,16,32} (reference src/filter.c:174-249, :306-440, :546-808,
+   :879-1380; TYPE3 rotation structure, parameters in filter_params.h).  Only the
+   4-point pair is reachable in the codec (OD_FILT_SIZE() == 0, src/filter.h:99); the
+   larger ones are exercised by the reference's dcttest/tools.  In/out may alias.
+     pre : +-1 butterflies; scale t[h+k] = (t*P_k) >> 6, "+1 if positive" (skipped for
+           P_k == 64); rotations j = n-2 .. h: t[j+1] += (t[j]*A_j+32)>>6,
+           t[j] += (t[j+1]*B_j+32)>>6; closing butterflies.
+     post: same butterflies; rotations undone j = h .. n-2 in reverse; scale undone
+           with C truncating division (t << 6)/P_k; closing butterflies. */
+static const int *lap_params(int n) {
+  static const int p4[] = LAP_PARAMS4, p8[] = LAP_PARAMS8, p16[] = LAP_PARAMS16,
+   p32[] = LAP_PARAMS32;
+  return n == 4 ? p4 : n == 8 ? p8 : n == 16 ? p16 : p32;
+}
+
+void orc_pre_filter_n(int n, coeff *y, const coeff *x) {
+  const int *P = lap_params(n);
+  int h = n/2, i, j;
+  coeff t[32];
+  for (i = 0; i < h; i++) t[n - 1 - i] = x[i] - x[n - 1 - i];
+  for (i = 0; i < h; i++) t[i] = x[i] - (t[n - 1 - i] >> 1);
+  for (i = 0; i < h; i++) {
+    if (P[i] != 64) {
+      t[h + i] = (t[h + i]*P[i]) >> 6;
+      t[h + i] += t[h + i] > 0;
+    }
+  }
+  for (j = n - 2; j >= h; j--) {
+    t[j + 1] += (t[j]*P[h + (j - h)] + 32) >> 6;
+    t[j] += (t[j + 1]*P[2*h - 1 + (j - h)] + 32) >> 6;
+  }
+  for (i = 0; i < h; i++) t[i] += t[n - 1 - i] >> 1;
+  for (i = 0; i < h; i++) y[i] = t[i];
+  for (i = 0; i < h; i++) y[n - 1 - i] = t[i] - t[n - 1 - i];
+}
+
+void orc_post_filter_n(int n, coeff *x, const coeff *y) {
+  const int *P = lap_params(n);
+  int h = n/2, i, j;
+  coeff t[32];
+  for (i = 0; i < h; i++) t[n - 1 - i] = y[i] - y[n - 1 - i];
+  for (i = 0; i < h; i++) t[i] = y[i] - (t[n - 1 - i] >> 1);
+  for (j = h; j <= n - 2; j++) {
+    t[j] -= (t[j + 1]*P[2*h - 1 + (j - h)] + 32) >> 6;
+    t[j + 1] -= (t[j]*P[h + (j - h)] + 32) >> 6;
+  }
+  for (i = 0; i < h; i++) {
+    if (P[i] != 64) t[h + i] = (t[h + i]*64)/P[i];
+  }
+  for (i = 0; i < h; i++) t[i] += t[n - 1 - i] >> 1;
+  for (i = 0; i < h; i++) x[i] = t[i];
+  for (i = 0; i < h; i++) x[n - 1 - i] = t[i] - t[n - 1 - i];
 }

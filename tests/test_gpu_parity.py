@@ -555,3 +555,18 @@ def test_pvq_lds_variant_matches_register_variant(hip, monkeypatch):
         assert np.array_equal(y3, y2)
         for f in ('cg', 'g', 'cos_dist', 'dist', 'qg', 'k', 'ncand'):
             assert np.array_equal(b3[f], b2[f]), f
+
+
+def test_filters_8_16_32(hip):
+    """od_pre/post_filter{4,8,16,32}: device vs the reference's vectors, exact inversion."""
+    import daala_amd.binding as b
+    g = golden('filter_n_vectors.npz')
+    for n in (8, 16, 32):
+        assert np.array_equal(b.od_filter_vectors(n, g['x%d' % n]), g['pre%d' % n])
+        assert np.array_equal(b.od_filter_vectors(n, g['x%d' % n], inverse=True), g['post%d' % n])
+        rng = np.random.default_rng(n)
+        v = rng.integers(-200000, 200001, size=(20001, n), dtype=np.int32)
+        assert np.array_equal(b.od_filter_vectors(n, b.od_filter_vectors(n, v), inverse=True), v)
+    g4 = golden('filter_vectors.npz')
+    assert np.array_equal(b.od_filter_vectors(4, g4['x']), g4['pre'])
+    assert np.array_equal(b.od_filter_vectors(4, g4['x'], inverse=True), g4['post'])

@@ -172,3 +172,21 @@ def test_compute_dist_golden():
                 got = o.orc_compute_dist(p32(np.ascontiguousarray(x)), p32(np.ascontiguousarray(y)), n,
                                          pf64(np.ascontiguousarray(g['mag2_%d' % bs])), m)
                 assert got == d
+
+
+def test_filters_8_16_32_against_reference_vectors():
+    """A3, the n-point variants (only the reference's dcttest/tools reach them):
+    oracle == reference outputs, and post(pre(x)) == x."""
+    o = oracle()
+    g = load('filter_n_vectors.npz')
+    for n in (8, 16, 32):
+        for x, a, b in zip(g['x%d' % n], g['pre%d' % n], g['post%d' % n]):
+            x = np.ascontiguousarray(x)
+            y = np.zeros(n, np.int32)
+            o.orc_pre_filter_n(n, p32(y), p32(x))
+            assert np.array_equal(y, a)
+            z = np.zeros(n, np.int32)
+            o.orc_post_filter_n(n, p32(z), p32(y))
+            assert np.array_equal(z, x)
+            o.orc_post_filter_n(n, p32(y), p32(x))
+            assert np.array_equal(y, b)

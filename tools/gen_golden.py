@@ -72,6 +72,23 @@ def filter_vectors():
                         cfl_luma=luma, **ln_out, **cfl)
 
 
+def filter_n_vectors():
+    """od_pre/post_filter{8,16,32} (src/filter.c:306-1380): the variants only the
+    reference's transform test tools reach; inputs + reference outputs as data."""
+    out = {}
+    for n in (8, 16, 32):
+        v = rng.integers(-40000, 40001, size=(192, n), dtype=np.int32)
+        v[:32] = rng.integers(-4, 5, size=(32, n))
+        v[32:64] = rng.integers(-2040, 2041, size=(32, n))       # (pixel - 128) << 4 range
+        pre = np.zeros_like(v)
+        post = np.zeros_like(v)
+        for i in range(len(v)):
+            getattr(r, 'od_pre_filter%d' % n)(p32(pre[i]), p32(v[i]))
+            getattr(r, 'od_post_filter%d' % n)(p32(post[i]), p32(v[i]))
+        out['x%d' % n], out['pre%d' % n], out['post%d' % n] = v, pre, post
+    np.savez_compressed(os.path.join(G, 'filter_n_vectors.npz'), **out)
+
+
 def plane_forward():
     pic_w, pic_h, fw, fh = 150, 100, 192, 128     # reference pads to multiples of 64
     nhsb, nvsb = fw//32, fh//32
@@ -239,6 +256,7 @@ def dcttest_md5():
 if __name__ == '__main__':
     dct_vectors()
     filter_vectors()
+    filter_n_vectors()
     plane_forward()
     pvq_vectors()
     encoder_params()
