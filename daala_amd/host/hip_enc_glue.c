@@ -157,6 +157,32 @@ int od_pvq_encode(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out
     T.band = 0;
     T.cand = 0;
     T.active = T.blk >= 0 && T.blk < L->nblk;
+    if (T.active) {
+      /* The feed is band-major (the device's coalesced layout), so the records of
+         one block sit nblk entries apart: start pulling them in now, pvq_theta's
+         own arithmetic hides the latency. */
+      size_t nrec;
+      int b;
+      nrec = (size_t)L->nbands*L->nblk;
+      for (b = 0; b < L->nbands; b++) {
+        size_t rec;
+        int nb;
+        int c;
+        rec = (size_t)b*L->nblk + T.blk;
+        nb = L->off[b + 1] - L->off[b];
+        __builtin_prefetch(L->ncand + rec);
+        __builtin_prefetch(L->cg + rec);
+        for (c = 0; c < 2; c++) {
+          const int32_t *y;
+          int o;
+          __builtin_prefetch(L->k + c*nrec + rec);
+          __builtin_prefetch(L->qg + c*nrec + rec);
+          __builtin_prefetch(L->cos_dist + c*nrec + rec);
+          y = L->y + (size_t)2*L->nblk*(L->off[b] - 1) + ((size_t)c*L->nblk + T.blk)*nb;
+          for (o = 0; o < nb; o += 16) __builtin_prefetch(y + o);
+        }
+      }
+    }
   }
   ret = od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust,
    is_keyframe, q_scaling, bx, by, qm, qm_inv);
