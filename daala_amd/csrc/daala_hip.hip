@@ -1132,6 +1132,19 @@ int od_hip_calibrate_traffic(int mode, size_t bytes) {
   return 0;
 }
 
+int od_hip_host_register(void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = ensure_device()) return rc;
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return 0;
+}
+
+int od_hip_host_unregister(void *ptr) {
+  if (!ptr) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipHostUnregister(ptr));
+  return 0;
+}
+
 int od_hip_sync(od_hip_ctx *ctx) {
   if (!ctx) return fail(OD_HIP_EFAULT, "null context");
   HIPCHK(hipSetDevice(ctx->device));

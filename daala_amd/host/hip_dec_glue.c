@@ -56,6 +56,7 @@ typedef struct dec_tls {
   od_hip_ctx *ctx;          /* one-slot device context of this worker, or NULL */
   od_dct_func_2d idct_cpu[OD_NBSIZES];
   unsigned char *rec[3];    /* device output of the current frame */
+  int pinned[6];            /* dtmp[0..2], rec[0..2] page-locked */
   long idct_skipped;
   int failed;
   double t_device;
@@ -242,8 +243,16 @@ static void *dworker(void *arg) {
     g.nslots = 1;
     D.ctx = od_hip_ctx_create(J->device, &g);
     for (pli = 0; pli < 3; pli++) {
-      D.rec[pli] = (unsigned char *)malloc((size_t)(st->frame_width >> (pli > 0))
-       *(st->frame_height >> (pli > 0)));
+      size_t np;
+      np = (size_t)(st->frame_width >> (pli > 0))*(st->frame_height >> (pli > 0));
+      D.rec[pli] = (unsigned char *)malloc(np);
+      /* page-lock what crosses PCIe every frame: the decoder's coefficient planes
+         (upload) and the picture buffers (download); failure only costs speed */
+      if (D.ctx != NULL) {
+        D.pinned[pli] = od_hip_host_register(st->dtmp[pli], np*sizeof(od_coeff)) == 0;
+        D.pinned[3 + pli] = D.rec[pli] != NULL
+         && od_hip_host_register(D.rec[pli], np) == 0;
+      }
     }
     for (i = 0; i < OD_NBSIZES; i++) {
       D.idct_cpu[i] = st->opt_vtbl.idct_2d[i];
@@ -299,6 +308,10 @@ static void *dworker(void *arg) {
     if (t > J->t_end) J->t_end = t;
   }
   pthread_mutex_unlock(&J->mu);
+  for (pli = 0; pli < 3; pli++) {
+    if (D.pinned[pli]) od_hip_host_unregister(st->dtmp[pli]);
+    if (D.pinned[3 + pli]) od_hip_host_unregister(D.rec[pli]);
+  }
   if (D.ctx != NULL) od_hip_ctx_destroy(D.ctx);
   for (pli = 0; pli < 3; pli++) free(D.rec[pli]);
   if (dec != NULL) daala_decode_free(dec);

@@ -325,6 +325,13 @@ int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *o
  * known byte count (tools/profile_round.sh). */
 int od_hip_calibrate_traffic(int mode, size_t bytes);
 
+/* Page-locks (hipHostRegister) / unlocks a host buffer the caller keeps handing to the
+ * upload/download entry points - e.g. the reference's dtmp coefficient planes in the
+ * decoder binding - so that those copies run as direct DMA instead of through a
+ * staging buffer.  Optional: unregistered memory works, slower. */
+int od_hip_host_register(void *ptr, size_t bytes);
+int od_hip_host_unregister(void *ptr);
+
 /* Synchronise the context's stream / time its last batch (ms, HIP events). */
 int od_hip_sync(od_hip_ctx *ctx);
 
