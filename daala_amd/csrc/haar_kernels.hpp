@@ -30,7 +30,9 @@ __global__ __launch_bounds__(64) void k_haar_forward_plane(HaarArgs a) {
   __shared__ int32_t T[2][SB*LD];
   __shared__ int32_t Y[SB*LD];
   const int lane = threadIdx.x;
-  const size_t org = (size_t)blockIdx.z*a.fstride + (size_t)(blockIdx.y*SB)*a.w + blockIdx.x*SB;
+  int sbx, sby, fr;
+  xcd_tile_coords(sbx, sby, fr);   // 4 adjacent luma SBs share each 128-byte line of the 8-bit plane
+  const size_t org = (size_t)fr*a.fstride + (size_t)(sby*SB)*a.w + sbx*SB;
   // load: dword = 4 pixels; SB*SB/4 dwords over 64 lanes
   for (int e = lane; e < SB*SB/4; e += 64) {
     const int r = e/(SB/4), c4 = e%(SB/4);
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(64) void k_haar_inverse_plane(HaarArgs a) {
   __shared__ int32_t X[2][SB*LD];
   __shared__ int32_t Y[SB*LD];
   const int lane = threadIdx.x;
-  const size_t org = (size_t)blockIdx.z*a.fstride + (size_t)(blockIdx.y*SB)*a.w + blockIdx.x*SB;
+  int sbx, sby, fr;
+  xcd_tile_coords(sbx, sby, fr);   // 4 adjacent luma SBs share each 128-byte line of the 8-bit plane
+  const size_t org = (size_t)fr*a.fstride + (size_t)(sby*SB)*a.w + sbx*SB;
   for (int e = lane; e < SB*SB/4; e += 64) {
     const int r = e/(SB/4), c4 = e%(SB/4);
     const int4 v = *reinterpret_cast<const int4 *>(a.d + org + (size_t)r*a.w + 4*c4);

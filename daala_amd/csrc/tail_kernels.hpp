@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
   __shared__ int dirs[16], vars[16], thresh[16];
   __shared__ int sh_w;
   const int t = threadIdx.x;
-  const int sbx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
+  int sbx, sby, f;
+  xcd_tile_coords(sbx, sby, f);        // 3-sample borders: neighbours share lines
   const int flag = a.flags[(size_t)f*a.nhsb*a.nvsb + sby*a.nhsb + sbx];
   const bool dering_on = a.q[0] > 0 && flag;
   const int sb_bsize = a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];

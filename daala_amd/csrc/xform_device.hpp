@@ -78,6 +78,23 @@ __device__ __forceinline__ void lap4_post(int32_t &x0, int32_t &x1, int32_t &x2,
   x3 = s0 - d3;
 }
 
+// XCD-aware workgroup order (cdna guide T1).  Workgroups are dealt round-robin over the
+// 8 XCDs, each with its own L2, while neighbouring tiles share cache lines (halo rows,
+// unaligned or sub-line row segments): the plain order makes several XCDs fetch the
+// same lines from HBM (rocprofv3 FETCH_SIZE showed 2-4x the input bytes).  Each XCD is
+// given a CONTIGUOUS run of the (x, y, z) grid instead.  Pure speed: any mapping is
+// correct.  Bijective for every grid size.
+__device__ __forceinline__ void xcd_tile_coords(int &bx, int &by, int &bz) {
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  const unsigned total = gx*gy*gridDim.z;
+  const unsigned lin = blockIdx.x + gx*(blockIdx.y + gy*blockIdx.z);
+  const unsigned q = total/8, r = total%8, xcd = lin%8, idx = lin/8;
+  const unsigned m = (xcd < r ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q) + idx;
+  bx = m%gx;
+  by = (m/gx)%gy;
+  bz = m/(gx*gy);
+}
+
 __device__ __forceinline__ void haar2x2(int32_t &ll, int32_t &lh, int32_t &hl,
                                         int32_t &hh) {
   ll += hl;

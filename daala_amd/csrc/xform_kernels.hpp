@@ -230,8 +230,9 @@ __global__ __launch_bounds__(SB*SB/4) void k_postfilter_clamp(PostArgs a) {
   using T = SbTile<SB>;
   __shared__ int32_t X[SB*T::LD];
   const int t = threadIdx.x;
-  const int f = blockIdx.z;
-  const int x0 = (int)blockIdx.x*SB - SB/2, y0 = (int)blockIdx.y*SB - SB/2;
+  int bx, by, f;
+  xcd_tile_coords(bx, by, f);          // corner-centred tiles straddle cache lines of 4 neighbours
+  const int x0 = bx*SB - SB/2, y0 = by*SB - SB/2;
   const int32_t *c = a.c + (size_t)f*a.c_fstride;
   uint8_t *rec = a.rec + (size_t)f*a.rec_fstride;
   const int r = t/(SB/4), c4 = (t%(SB/4))*4;
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(SB*SB/4) void k_postfilter_clamp(PostArgs a) {
     X[r*T::LD + c4 + 2] = v.z; X[r*T::LD + c4 + 3] = v.w;
   }
   __syncthreads();
-  const bool vbound = blockIdx.x > 0 && (int)blockIdx.x < a.nhsb;   // internal x boundary
-  const bool hbound = blockIdx.y > 0 && (int)blockIdx.y < a.nvsb;
+  const bool vbound = bx > 0 && bx < a.nhsb;   // internal x boundary
+  const bool hbound = by > 0 && by < a.nvsb;
   if (vbound && t < SB) {
     int gyy = y0 + t;
     if (gyy >= 0 && gyy < a.h) {
