@@ -171,6 +171,35 @@ def e2e_encode(frames, device, ref_mpix):
     return out
 
 
+def e2e_encode_ranks(frames, device, world, dist, torch):
+    """N > 1: every rank encodes its own 30 frames through the live seam on its own GPU
+    with its share of the host CPUs; aggregate = all frames / slowest rank.  (No
+    collective on the data path: frames are independent.)"""
+    try:
+        import hipenc_binding as H
+        ok = H.have_hipenc()
+    except ImportError:
+        ok = False
+    sec = -1.0
+    nw = max(1, min(16, host_cpu_budget()//world))
+    if ok:
+        buf = H.pack_frames(frames, PIC_W, PIC_H)
+        prm = H.Params(PIC_W, PIC_H, 20, 7, 1, min(nw, len(frames)), 0, 0)
+        dist.barrier()
+        n, pk, st = H.encode(prm, buf, len(frames), use_device=1, device=device)
+        if n >= 0:
+            sec = st.t_total_s
+    t = torch.tensor([sec, -sec], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    slowest, fastest = float(t[0].item()), -float(t[1].item())
+    if fastest < 0:
+        return None                      # some rank could not run it
+    return {'Mpixels_per_s': round(world*len(frames)*PIC_W*PIC_H/slowest/1e6, 3),
+            'frames_per_gpu': len(frames), 'host_workers_per_gpu': nw,
+            'seconds_slowest_rank': round(slowest, 3),
+            'what': 'every rank: 30 keyframes through the live seam on its own GPU; aggregate'}
+
+
 KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel name
     'k_forward_pyramid_luma': 'k_forward_rt<32, 4, false>',
     'k_forward_pyramid_chroma': 'k_forward_rt<16, 3, false>',
@@ -338,6 +367,10 @@ def main():
             2*sum(v['avg_ms'] for k, v in hk.items() if 'chroma' in k)
         lossless_extra = {'kernels': hk, 'Mpixels_per_s_fwd_plus_inv': round(FRAMES*PIC_W*PIC_H/(tot*1e-3)/1e6, 1),
                           'what': 'od_hip_forward_haar + od_hip_inverse_haar of 30 frames (round trip exact)'}
+    e2e_multi = None
+    if world > 1 and not args.no_cpu_baseline:
+        ctx.close()
+        e2e_multi = e2e_encode_ranks(frames, local_rank, world, dist, torch)
     if rank == 0:
         px = world*FRAMES*PIC_W*PIC_H*args.steps
         value = px/elapsed/1e6
@@ -395,6 +428,8 @@ def main():
             e2e = e2e_encode(frames, local_rank, refenc['value'] if refenc else None)
             if e2e:
                 line['e2e_encode'] = e2e
+        if e2e_multi:
+            line['e2e_encode'] = e2e_multi
         if args.skip_pvq:
             line['INVALID'] = 'profiling run with --skip-pvq'
         print(json.dumps(line))

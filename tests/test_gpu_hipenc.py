@@ -144,3 +144,24 @@ def test_hip_encoder_packets_identical_4k_geometry():
     assert n == n0 and got == want
     assert st.dev_hits > 0 and st.lost_sync == 0
     print('4K x%d: plain search %.2fs, device feed %.2fs' % (nf, st0.t_total_s, st.t_total_s))
+
+
+@pytest.mark.parametrize('w,h,quant,masking', [(355, 291, 20, 1), (64, 48, 1, 1), (130, 66, 60, 0),
+                                               (32, 32, 400, 1), (200, 120, 8, 1)])
+def test_hip_encoder_odd_geometry_and_quantizers(w, h, quant, masking):
+    """Picture sizes that are not multiples of the block sizes (padding, edge gating of
+    the split lapping) and quantizer extremes: device feed == plain reference search,
+    packets byte for byte, and the decoder seam returns the reference decoder's pictures."""
+    nf = 2
+    cw, ch = (w + 1)//2, (h + 1)//2
+    fr = [[synth_plane(w, h, s), synth_plane(cw, ch, s, 1), synth_plane(cw, ch, s + 1, 1)] for s in (41, 42)]
+    buf = H.pack_frames(fr, w, h)
+    prm = H.Params(w, h, quant, 7, masking, 2, 1, 0)
+    n0, want, st0 = H.encode(prm, buf, nf)
+    n, got, st = H.encode(prm, buf, nf, use_device=1)
+    assert n == n0 and got == want
+    assert st.check_fail == 0 and st.lost_sync == 0
+    hdr = H.headers(prm)
+    nd0, pics0, _, _ = H.decode(prm, hdr, got, use_device=0)
+    nd1, pics1, _, ds = H.decode(prm, hdr, got, use_device=1)
+    assert nd0 == nf and nd1 == nf and np.array_equal(pics0, pics1)
