@@ -171,7 +171,7 @@ def e2e_encode(frames, device, ref_mpix):
     return out
 
 
-def e2e_encode_ranks(frames, device, world, dist, torch):
+def e2e_encode_ranks(frames, device, world, dist, torch, red_dev='cuda'):
     """N > 1: every rank encodes its own 30 frames through the live seam on its own GPU
     with its share of the host CPUs; aggregate = all frames / slowest rank.  (No
     collective on the data path: frames are independent.)"""
@@ -189,7 +189,7 @@ def e2e_encode_ranks(frames, device, world, dist, torch):
         n, pk, st = H.encode(prm, buf, len(frames), use_device=1, device=device)
         if n >= 0:
             sec = st.t_total_s
-    t = torch.tensor([sec, -sec], dtype=torch.float64, device='cuda')
+    t = torch.tensor([sec, -sec], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     slowest, fastest = float(t[0].item()), -float(t[1].item())
     if fastest < 0:
@@ -243,6 +243,13 @@ def main():
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Rehearsal of the N > 1 code path on a 1-GPU box (tools/rehearse_multirank.sh):
+    # BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo for the barrier and the
+    # max-time reduce (RCCL refuses two ranks on one GPU).  Never set by the driver.
+    rehearse = os.environ.get('BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
+    red_dev = 'cpu' if rehearse else 'cuda'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
@@ -251,8 +258,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
 
     import daala_amd.binding as b
     from testlib import random_bsize_map
@@ -302,7 +312,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -370,7 +380,7 @@ def main():
     e2e_multi = None
     if world > 1 and not args.no_cpu_baseline:
         ctx.close()
-        e2e_multi = e2e_encode_ranks(frames, local_rank, world, dist, torch)
+        e2e_multi = e2e_encode_ranks(frames, local_rank, world, dist, torch, red_dev)
     if rank == 0:
         px = world*FRAMES*PIC_W*PIC_H*args.steps
         value = px/elapsed/1e6
