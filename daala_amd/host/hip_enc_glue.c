@@ -310,6 +310,9 @@ typedef struct job {
   int next_upload;
   int next_encode;
   int encoded;          /* frames completely coded */
+  int nslots;           /* device slots: one batch, or two half-buffers of `batch` */
+  unsigned char *done;  /* per frame: completely coded */
+  int done_prefix;      /* frames [0, done_prefix) are all coded */
   int launched_upto;    /* frames [0, launched_upto) have a feed run enqueued */
   int failed;
   /* outputs */
@@ -343,7 +346,7 @@ static int upload_frame(job *J, daala_enc_ctx *enc, int f) {
     planes[pli] = pad->planes[pli].data;
     ystride[pli] = pad->planes[pli].ystride;
   }
-  return od_hip_upload_planes(J->ctx, f - J->batch0, planes, ystride);
+  return od_hip_upload_planes(J->ctx, f % J->nslots, planes, ystride);
 }
 
 static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
@@ -354,7 +357,7 @@ static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
   T.lev = NULL;
   if (J->views != NULL) T.lev = J->views + 4*(size_t)f;
   else if (J->feed != NULL) {
-    if (od_hip_enc_feed_view(J->feed, f - J->batch0, lev) != 0) return -1;
+    if (od_hip_enc_feed_view(J->feed, f % J->nslots, lev) != 0) return -1;
     T.lev = lev;
   }
   /* Frame f of the stream on a context that did not code frames 0..f-1: the
@@ -420,6 +423,8 @@ static void *worker(void *arg) {
       pthread_mutex_lock(&J->mu);
       if (rc != 0) J->failed = 1;
       J->encoded++;
+      J->done[f] = 1;
+      while (J->done_prefix < J->nframes && J->done[J->done_prefix]) J->done_prefix++;
       pthread_cond_broadcast(&J->cv);
       continue;
     }
@@ -465,9 +470,18 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
     int cap;
     per_frame = 33.*((p->pic_width + 63) & ~63)*((p->pic_height + 63) & ~63);
     cap = (int)(6e9/per_frame);
-    if (cap < nw) cap = nw;
-    if (J.batch > cap) J.batch = cap;
+    if (cap < 2*nw) cap = 2*nw;
+    /* longer streams: two half-buffers of cap/2 frames, batch k+1 is computed and
+       copied while batch k is being coded */
+    if (J.batch > cap) J.batch = cap/2;
   }
+  /* Device slots: frame f lives in slot f % nslots.  A stream that does not fit one
+     batch uses two half-buffers; batch k (frames [k*batch, (k+1)*batch)) may be
+     uploaded and launched as soon as batch k-2, the previous user of its half, is
+     completely coded. */
+  J.nslots = J.batch >= nframes ? nframes : 2*J.batch;
+  J.done = (unsigned char *)calloc(nframes, 1);
+  if (J.done == NULL) return OD_HIP_EFAULT;
   J.pkt = (unsigned char **)calloc(nframes, sizeof(*J.pkt));
   J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
   th = (pthread_t *)calloc(nw, sizeof(*th));
@@ -490,7 +504,7 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
     g.frame_height = (p->pic_height + (2*OD_BSIZE_MAX - 1)) & ~(2*OD_BSIZE_MAX - 1);
     g.nplanes = 3;
     g.xdec[1] = g.xdec[2] = 1;
-    g.nslots = J.batch;
+    g.nslots = J.nslots;
     J.ctx = od_hip_ctx_create(device, &g);
     if (J.ctx == NULL) return OD_HIP_ENODEV;
     J.feed = od_hip_enc_feed_create(J.ctx);
@@ -517,9 +531,9 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
     for (b0 = 0; b0 < nframes && !J.failed; b0 += J.batch) {
       double ta;
       double tb;
-      /* the previous batch's slots and host mirrors are reused: wait until all
-         of its frames are completely coded */
-      while (!J.failed && J.encoded < b0) pthread_cond_wait(&J.cv, &J.mu);
+      /* this batch's half-buffer (device slots + pinned host mirror) was last used
+         by batch k-2: wait until all of that batch's frames are completely coded */
+      while (!J.failed && J.done_prefix < b0 - J.batch) pthread_cond_wait(&J.cv, &J.mu);
       J.batch0 = b0;
       J.batch_n = nframes - b0 < J.batch ? nframes - b0 : J.batch;
       J.uploaded = 0;
@@ -531,7 +545,7 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
       tb = now_s();
       J.st.t_upload_s += tb - ta;
       if (J.failed) break;
-      if (od_hip_enc_feed_run(J.feed, 0, J.batch_n) != 0) {
+      if (od_hip_enc_feed_run(J.feed, b0 % J.nslots, J.batch_n) != 0) {
         J.failed = 1;
         break;
       }
@@ -560,6 +574,7 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   if (J.ctx != NULL) od_hip_ctx_destroy(J.ctx);
   free(J.pkt);
   free(J.pkt_len);
+  free(J.done);
   free(th);
   pthread_mutex_destroy(&J.mu);
   pthread_cond_destroy(&J.cv);
