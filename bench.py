@@ -377,10 +377,7 @@ def main():
             2*sum(v['avg_ms'] for k, v in hk.items() if 'chroma' in k)
         lossless_extra = {'kernels': hk, 'Mpixels_per_s_fwd_plus_inv': round(FRAMES*PIC_W*PIC_H/(tot*1e-3)/1e6, 1),
                           'what': 'od_hip_forward_haar + od_hip_inverse_haar of 30 frames (round trip exact)'}
-    e2e_multi = None
-    if world > 1 and not args.no_cpu_baseline:
-        ctx.close()
-        e2e_multi = e2e_encode_ranks(frames, local_rank, world, dist, torch, red_dev)
+    line = None
     if rank == 0:
         px = world*FRAMES*PIC_W*PIC_H*args.steps
         value = px/elapsed/1e6
@@ -438,12 +435,16 @@ def main():
             e2e = e2e_encode(frames, local_rank, refenc['value'] if refenc else None)
             if e2e:
                 line['e2e_encode'] = e2e
-        if e2e_multi:
-            line['e2e_encode'] = e2e_multi
         if args.skip_pvq:
             line['INVALID'] = 'profiling run with --skip-pvq'
-        print(json.dumps(line))
     ctx.close()
+    if world > 1 and not args.no_cpu_baseline:
+        # every rank takes part (after rank 0 has read everything it needs from its ctx)
+        e2e_multi = e2e_encode_ranks(frames, local_rank, world, dist, torch, red_dev)
+        if rank == 0 and e2e_multi:
+            line['e2e_encode'] = e2e_multi
+    if rank == 0:
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -15,7 +15,8 @@ pytestmark = [pytest.mark.gpu,
 
 
 @pytest.mark.parametrize('w,h,quant,masking,seed', ((176, 112, 20, 1, 3), (176, 112, 8, 1, 5),
-                                                     (352, 288, 30, 0, 6)))
+                                                     (352, 288, 30, 0, 6), (355, 291, 20, 1, 41),
+                                                     (130, 66, 60, 0, 41)))
 def test_device_decode_tail_equals_reference_decoder(w, h, quant, masking, seed):
     import daala_amd.binding as b
     r = None
