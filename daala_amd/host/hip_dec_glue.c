@@ -56,7 +56,7 @@ typedef struct dec_tls {
   od_hip_ctx *ctx;          /* one-slot device context of this worker, or NULL */
   od_dct_func_2d idct_cpu[OD_NBSIZES];
   unsigned char *rec[3];    /* device output of the current frame */
-  int pinned[6];            /* dtmp[0..2], rec[0..2] page-locked */
+  int pinned[3];            /* rec[0..2] page-locked */
   long idct_skipped;
   int failed;
   double t_device;
@@ -244,15 +244,19 @@ static void *dworker(void *arg) {
     D.ctx = od_hip_ctx_create(J->device, &g);
     for (pli = 0; pli < 3; pli++) {
       size_t np;
+      void *mem;
       np = (size_t)(st->frame_width >> (pli > 0))*(st->frame_height >> (pli > 0));
-      D.rec[pli] = (unsigned char *)malloc(np);
-      /* page-lock what crosses PCIe every frame: the decoder's coefficient planes
-         (upload) and the picture buffers (download); failure only costs speed */
-      if (D.ctx != NULL) {
-        D.pinned[pli] = od_hip_host_register(st->dtmp[pli], np*sizeof(od_coeff)) == 0;
-        D.pinned[3 + pli] = D.rec[pli] != NULL
-         && od_hip_host_register(D.rec[pli], np) == 0;
-      }
+      /* The picture buffers cross PCIe every frame: page-lock them.  They are
+         page-aligned and padded to whole pages so that the locked range never
+         shares a page with anybody else's memory (a registered range that covers
+         part of a neighbouring heap block makes the runtime treat that block as
+         pinned too).  The reference's own dtmp planes are left alone for that
+         reason.  Failure to lock only costs speed. */
+      np = (np + 4095) & ~(size_t)4095;
+      mem = NULL;
+      if (posix_memalign(&mem, 4096, np) != 0) mem = NULL;
+      D.rec[pli] = (unsigned char *)mem;
+      D.pinned[pli] = mem != NULL && od_hip_host_register(mem, np) == 0;
     }
     for (i = 0; i < OD_NBSIZES; i++) {
       D.idct_cpu[i] = st->opt_vtbl.idct_2d[i];
@@ -309,8 +313,7 @@ static void *dworker(void *arg) {
   }
   pthread_mutex_unlock(&J->mu);
   for (pli = 0; pli < 3; pli++) {
-    if (D.pinned[pli]) od_hip_host_unregister(st->dtmp[pli]);
-    if (D.pinned[3 + pli]) od_hip_host_unregister(D.rec[pli]);
+    if (D.pinned[pli]) od_hip_host_unregister(D.rec[pli]);
   }
   if (D.ctx != NULL) od_hip_ctx_destroy(D.ctx);
   for (pli = 0; pli < 3; pli++) free(D.rec[pli]);
