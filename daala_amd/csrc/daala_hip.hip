@@ -401,7 +401,7 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   }
   ctx->bsize_sz = (size_t)ctx->nhsb*4*ctx->nvsb*4;
   ok = ok && hipMalloc((void **)&ctx->bsize, ns*ctx->bsize_sz) == hipSuccess;
-  ok = ok && hipMemset(ctx->bsize, 3, ns*ctx->bsize_sz) == hipSuccess;
+  ok = ok && hipMemsetAsync(ctx->bsize, 3, ns*ctx->bsize_sz, ctx->stream) == hipSuccess;
   ok = ok && hipMalloc((void **)&ctx->qm_dev, 4*1024*sizeof(int16_t)) == hipSuccess;
   ok = ok && hipMalloc((void **)&ctx->rsq, PVQ_RSQ_TAB*sizeof(double)) == hipSuccess;
   if (ok) {
@@ -414,9 +414,12 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
   for (int b = 0; ok && b < 4; b++) {
     ok = ok && hipMalloc((void **)&ctx->tab[b], tabn[b]*sizeof(uint16_t)) == hipSuccess;
-    ok = ok && hipMemcpy(ctx->tab[b], tabs[b], tabn[b]*sizeof(uint16_t),
-                         hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->tab[b], tabs[b], tabn[b]*sizeof(uint16_t),
+                              hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
   }
+  // everything above was issued on ctx->stream; nothing may still be in flight when the
+  // first caller-visible operation starts
+  ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
   if (!ok) {
     fail(OD_HIP_ENODEV, "device allocation failed");
     od_hip_ctx_destroy(ctx);
@@ -657,36 +660,38 @@ int od_hip_download_level(od_hip_ctx *ctx, int slot, int pli, int level, od_coef
   if (int rc = check_plane(ctx, slot, pli)) return rc;
   if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
   if (level < 0 || level >= ctx->nlev[pli]) return fail(OD_HIP_EINVAL, "level out of range");
+  // stream-ordered: copies on the context's own stream, then wait (the null stream a
+  // plain hipMemcpy uses is not ordered against ctx->stream, a non-blocking stream)
+  HIPCHK(hipMemcpyAsync(dst, ctx->lev[pli] + ((size_t)slot*ctx->nlev[pli] + level)*ctx->psz[pli],
+                        ctx->psz[pli]*4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(dst, ctx->lev[pli] + ((size_t)slot*ctx->nlev[pli] + level)*ctx->psz[pli],
-                   ctx->psz[pli]*4, hipMemcpyDeviceToHost));
   return 0;
 }
 
 int od_hip_download_coeffs(od_hip_ctx *ctx, int slot, int pli, od_coeff *dst) {
   if (int rc = check_plane(ctx, slot, pli)) return rc;
   if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipMemcpyAsync(dst, ctx->d[pli] + (size_t)slot*ctx->psz[pli], ctx->psz[pli]*4,
+                        hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(dst, ctx->d[pli] + (size_t)slot*ctx->psz[pli], ctx->psz[pli]*4,
-                   hipMemcpyDeviceToHost));
   return 0;
 }
 
 int od_hip_upload_coeffs(od_hip_ctx *ctx, int slot, int pli, const od_coeff *src) {
   if (int rc = check_plane(ctx, slot, pli)) return rc;
   if (!src) return fail(OD_HIP_EFAULT, "null pointer");
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(ctx->d[pli] + (size_t)slot*ctx->psz[pli], src, ctx->psz[pli]*4,
-                   hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(ctx->d[pli] + (size_t)slot*ctx->psz[pli], src, ctx->psz[pli]*4,
+                        hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));      // src may be reused by the caller
   return 0;
 }
 
 int od_hip_download_recon(od_hip_ctx *ctx, int slot, int pli, unsigned char *dst) {
   if (int rc = check_plane(ctx, slot, pli)) return rc;
   if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipMemcpyAsync(dst, ctx->rec[pli] + (size_t)slot*ctx->psz[pli], ctx->psz[pli],
+                        hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(dst, ctx->rec[pli] + (size_t)slot*ctx->psz[pli], ctx->psz[pli],
-                   hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -789,13 +794,14 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
   if (bands) {
     std::vector<double> cg(nrec), g(nrec), cd(2*nrec), di(2*nrec);
     std::vector<int32_t> qg(2*nrec), k(2*nrec), nc(nrec);
-    HIPCHK(hipMemcpy(cg.data(), o.cg + slot*nrec, nrec*8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(g.data(), o.g + slot*nrec, nrec*8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cd.data(), o.cos_dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(di.data(), o.dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(qg.data(), o.qg + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(k.data(), o.k + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(nc.data(), o.ncand + slot*nrec, nrec*4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(cg.data(), o.cg + slot*nrec, nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(g.data(), o.g + slot*nrec, nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cd.data(), o.cos_dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(di.data(), o.dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(qg.data(), o.qg + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(k.data(), o.k + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nc.data(), o.ncand + slot*nrec, nrec*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < nb; b++) {
       for (int blk = 0; blk < nblk; blk++) {
         size_t r = (size_t)b*nblk + blk;
@@ -811,7 +817,8 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
   if (y) {
     // device: band-major [band][cand][block][n_b]  ->  API: [block][cand][ncoded]
     std::vector<int32_t> yd(ny);
-    HIPCHK(hipMemcpy(yd.data(), o.y + slot*ny, ny*4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(yd.data(), o.y + slot*ny, ny*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     memset(y, 0, (size_t)nblk*2*ncoded*sizeof(int32_t));
     for (int b = 0; b < nb; b++) {
       int nbnd = off[b + 1] - off[b];
@@ -1002,10 +1009,14 @@ int ensure_tail_buffers(od_hip_ctx *ctx) {
   for (int p = 0; p < ctx->geo.nplanes; p++) {
     HIPCHK(hipMalloc((void **)&ctx->p32[p], ns*ctx->psz[p]*4));
     HIPCHK(hipMalloc((void **)&ctx->bskip[p], ns*(size_t)(ctx->geo.frame_width/4)*(ctx->geo.frame_height/4)));
-    HIPCHK(hipMemset(ctx->bskip[p], 0, ns*(size_t)(ctx->geo.frame_width/4)*(ctx->geo.frame_height/4)));
+    HIPCHK(hipMemsetAsync(ctx->bskip[p], 0, ns*(size_t)(ctx->geo.frame_width/4)*(ctx->geo.frame_height/4), ctx->stream));
   }
   HIPCHK(hipMalloc((void **)&ctx->dflags, ns*ctx->nhsb*ctx->nvsb));
-  HIPCHK(hipMemset(ctx->dflags, 0, ns*ctx->nhsb*ctx->nvsb));
+  // on the context's stream: a plain hipMemset runs on the null stream, asynchronously to
+  // the host, and ctx->stream (non-blocking) does not wait for it - the uploads that
+  // follow could be overwritten by a late memset (seen as rare +-1 pixels in multi-worker
+  // decodes: zeroed dering flags)
+  HIPCHK(hipMemsetAsync(ctx->dflags, 0, ns*ctx->nhsb*ctx->nvsb, ctx->stream));
   return 0;
 }
 }  // namespace
