@@ -17,7 +17,9 @@
  * (include/daala_hip.h section 4b) while with-reference and chroma searches, whose
  * inputs depend on the serial reconstruction, stay the reference's C code.
  * No reference text lives in this file. */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -315,6 +317,7 @@ typedef struct job {
   int done_prefix;      /* frames [0, done_prefix) are all coded */
   int launched_upto;    /* frames [0, launched_upto) have a feed run enqueued */
   int failed;
+  int next_worker_id;
   /* outputs */
   unsigned char **pkt;
   long *pkt_len;
@@ -389,11 +392,43 @@ static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
   return 0;
 }
 
+/* Optional placement of the workers: HIPENC_PIN=<stride> pins worker i to the
+   (i*stride)-th CPU of the process's affinity mask, so that workers do not end up as
+   SMT siblings of one core or crowd one L3 slice when the scheduler is free to put
+   them anywhere on a 256-thread host.  Unset: the scheduler decides. */
+static void pin_worker(int idx) {
+  const char *e;
+  int stride;
+  cpu_set_t all;
+  cpu_set_t one;
+  int c;
+  int seen;
+  e = getenv("HIPENC_PIN");
+  if (e == NULL) return;
+  stride = atoi(e);
+  if (stride < 1) return;
+  if (sched_getaffinity(0, sizeof(all), &all) != 0) return;
+  seen = 0;
+  for (c = 0; c < CPU_SETSIZE; c++) {
+    if (!CPU_ISSET(c, &all)) continue;
+    if (seen == idx*stride) {
+      CPU_ZERO(&one);
+      CPU_SET(c, &one);
+      pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+      return;
+    }
+    seen++;
+  }
+}
+
 static void *worker(void *arg) {
   job *J;
   daala_enc_ctx *enc;
   J = (job *)arg;
   memset(&T, 0, sizeof(T));
+  pthread_mutex_lock(&J->mu);
+  pin_worker(J->next_worker_id++);
+  pthread_mutex_unlock(&J->mu);
   T.check = J->p->check;
   T.time_cpu = 1;
   enc = make_encoder(J->p, J->p->pic_width, J->p->pic_height);
