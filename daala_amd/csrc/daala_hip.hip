@@ -1107,7 +1107,7 @@ int od_hip_decode_tail(od_hip_ctx *ctx, int slot0, int nslots, const int32_t *th
 
 int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out) {
   if (!x || !y || !out) return fail(OD_HIP_EFAULT, "null pointer");
-  if (n < 0 || fn < 0 || fn > 6) return fail(OD_HIP_EINVAL, "bad arguments");
+  if (n < 0 || fn < 0 || fn > 7) return fail(OD_HIP_EINVAL, "bad arguments");
   if (int rc = ensure_device()) return rc;
   if (n == 0) return 0;
   size_t nb = (size_t)n*8;

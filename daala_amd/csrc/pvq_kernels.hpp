@@ -135,6 +135,24 @@ __device__ inline double pvq_pow_2_3(double x) {
   return c0 + corr;
 }
 
+// x^(-1./6) rounded to nearest for od_compute_dist's activity factor
+// (pow(.25 + var_stat/256, -1./6), src/encode.c:1002).  Same idea as pvq_pow_2_3: seed
+// y0, then ONE Newton step whose residual 1 - x*y0^6 is evaluated in double-double
+// (y0^2 exact, cubed and multiplied by x with first-order tails: error ~1e-31), and the
+// first-order correction for the exponent being the double c = -1./6 = -1/6 + d,
+// d = 2^-55/3: x^c = x^(-1/6) * (1 + d ln x).
+__device__ inline double pvq_pow_m1_6(double x) {
+  if (!(x > 0) || x > 1e300) return pow(x, -1./6);
+  const double y0 = 1./sqrt(cbrt(x));
+  const double ph = y0*y0, pl = fma(y0, y0, -ph);                       // y0^2
+  const double qh = ph*ph, ql = fma(ph, ph, -qh) + 2*ph*pl;             // y0^4
+  const double sh = qh*ph, sl = fma(qh, ph, -sh) + qh*pl + ql*ph;       // y0^6
+  const double th = x*sh, tl = fma(x, sh, -th) + x*sl;                  // x*y0^6 ~ 1
+  const double r = (1. - th) - tl;
+  const double d = 9.251858538542970e-18;                               // 2^-55/3
+  return y0 + y0*(r*(1./6) + d*log(x));
+}
+
 // od_gain_compand (src/pvq.c:422-425).
 __device__ __forceinline__ double pvq_gain_compand(double g, int q0, double beta) {
   if (beta == 1) return g/q0;

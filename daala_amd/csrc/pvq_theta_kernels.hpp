@@ -243,7 +243,8 @@ __global__ void k_hv_intra_pred_blocks(const int32_t *__restrict__ d, int w,
 
 // Diagnostic: evaluates the transcendental functions the PVQ path uses so that
 // tests can quantify OCML vs host-libm agreement.
-// fn: 0 pow(x, y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y, 6 pvq_pow_2_3(x).
+// fn: 0 pow(x, y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y, 6 pvq_pow_2_3(x),
+// 7 pvq_pow_m1_6(x).
 __global__ void k_libm_probe(int fn, int n, const double *__restrict__ x,
                              const double *__restrict__ y, double *__restrict__ out) {
   const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -256,6 +257,7 @@ __global__ void k_libm_probe(int fn, int n, const double *__restrict__ x,
     case 3: r = cos(x[i]); break;
     case 4: r = sqrt(x[i]); break;
     case 6: r = pvq_pow_2_3(x[i]); break;
+    case 7: r = pvq_pow_m1_6(x[i]); break;
     default: r = x[i]/y[i]; break;
   }
   out[i] = r;
@@ -305,7 +307,7 @@ __global__ void k_compute_dist_blocks(int n, int nblk, const int32_t *__restrict
       double calibration, var_stat;
       if (masking) { calibration = 1.95; var_stat = 9./mean_var; }
       else { calibration = 1.62; var_stat = min_var; }
-      const double activity = calibration*pow(.25 + var_stat/(1 << 2*4), -1./6);
+      const double activity = calibration*pvq_pow_m1_6(.25 + var_stat/(1 << 2*4));
       // 8x8 fDCT of the error: columns into rows of z, then columns of z into rows
       int32_t z[64], et[64];
       for (int c = 0; c < 8; c++) {

@@ -316,7 +316,8 @@ int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coe
 
 /* Diagnostic: the device's pow/acos/sin/cos/sqrt/divide on n doubles, so tests can
  * quantify agreement with the host libm the reference uses.
- * fn: 0 pow(x,y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y. */
+ * fn: 0 pow(x,y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y, 6 the device's
+ * x^(1/1.5) (gain companding), 7 the device's x^(-1/6) (od_compute_dist activity). */
 int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out);
 
 /* Profiling aid: streams a `bytes`-sized device buffer once with the access width

@@ -77,3 +77,17 @@ def test_pow_2_3_double_double_matches_glibc():
     print('pvq_pow_2_3: identical %.5f%%, max %g ulp' % (100*frac, d.max()))
     assert d.max() <= 1 and frac >= 0.999
     assert probe(6, np.array([0.0]))[0] == 0.0
+
+
+def test_pow_m1_6_double_double_matches_glibc():
+    """pvq_pow_m1_6 (od_compute_dist's activity factor, pow(.25 + var/256, -1./6)) against
+    the host libm pow the reference calls."""
+    rng = np.random.default_rng(4)
+    n = 400000
+    x = np.concatenate([.25 + 10.0**rng.uniform(-3, 6, n), .25 + rng.integers(0, 1 << 20, n)/256.,
+                        .25 + 9./(1. + rng.integers(0, 1 << 16, n))/256.])
+    host = np.array([math.pow(a, -1./6) for a in x])
+    d = ulp_diff(probe(7, x), host)
+    frac = np.mean(d == 0)
+    print('pvq_pow_m1_6: identical %.5f%%, max %g ulp' % (100*frac, d.max()))
+    assert d.max() <= 1 and frac >= 0.998

@@ -518,15 +518,16 @@ def test_hv_intra_pred_blocks(hip):
 
 def test_compute_dist_blocks(hip):
     """od_compute_dist on the device vs the reference values in the golden fixture.
-    Everything is exact except pow(., -1/6) (OCML vs glibc, <= 1 ulp each), which
-    enters squared: relative tolerance 8 ulp."""
+    Everything is exact except pow(., -1/6): the device evaluates it in double-double
+    (pvq_pow_m1_6, 99.9 % identical to glibc, never more than 1 ulp), it enters squared:
+    relative tolerance 8 ulp, and the large majority of the sums must be identical."""
     g = golden('compute_dist.npz')
     for bs in (1, 2, 3):
         for m in (0, 1):
             d = hip.od_compute_dist_blocks(bs, g['x_%d' % bs], g['y_%d' % bs], g['mag2_%d' % bs], m)
             e = g['dist_%d_m%d' % (bs, m)]
             assert np.all(np.abs(d - e) <= 8*np.spacing(np.abs(e)))
-            assert np.mean(d == e) > 0.3
+            assert np.mean(d == e) > 0.9
 
 
 def test_pvq_lds_variant_matches_register_variant(hip, monkeypatch):
