@@ -56,7 +56,8 @@ typedef struct dec_tls {
   od_hip_ctx *ctx;          /* one-slot device context of this worker, or NULL */
   od_dct_func_2d idct_cpu[OD_NBSIZES];
   unsigned char *rec[3];    /* device output of the current frame */
-  int pinned[3];            /* rec[0..2] page-locked */
+  int pinned[6];            /* rec[0..2], stage[0..2] page-locked */
+  od_coeff *stage[3];       /* page-locked staging copies of the coefficient planes */
   long idct_skipped;
   int failed;
   double t_device;
@@ -125,7 +126,14 @@ static int device_frame(od_state *state) {
   nplanes = state->info.nplanes;
   if (od_hip_set_bsize(D.ctx, 0, state->bsize, state->bstride) != 0) return -1;
   for (pli = 0; pli < nplanes; pli++) {
-    if (od_hip_upload_coeffs(D.ctx, 0, pli, state->dtmp[pli]) != 0) return -2;
+    const od_coeff *src;
+    src = state->dtmp[pli];
+    if (D.stage[pli] != NULL) {
+      memcpy(D.stage[pli], src, sizeof(od_coeff)*(size_t)(state->frame_width >> (pli > 0))
+       *(state->frame_height >> (pli > 0)));
+      src = D.stage[pli];
+    }
+    if (od_hip_upload_coeffs(D.ctx, 0, pli, src) != 0) return -2;
     bskip[pli] = state->bskip[pli];
     quant[pli] = state->quantizer[pli];
     /* od_dering's threshold (src/filter.c:1876), host libm as in the reference */
@@ -257,6 +265,18 @@ static void *dworker(void *arg) {
       if (posix_memalign(&mem, 4096, np) != 0) mem = NULL;
       D.rec[pli] = (unsigned char *)mem;
       D.pinned[pli] = mem != NULL && od_hip_host_register(mem, np) == 0;
+      /* coefficient upload: dtmp -> own page-locked staging plane -> DMA (a copy
+         straight from the reference's pageable plane goes through the runtime's
+         staging buffers in small synchronous chunks) */
+      np = (np*sizeof(od_coeff) + 4095) & ~(size_t)4095;
+      mem = NULL;
+      if (posix_memalign(&mem, 4096, np) != 0) mem = NULL;
+      D.stage[pli] = (od_coeff *)mem;
+      D.pinned[3 + pli] = mem != NULL && od_hip_host_register(mem, np) == 0;
+      if (!D.pinned[3 + pli]) {
+        free(mem);
+        D.stage[pli] = NULL;
+      }
     }
     for (i = 0; i < OD_NBSIZES; i++) {
       D.idct_cpu[i] = st->opt_vtbl.idct_2d[i];
@@ -314,6 +334,8 @@ static void *dworker(void *arg) {
   pthread_mutex_unlock(&J->mu);
   for (pli = 0; pli < 3; pli++) {
     if (D.pinned[pli]) od_hip_host_unregister(D.rec[pli]);
+    if (D.pinned[3 + pli]) od_hip_host_unregister(D.stage[pli]);
+    free(D.stage[pli]);
   }
   if (D.ctx != NULL) od_hip_ctx_destroy(D.ctx);
   for (pli = 0; pli < 3; pli++) free(D.rec[pli]);
