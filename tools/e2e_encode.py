@@ -23,12 +23,16 @@ def main():
     ap.add_argument('--ref-frames', type=int, default=2)
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--masking', type=int, default=1)
+    ap.add_argument('--size', default='1920x1080', help='picture size WxH (default: BASELINE configs[1])')
     ap.add_argument('--host-only', action='store_true', help='same driver, plain C search (no device)')
     ap.add_argument('--decode', action='store_true', help='also decode the packets (device tail vs reference)')
     args = ap.parse_args()
     import hipenc_binding as H
-    from bench import make_frames, PIC_W, PIC_H
-    frames = make_frames(args.frames, seed0=1)
+    import bench
+    PIC_W, PIC_H = (int(v) for v in args.size.split('x'))
+    if (PIC_W, PIC_H) != (bench.PIC_W, bench.PIC_H):
+        bench.FW, bench.FH = (PIC_W + 63)//64*64, (PIC_H + 63)//64*64     # generator works on padded planes
+    frames = bench.make_frames(args.frames, seed0=1)
     buf = H.pack_frames(frames, PIC_W, PIC_H)
     res = {'frames': args.frames, 'workers': args.workers, 'pic': [PIC_W, PIC_H]}
     px = PIC_W*PIC_H
