@@ -400,7 +400,10 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 2),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach/HBM_PEAK_GBS, 5),
                          'algorithmic_bytes_per_launch': alg_bytes[dom],
-                         'traffic': traffic},
+                         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE +
+                         # WRITE_SIZE, calibrated; profiles/*_traffic.json), or null
+                         'traffic': traffic['hbm_bytes_per_launch'] if traffic else None,
+                         'traffic_detail': traffic},
             'kernels': {k: {kk: round(vv, 4) if isinstance(vv, float) else vv
                             for kk, vv in v.items()} for k, v in kernels.items()},
         }
