@@ -165,3 +165,50 @@ def test_hip_encoder_odd_geometry_and_quantizers(w, h, quant, masking):
     nd0, pics0, _, _ = H.decode(prm, hdr, got, use_device=0)
     nd1, pics1, _, ds = H.decode(prm, hdr, got, use_device=1)
     assert nd0 == nf and nd1 == nf and np.array_equal(pics0, pics1)
+
+
+def _content(kind, w, h, seed):
+    rng = np.random.default_rng(seed)
+    cw, ch = (w + 1)//2, (h + 1)//2
+
+    def plane(pw, ph):
+        if kind == 'noise':
+            return rng.integers(0, 256, (ph, pw), dtype=np.uint8)
+        if kind == 'flat':
+            return np.full((ph, pw), 128 + seed % 3, np.uint8)
+        if kind == 'bilevel':        # saturated 0/255 checker of random cell size: largest coefficients
+            c = int(rng.integers(1, 9))
+            yy, xx = np.mgrid[0:ph, 0:pw]
+            return (((yy//c + xx//c) & 1)*255).astype(np.uint8)
+        if kind == 'ramp':
+            yy, xx = np.mgrid[0:ph, 0:pw]
+            return ((xx*3 + yy*2) & 255).astype(np.uint8)
+        if kind == 'sparse':         # flat with a few isolated spikes: mostly zero bands
+            p = np.full((ph, pw), 100, np.uint8)
+            idx = rng.integers(0, ph*pw, 40)
+            p.ravel()[idx] = 255
+            return p
+        raise ValueError(kind)
+    return [plane(w, h), plane(cw, ch), plane(cw, ch)]
+
+
+@pytest.mark.parametrize('kind', ['noise', 'flat', 'bilevel', 'ramp', 'sparse'])
+@pytest.mark.parametrize('quant,masking', [(5, 1), (40, 0), (160, 1)])
+def test_hip_encoder_stress_content(kind, quant, masking):
+    """Degenerate and extreme pictures (all-small-block noise, all-zero bands, saturated
+    0/255 patterns = the largest coefficients the 24-bit multiplier proof covers, isolated
+    spikes) through the live encoder seam in check mode: packets identical, every device
+    answer equal to the C search, never out of step."""
+    w, h, nf = 160, 96, 2
+    buf = H.pack_frames([_content(kind, w, h, s) for s in (1, 2)], w, h)
+    prm = H.Params(w, h, quant, 7, masking, 2, 1, 0)
+    n0, want, st0 = H.encode(prm, buf, nf)
+    n, got, st = H.encode(prm, buf, nf, use_device=1)
+    assert n == n0 and got == want
+    assert st.check_fail == 0 and st.lost_sync == 0
+    if masking == 0:
+        assert st.g2_mismatch == 0
+    hdr = H.headers(prm)
+    nd0, pics0, _, _ = H.decode(prm, hdr, got, use_device=0)
+    nd1, pics1, _, _ = H.decode(prm, hdr, got, use_device=1)
+    assert nd0 == nf and nd1 == nf and np.array_equal(pics0, pics1)
