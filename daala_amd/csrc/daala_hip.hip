@@ -146,6 +146,19 @@ struct od_hip_ctx {
   int16_t *qm_dev;                           // scratch QM (1024 int16)
   double *rsq;                               // 1/sqrt(i) table (pvq_rsqrt_tab)
   int pvq_impl = 3;                          // 3 = register-resident, 2 = LDS-resident
+  // The PVQ launches of a step (35 of them, all independent: they only read pyramid
+  // levels) go round-robin over a few side streams so that the tail of one kernel - a
+  // few waves with large K - overlaps the next kernels instead of idling the chip.
+  // They are joined back into `stream` lazily, before anything else touches the context.
+  static constexpr int NAUX = 4;
+  hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t aux_done[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t aux_dep = nullptr;
+  int naux = 3;                              // OD_HIP_PVQ_STREAMS (0: everything on `stream`); 3 measured best
+  int aux_rr = 0;
+  bool aux_pending = false;
+  hipEvent_t phase_a = nullptr;              // start of the PVQ batch in flight (timing only)
+  int16_t *qm_slots = nullptr;               // [plane][level][1024]: one QM copy per (plane, level)
   // PVQ results per (plane, level)
   PvqSoA pvq[OD_HIP_NPLANES_MAX][4];         // device SoA, all slots
   bool pvq_alloc[OD_HIP_NPLANES_MAX][4];
@@ -173,28 +186,50 @@ struct Timed {
   od_hip_ctx *ctx;
   const char *name;
   hipEvent_t a = nullptr;
-  Timed(od_hip_ctx *c, const char *n) : ctx(c), name(n) {
+  hipStream_t st;
+  Timed(od_hip_ctx *c, const char *n, hipStream_t s = nullptr) : ctx(c), name(n), st(s ? s : c->stream) {
     if (ctx->timing) {
       a = get_event(ctx);
-      if (a) (void)hipEventRecord(a, ctx->stream);
+      if (a) (void)hipEventRecord(a, st);
     }
   }
   ~Timed() {
     if (a) {
       hipEvent_t b = get_event(ctx);
       if (b) {
-        (void)hipEventRecord(b, ctx->stream);
+        (void)hipEventRecord(b, st);
         ctx->spans[name].push_back({a, b});
       }
     }
   }
 };
 
-int check_slots(od_hip_ctx *ctx, int slot0, int nslots) {
+// Joins the side streams back into ctx->stream (device-side dependency, no host wait).
+int join_aux(od_hip_ctx *ctx) {
+  if (!ctx->aux_pending) return 0;
+  for (int i = 0; i < ctx->naux; i++) {
+    HIPCHK(hipEventRecord(ctx->aux_done[i], ctx->aux[i]));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->aux_done[i], 0));
+  }
+  ctx->aux_pending = false;
+  if (ctx->phase_a) {
+    // wall time of the whole concurrent PVQ batch (the per-kernel spans overlap)
+    hipEvent_t b = get_event(ctx);
+    if (b) {
+      (void)hipEventRecord(b, ctx->stream);
+      ctx->spans["pvq_phase"].push_back({ctx->phase_a, b});
+    }
+    ctx->phase_a = nullptr;
+  }
+  return 0;
+}
+
+int check_slots(od_hip_ctx *ctx, int slot0, int nslots, bool join = true) {
   if (!ctx) return fail(OD_HIP_EFAULT, "null context");
   if (slot0 < 0 || nslots < 1 || slot0 + nslots > ctx->geo.nslots)
     return fail(OD_HIP_EINVAL, "slot range out of bounds");
   HIPCHK(hipSetDevice(ctx->device));
+  if (join) return join_aux(ctx);
   return 0;
 }
 
@@ -409,6 +444,16 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
     ok = hipGetLastError() == hipSuccess;
   }
   if (const char *e = getenv("OD_HIP_PVQ_IMPL")) ctx->pvq_impl = atoi(e);
+  if (const char *e = getenv("OD_HIP_PVQ_STREAMS")) {
+    int v = atoi(e);
+    ctx->naux = v < 0 ? 0 : v > od_hip_ctx::NAUX ? od_hip_ctx::NAUX : v;
+  }
+  for (int i = 0; ok && i < ctx->naux; i++) {
+    ok = ok && hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->aux_done[i], hipEventDisableTiming) == hipSuccess;
+  }
+  ok = ok && hipEventCreateWithFlags(&ctx->aux_dep, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipMalloc((void **)&ctx->qm_slots, 3*4*1024*sizeof(int16_t)) == hipSuccess;
   const uint16_t *tabs[4] = {CODING_TO_RASTER_4, CODING_TO_RASTER_8, CODING_TO_RASTER_16,
                              CODING_TO_RASTER_32};
   const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
@@ -431,6 +476,7 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
 void od_hip_ctx_destroy(od_hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  for (int i = 0; i < od_hip_ctx::NAUX; i++) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int p = 0; p < OD_HIP_NPLANES_MAX; p++) {
     if (ctx->pix[p]) (void)hipFree(ctx->pix[p]);
@@ -449,6 +495,12 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
   for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
   if (ctx->bsize) (void)hipFree(ctx->bsize);
   if (ctx->dflags) (void)hipFree(ctx->dflags);
+  for (int i = 0; i < od_hip_ctx::NAUX; i++) {
+    if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+    if (ctx->aux_done[i]) (void)hipEventDestroy(ctx->aux_done[i]);
+  }
+  if (ctx->aux_dep) (void)hipEventDestroy(ctx->aux_dep);
+  if (ctx->qm_slots) (void)hipFree(ctx->qm_slots);
   if (ctx->qm_dev) (void)hipFree(ctx->qm_dev);
   if (ctx->rsq) (void)hipFree(ctx->rsq);
   for (auto &kv : ctx->spans) for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -714,7 +766,7 @@ int od_hip_pvq_nblocks(od_hip_ctx *ctx, int pli, int level) {
 
 int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
                             const int16_t *qm, const int32_t *q, const double *beta) {
-  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  if (int rc = check_slots(ctx, slot0, nslots, false)) return rc;
   if (!qm || !q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
   int nblk = od_hip_pvq_nblocks(ctx, pli, level);
   if (nblk < 0) return nblk;
@@ -737,8 +789,17 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
     HIPCHK(hipMalloc((void **)&o.y, ns*ny*4));
     ctx->pvq_alloc[pli][level] = true;
   }
-  HIPCHK(hipMemcpyAsync(ctx->qm_dev + bs*1024, qm, (size_t)n*n*sizeof(int16_t),
-                        hipMemcpyHostToDevice, ctx->stream));
+  // one QM copy per (plane, level): kernels of earlier calls may still be running on the
+  // side streams when the next call uploads its table
+  int16_t *qm_d = ctx->qm_slots + ((size_t)pli*4 + level)*1024;
+  HIPCHK(hipMemcpyAsync(qm_d, qm, (size_t)n*n*sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->naux > 0) {
+    if (ctx->timing && !ctx->aux_pending && !ctx->phase_a) {
+      ctx->phase_a = get_event(ctx);
+      if (ctx->phase_a) (void)hipEventRecord(ctx->phase_a, ctx->stream);
+    }
+    HIPCHK(hipEventRecord(ctx->aux_dep, ctx->stream));   // after the pyramid + table
+  }
   a.lev = ctx->lev[pli] + ((size_t)slot0*ctx->nlev[pli] + level)*ctx->psz[pli];
   a.lev_fstride = (size_t)ctx->nlev[pli]*ctx->psz[pli];
   a.w = ctx->pw[pli];
@@ -747,7 +808,7 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
   a.nby = ctx->ph[pli]/n;
   for (int i = 0; i < a.nbands; i++) { a.q[i] = q[i]; a.beta[i] = beta[i]; }
   a.tab = ctx->tab[bs];
-  a.qm = ctx->qm_dev + bs*1024;
+  a.qm = qm_d;
   a.rec_fstride = nrec;
   a.y_fstride = ny;
   a.out.cg = o.cg + slot0*nrec;
@@ -766,11 +827,20 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
       if (a.off[b + 1] - a.off[b] == sizes[si]) a.band_list[nlist++] = b;
     }
     if (!nlist) continue;
+    hipStream_t ls = ctx->stream;
+    if (ctx->naux > 0) {
+      // OD_HIP_PVQ_ASSIGN=1: by kernel class (128 | 32 | 15+8) instead of round-robin
+      static const int by_class = getenv("OD_HIP_PVQ_ASSIGN") ? atoi(getenv("OD_HIP_PVQ_ASSIGN")) : 0;
+      const int cls = sizes[si] == 128 ? 0 : sizes[si] == 32 ? 1 : 2;
+      ls = ctx->aux[(by_class ? cls : ctx->aux_rr++) % ctx->naux];
+      HIPCHK(hipStreamWaitEvent(ls, ctx->aux_dep, 0));
+      ctx->aux_pending = true;
+    }
     switch (sizes[si]) {
-      case 15: { Timed tm(ctx, "k_pvq_noref<15>"); launch_pvq<15>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
-      case 8: { Timed tm(ctx, "k_pvq_noref<8>"); launch_pvq<8>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
-      case 32: { Timed tm(ctx, "k_pvq_noref<32>"); launch_pvq<32>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
-      default: { Timed tm(ctx, "k_pvq_noref<128>"); launch_pvq<128>(a, nlist, nblk, nslots, ctx->stream, ctx->pvq_impl, ctx->rsq); break; }
+      case 15: { Timed tm(ctx, "k_pvq_noref<15>", ls); launch_pvq<15>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
+      case 8: { Timed tm(ctx, "k_pvq_noref<8>", ls); launch_pvq<8>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
+      case 32: { Timed tm(ctx, "k_pvq_noref<32>", ls); launch_pvq<32>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
+      default: { Timed tm(ctx, "k_pvq_noref<128>", ls); launch_pvq<128>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
     }
     HIPCHK(hipGetLastError());
   }
@@ -780,6 +850,7 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
 int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
                         od_hip_pvq_band *bands, int32_t *y) {
   if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (int rc = join_aux(ctx)) return rc;
   int nblk = od_hip_pvq_nblocks(ctx, pli, level);
   if (nblk < 0) return nblk;
   if (!ctx->pvq_alloc[pli][level]) return fail(OD_HIP_EINVAL, "no PVQ results for this level");
@@ -1159,12 +1230,14 @@ int od_hip_host_unregister(void *ptr) {
 int od_hip_sync(od_hip_ctx *ctx) {
   if (!ctx) return fail(OD_HIP_EFAULT, "null context");
   HIPCHK(hipSetDevice(ctx->device));
+  if (int rc = join_aux(ctx)) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
 int od_hip_timing_reset(od_hip_ctx *ctx) {
   if (!ctx) return fail(OD_HIP_EFAULT, "null context");
+  if (int rc = join_aux(ctx)) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (auto &kv : ctx->spans) {
     for (auto &s : kv.second) { ctx->pool.push_back(s.a); ctx->pool.push_back(s.b); }
@@ -1176,6 +1249,7 @@ int od_hip_timing_reset(od_hip_ctx *ctx) {
 
 int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches, double *total_ms) {
   if (!ctx || !kernel || !launches || !total_ms) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = join_aux(ctx)) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *launches = 0;
   *total_ms = 0;

@@ -105,6 +105,7 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
     auto &L = f->lev[l];
     if (int rc = od_hip_pvq_noref_search(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
   }
+  if (int rc = join_aux(ctx)) return rc;          // the PVQ launches run on side streams
   HIPCHK(hipEventRecord(f->computed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
   for (int s = slot0; s < slot0 + nslots; s++) {
