@@ -39,7 +39,7 @@ class FeedLevel(ctypes.Structure):
     _fields_ = [('n', ctypes.c_int32), ('nbands', ctypes.c_int32), ('nblk', ctypes.c_int32),
                 ('nbx', ctypes.c_int32), ('off', ctypes.c_int32*11), ('pad', ctypes.c_int32),
                 ('cg', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P), ('cos_dist', F64P),
-                ('y', I32P)]
+                ('y', I32P), ('lev', I32P), ('lev_stride', ctypes.c_int32), ('pad2', ctypes.c_int32)]
 
 
 PVQ_BAND_DTYPE = np.dtype([('cg', 'f8'), ('g', 'f8'), ('cos_dist', 'f8', 2), ('dist', 'f8', 2),
@@ -362,7 +362,8 @@ class DaalaHip(object):
                         'qg': np.ctypeslib.as_array(v.qg, (2*nrec,)).copy(),
                         'k': np.ctypeslib.as_array(v.k, (2*nrec,)).copy(),
                         'cos_dist': np.ctypeslib.as_array(v.cos_dist, (2*nrec,)).copy(),
-                        'y': np.ctypeslib.as_array(v.y, (ny,)).copy()})
+                        'y': np.ctypeslib.as_array(v.y, (ny,)).copy(),
+                        'lev': np.ctypeslib.as_array(v.lev, self.plane_shape(0)).copy()})
         return out
 
     def set_decode_info(self, slot, dering_flags, bskip):

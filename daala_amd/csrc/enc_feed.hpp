@@ -8,6 +8,7 @@ struct od_hip_enc_feed {
   od_hip_ctx *ctx = nullptr;
   hipStream_t copy = nullptr;
   hipEvent_t computed = nullptr;
+  hipEvent_t transformed = nullptr;       // forward pyramid done (the level planes can be copied)
   std::vector<hipEvent_t> ready;          // one per slot
   std::vector<char> pending;              // slot has a copy in flight / landed
   struct Lev {
@@ -20,6 +21,7 @@ struct od_hip_enc_feed {
     // pinned host mirrors, all slots: [slot][...]
     int32_t *ncand = nullptr, *k = nullptr, *qg = nullptr, *y = nullptr;
     double *cos_dist = nullptr, *cg = nullptr;
+    od_coeff *plane = nullptr;            // [slot][h][w] the pyramid level itself
   } lev[4];
 };
 
@@ -36,9 +38,11 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
     if (l.cg) (void)hipHostFree(l.cg);
     if (l.y) (void)hipHostFree(l.y);
     if (l.cos_dist) (void)hipHostFree(l.cos_dist);
+    if (l.plane) (void)hipHostFree(l.plane);
   }
   for (auto e : f->ready) if (e) (void)hipEventDestroy(e);
   if (f->computed) (void)hipEventDestroy(f->computed);
+  if (f->transformed) (void)hipEventDestroy(f->transformed);
   if (f->copy) (void)hipStreamDestroy(f->copy);
   delete f;
 }
@@ -51,6 +55,7 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
   size_t ns = ctx->geo.nslots;
   bool ok = hipStreamCreateWithFlags(&f->copy, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&f->computed, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&f->transformed, hipEventDisableTiming) == hipSuccess;
   f->ready.assign(ns, nullptr);
   f->pending.assign(ns, 0);
   for (size_t s = 0; ok && s < ns; s++)
@@ -71,6 +76,7 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
     ok = ok && hipHostMalloc((void **)&L.cg, ns*L.nrec*8) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.cos_dist, ns*2*L.nrec*8) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.y, ns*L.ny*4) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.plane, ns*ctx->psz[0]*sizeof(od_coeff)) == hipSuccess;
   }
   if (!ok) {
     fail(OD_HIP_ENODEV, "encoder feed allocation failed");
@@ -101,6 +107,16 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
     if (f->pending[s]) HIPCHK(hipEventSynchronize(f->ready[s]));
   }
   if (int rc = od_hip_forward_pyramid(ctx, slot0, nslots)) return rc;
+  // the level planes are final here: their copies overlap the PVQ searches
+  HIPCHK(hipEventRecord(f->transformed, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(f->copy, f->transformed, 0));
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    for (int l = 0; l < 4; l++) {
+      HIPCHK(hipMemcpyAsync(f->lev[l].plane + (size_t)s*ctx->psz[0],
+                            ctx->lev[0] + ((size_t)s*ctx->nlev[0] + l)*ctx->psz[0],
+                            ctx->psz[0]*sizeof(od_coeff), hipMemcpyDeviceToHost, f->copy));
+    }
+  }
   for (int l = 0; l < 4; l++) {
     auto &L = f->lev[l];
     if (int rc = od_hip_pvq_noref_search(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
@@ -146,6 +162,9 @@ int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4])
     v.cg = L.cg + slot*L.nrec;
     v.cos_dist = L.cos_dist + slot*2*L.nrec;
     v.y = L.y + slot*L.ny;
+    v.lev = L.plane + (size_t)slot*f->ctx->psz[0];
+    v.lev_stride = f->ctx->pw[0];
+    v.pad2 = 0;
   }
   return 0;
 }

@@ -60,6 +60,8 @@ typedef struct glue_tls {
   int check;
   int time_cpu;
   int pli;                        /* plane of the block being coded */
+  daala_enc_ctx *enc;             /* encoder of the frame being coded by this thread */
+  od_dct_func_2d fdct_cpu[OD_NBSIZES];   /* the context's own fdct_2d entries */
   od_hipenc_stats st;
 } glue_tls;
 
@@ -143,6 +145,69 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
   }
   return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
 }
+
+/* fdct_2d entries of the worker's vtable (struct od_state_opt_vtbl, src/state.h:106).
+   For keyframe luma every forward transform the encoder asks for - od_block_encode in
+   the block-size RDO pass (src/encode.c:1139) and od_compute_dcts (:1308) - has the
+   lapped picture + the split filters of its ancestors as input and writes into the
+   dtmp[0] plane at the block's position: exactly one block of the device's forward
+   pyramid, which the feed carries.  Anything else (chroma, od_compute_dist's 8x8
+   error transform into a stack buffer) runs the context's C transform. */
+static void fdct_from_feed(int bs, od_coeff *y, int ystride, const od_coeff *x,
+ int xstride) {
+  if (T.lev != NULL && T.enc != NULL && T.enc->state.frame_type == OD_I_FRAME) {
+    const od_state *st;
+    od_coeff *d0;
+    int w;
+    int h;
+    st = &T.enc->state;
+    d0 = st->dtmp[0];
+    w = st->frame_width;
+    h = st->frame_height;
+    if (ystride == w && y >= d0 && y < d0 + (size_t)w*h) {
+      const od_hip_feed_level *L;
+      size_t off;
+      int n;
+      int yy;
+      int xx;
+      off = (size_t)(y - d0);
+      yy = (int)(off/w);
+      xx = (int)(off%w);
+      n = 4 << bs;
+      L = &T.lev[3 - bs];
+      if (L->lev != NULL && L->n == n && (yy & (n - 1)) == 0 && (xx & (n - 1)) == 0) {
+        const od_coeff *src;
+        int i;
+        src = L->lev + (size_t)yy*L->lev_stride + xx;
+        if (T.check) {
+          od_coeff tmp[32*32];
+          (*T.fdct_cpu[bs])(tmp, n, x, xstride);
+          for (i = 0; i < n; i++) {
+            if (memcmp(tmp + i*n, src + (size_t)i*L->lev_stride, sizeof(od_coeff)*n) != 0) {
+              T.st.fdct_check_fail++;
+              break;
+            }
+          }
+        }
+        for (i = 0; i < n; i++) {
+          memcpy(y + (size_t)i*ystride, src + (size_t)i*L->lev_stride, sizeof(od_coeff)*n);
+        }
+        T.st.fdct_hits++;
+        return;
+      }
+    }
+  }
+  (*T.fdct_cpu[bs])(y, ystride, x, xstride);
+}
+
+#define FDCT_HOOK(name, bs) \
+  static void name(od_coeff *y, int ystride, const od_coeff *x, int xstride) { \
+    fdct_from_feed(bs, y, ystride, x, xstride); \
+  }
+FDCT_HOOK(hook_fdct4, 0)
+FDCT_HOOK(hook_fdct8, 1)
+FDCT_HOOK(hook_fdct16, 2)
+FDCT_HOOK(hook_fdct32, 3)
 
 int od_pvq_encode(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out,
  int q0, int pli, int bs, const double *beta, int robust, int is_keyframe,
@@ -332,6 +397,8 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->lost_sync += b->lost_sync;
   a->check_fail += b->check_fail;
   a->search_cpu_s += b->search_cpu_s;
+  a->fdct_hits += b->fdct_hits;
+  a->fdct_check_fail += b->fdct_check_fail;
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
@@ -373,6 +440,7 @@ static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
     enc->state.ref_imgi[OD_FRAME_PREV] = 0;
   }
   fill_img(&img, J->frames + J->frame_bytes*f, J->p->pic_width, J->p->pic_height);
+  T.enc = enc;
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
   J->pkt_len[f] = 0;
   while (daala_encode_packet_out(enc, 0, &dp) > 0) {
@@ -389,6 +457,7 @@ static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
     J->pkt_len[f] += 4 + dp.bytes;
   }
   T.lev = NULL;
+  T.enc = NULL;
   return 0;
 }
 
@@ -432,6 +501,15 @@ static void *worker(void *arg) {
   T.check = J->p->check;
   T.time_cpu = 1;
   enc = make_encoder(J->p, J->p->pic_width, J->p->pic_height);
+  if (enc != NULL) {
+    static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
+     hook_fdct32};
+    int i;
+    for (i = 0; i < OD_NBSIZES; i++) {
+      T.fdct_cpu[i] = enc->state.opt_vtbl.fdct_2d[i];
+      enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
+    }
+  }
   pthread_mutex_lock(&J->mu);
   if (enc == NULL) J->failed = 1;
   J->encoders_ready++;
@@ -500,10 +578,10 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   J.batch = p->batch > 0 && p->batch < nframes ? p->batch : nframes;
   if (p->batch <= 0) {
     /* default: everything at once, but keep the pinned host mirror of the feed
-       (about 33 bytes per padded luma sample and frame) under ~6 GB */
+       (about 49 bytes per padded luma sample and frame: records + pyramid) under ~6 GB */
     double per_frame;
     int cap;
-    per_frame = 33.*((p->pic_width + 63) & ~63)*((p->pic_height + 63) & ~63);
+    per_frame = 49.*((p->pic_width + 63) & ~63)*((p->pic_height + 63) & ~63);
     cap = (int)(6e9/per_frame);
     if (cap < 2*nw) cap = 2*nw;
     /* longer streams: two half-buffers of cap/2 frames, batch k+1 is computed and

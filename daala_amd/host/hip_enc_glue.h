@@ -33,6 +33,8 @@ typedef struct od_hipenc_stats {
   int64_t check_fail;      /* check mode: device answer != C answer (must be 0) */
   double search_cpu_s;     /* seconds inside the C pvq_search_rdo_double, all workers */
   double search_class_s[4];/* ... split: luma no-ref, luma with-ref, chroma no-ref, chroma with-ref */
+  int64_t fdct_hits;       /* luma fdct_2d calls answered from the device pyramid */
+  int64_t fdct_check_fail; /* check mode: device block != C transform (must be 0) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* enqueue of the device batch, wall */

@@ -253,6 +253,13 @@ typedef struct od_hip_feed_level {
   const int32_t *k;         /* [2][nbands*nblk] */
   const double *cos_dist;   /* [2][nbands*nblk] return value of the search */
   const int32_t *y;         /* pulses, see above */
+  /* The level's plane of the forward pyramid itself (od_hip_forward_pyramid): the fDCT of
+     every n x n block of the lapped picture, i.e. what fdct_2d produces at
+     src/encode.c:1139 (block-size RDO pass) and :1308 (od_compute_dcts) for luma.
+     Row-major, `lev_stride` elements per row, block (bx, by) at lev + by*n*lev_stride + bx*n. */
+  const od_coeff *lev;
+  int32_t lev_stride;
+  int32_t pad2;
 } od_hip_feed_level;
 
 od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx);

@@ -52,6 +52,7 @@ class Stats(ctypes.Structure):
                 ('cpu_other', ctypes.c_int64), ('g2_mismatch', ctypes.c_int64),
                 ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
                 ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
+                ('fdct_hits', ctypes.c_int64), ('fdct_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_total_s', ctypes.c_double)]
@@ -66,7 +67,8 @@ class FeedLevel(ctypes.Structure):
     _fields_ = [('n', c_int32), ('nbands', c_int32), ('nblk', c_int32), ('nbx', c_int32),
                 ('off', c_int32*11), ('pad', c_int32),
                 ('cg', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P),
-                ('cos_dist', F64P), ('y', I32P)]
+                ('cos_dist', F64P), ('y', I32P), ('lev', I32P), ('lev_stride', c_int32),
+                ('pad2', c_int32)]
 
 
 _lib = None

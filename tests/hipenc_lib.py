@@ -49,6 +49,8 @@ class OracleFeed:
                 v.off[i] = x
             v.cg, v.ncand, v.qg, v.k = pf64(a['cg']), p32(a['ncand']), p32(a['qg']), p32(a['k'])
             v.cos_dist, v.y = pf64(a['cos_dist']), p32(a['y'])
+            v.lev, v.lev_stride = p32(lev[l]), fw
+            a['lev'] = lev[l]
             self.levels.append(v)
             self.keep.append(a)
 

@@ -49,6 +49,7 @@ def test_device_feed_equals_oracle_feed(masking):
     for l in range(4):
         a, g = want.keep[l], got[l]
         nrec = g['nbands']*g['nblk']
+        assert np.array_equal(a['lev'], g['lev']), ('pyramid plane', l)
         assert np.array_equal(a['ncand'], g['ncand'])
         assert np.array_equal(a['cg'].view(np.int64), g['cg'].view(np.int64)) or masking == 1
         if masking == 1:   # beta = 1.5: libm pow on the host, DESIGN.md section 5
@@ -84,6 +85,7 @@ def test_hip_encoder_packets_identical_cif(masking):
     assert n > 0, n
     assert got == want
     assert st.dev_hits > 0 and st.check_fail == 0 and st.lost_sync == 0
+    assert st.fdct_hits > 0 and st.fdct_check_fail == 0
     if masking == 0:
         assert st.g2_mismatch == 0
 
@@ -205,7 +207,7 @@ def test_hip_encoder_stress_content(kind, quant, masking):
     n0, want, st0 = H.encode(prm, buf, nf)
     n, got, st = H.encode(prm, buf, nf, use_device=1)
     assert n == n0 and got == want
-    assert st.check_fail == 0 and st.lost_sync == 0
+    assert st.check_fail == 0 and st.lost_sync == 0 and st.fdct_check_fail == 0
     if masking == 0:
         assert st.g2_mismatch == 0
     hdr = H.headers(prm)

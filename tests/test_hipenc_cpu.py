@@ -54,6 +54,8 @@ def test_oracle_feed_gives_identical_packets(masking):
     assert got == want
     assert st.check_fail == 0 and st.lost_sync == 0 and st.g2_mismatch == 0
     assert st.dev_hits > 50000
+    # every luma forward transform of both passes came from the feed's pyramid
+    assert st.fdct_hits > 30000 and st.fdct_check_fail == 0
 
 
 def test_corrupt_feed_is_detected_not_trusted():
@@ -67,6 +69,18 @@ def test_corrupt_feed_is_detected_not_trusted():
     view.keep[1]['k'][::7] += 1
     n, got, st = H.encode(prm, buf, 1, [view])
     assert got == want and st.lost_sync > 0
+
+
+def test_corrupt_pyramid_is_caught_by_check_mode():
+    """The transform coefficients are taken from the feed without an independent host
+    value (unlike K): the OD_CHECKASM-style check mode is what catches a wrong pyramid."""
+    w, h = 352, 288
+    buf = setup_frames(w, h, [3])
+    prm = H.Params(w, h, 20, 7, 0, 1, 1, 0)
+    view = H.OracleFeed(prm, H.pad_frame(prm, buf)[0])
+    view.keep[2]['lev'][40, 72] += 1
+    n, got, st = H.encode(prm, buf, 1, [view])
+    assert st.fdct_check_fail > 0
 
 
 def test_no_device_is_loud():
