@@ -368,10 +368,19 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   J.device = device;
   J.pkt = (const unsigned char **)calloc(nframes, sizeof(*J.pkt));
   J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
+  if (J.pkt == NULL || J.pkt_len == NULL) {
+    free(J.pkt);
+    free(J.pkt_len);
+    return OD_HIP_EFAULT;
+  }
   o = 0;
   for (i = 0; i < nframes; i++) {
     long n;
-    if (o + 4 > pkt_bytes) return OD_HIP_EINVAL;
+    if (o + 4 > pkt_bytes) {
+      free(J.pkt);
+      free(J.pkt_len);
+      return OD_HIP_EINVAL;
+    }
     n = pkts[o] | pkts[o + 1] << 8 | pkts[o + 2] << 16 | (long)pkts[o + 3] << 24;
     J.pkt[i] = pkts + o + 4;
     J.pkt_len[i] = n;
@@ -380,6 +389,11 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   nw = p->nworkers < 1 ? 1 : p->nworkers;
   if (nw > nframes) nw = nframes;
   th = (pthread_t *)calloc(nw, sizeof(*th));
+  if (th == NULL) {
+    free(J.pkt);
+    free(J.pkt_len);
+    return OD_HIP_EFAULT;
+  }
   pthread_mutex_init(&J.mu, NULL);
   pthread_cond_init(&J.cv, NULL);
   for (i = 0; i < nw; i++) pthread_create(&th[i], NULL, dworker, &J);

@@ -594,11 +594,16 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
      completely coded. */
   J.nslots = J.batch >= nframes ? nframes : 2*J.batch;
   J.done = (unsigned char *)calloc(nframes, 1);
-  if (J.done == NULL) return OD_HIP_EFAULT;
   J.pkt = (unsigned char **)calloc(nframes, sizeof(*J.pkt));
   J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
   th = (pthread_t *)calloc(nw, sizeof(*th));
-  if (J.pkt == NULL || J.pkt_len == NULL || th == NULL) return OD_HIP_EFAULT;
+  if (J.done == NULL || J.pkt == NULL || J.pkt_len == NULL || th == NULL) {
+    free(J.done);
+    free(J.pkt);
+    free(J.pkt_len);
+    free(th);
+    return OD_HIP_EFAULT;
+  }
   pthread_mutex_init(&J.mu, NULL);
   pthread_cond_init(&J.cv, NULL);
   t_setup0 = now_s();
@@ -619,13 +624,20 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
     g.xdec[1] = g.xdec[2] = 1;
     g.nslots = J.nslots;
     J.ctx = od_hip_ctx_create(device, &g);
-    if (J.ctx == NULL) return OD_HIP_ENODEV;
-    J.feed = od_hip_enc_feed_create(J.ctx);
-    if (J.feed == NULL) {
-      od_hip_ctx_destroy(J.ctx);
-      return OD_HIP_ENODEV;
+    if (J.ctx != NULL) J.feed = od_hip_enc_feed_create(J.ctx);
+    if (J.ctx == NULL || J.feed == NULL || od_hipenc_level_params(p, qm, q, beta) != 0) {
+      long rc;
+      rc = J.ctx == NULL || J.feed == NULL ? OD_HIP_ENODEV : OD_HIP_EINVAL;
+      if (J.feed != NULL) od_hip_enc_feed_destroy(J.feed);
+      if (J.ctx != NULL) od_hip_ctx_destroy(J.ctx);
+      free(J.done);
+      free(J.pkt);
+      free(J.pkt_len);
+      free(th);
+      pthread_mutex_destroy(&J.mu);
+      pthread_cond_destroy(&J.cv);
+      return rc;
     }
-    if (od_hipenc_level_params(p, qm, q, beta) != 0) return OD_HIP_EINVAL;
     for (l = 0; l < 4; l++) od_hip_enc_feed_set_level(J.feed, l, qm[l], q[l], beta[l]);
   }
   for (i = 0; i < nw; i++) pthread_create(&th[i], NULL, worker, &J);
