@@ -174,6 +174,19 @@ def od_resample_luma_coeffs_420(luma, lstride, offsets, bs, chroma_bs):
     return pred
 
 
+def od_resample_luma_coeffs(luma, lstride, offsets, bs, chroma_bs, xdec, ydec):
+    """od_resample_luma_coeffs (src/intra.c:72) for any chroma decimation."""
+    luma = _c32(luma).ravel()
+    off = np.ascontiguousarray(offsets, dtype=np.int32)
+    n = 4 << bs
+    pred = np.empty((len(off), n, n), np.int32)
+    load().od_hip_resample_luma.argtypes = [I32P, I32P, ctypes.c_size_t, c_int, I32P, c_int, c_int,
+                                            c_int, c_int, c_int]
+    _chk(load().od_hip_resample_luma(_p32(pred), _p32(luma), luma.size, lstride, _p32(off),
+                                     len(off), bs, chroma_bs, xdec, ydec))
+    return pred
+
+
 def vtable_call(name, out, ostride, inp, istride):
     """Call one of the od_dct_func_2d drop-ins on (possibly aliasing) host arrays."""
     getattr(load(), name)(_p32(out), ostride, _p32(inp), istride)

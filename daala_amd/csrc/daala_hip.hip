@@ -363,9 +363,20 @@ int od_hip_filter_vectors(int n, int inverse, od_coeff *out, const od_coeff *in,
 int od_hip_resample_luma_420(od_coeff *pred, const od_coeff *luma, size_t luma_len,
                              int lstride, const int32_t *luma_off, int nblk, int bs,
                              int chroma_bs) {
+  return od_hip_resample_luma(pred, luma, luma_len, lstride, luma_off, nblk, bs, chroma_bs, 1, 1);
+}
+
+int od_hip_resample_luma(od_coeff *pred, const od_coeff *luma, size_t luma_len,
+                         int lstride, const int32_t *luma_off, int nblk, int bs,
+                         int chroma_bs, int xdec, int ydec) {
   if (!pred || !luma || !luma_off) return fail(OD_HIP_EFAULT, "null pointer");
-  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblk < 0 || (chroma_bs == 0 && bs != 0))
-    return fail(OD_HIP_EINVAL, "bad block size");
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblk < 0 || (chroma_bs == 0 && bs != 0) ||
+      xdec < 0 || xdec > 1 || ydec < 0 || ydec > 1)
+    return fail(OD_HIP_EINVAL, "bad block size / decimation");
+  // without decimation the chroma block is a plain copy whatever chroma_bs says
+  // (src/intra.c:76: the TF merge only happens for a decimated plane)
+  if (!xdec && !ydec && chroma_bs == 0) chroma_bs = 1;
+  const int mode = xdec && ydec ? 0 : xdec ? 1 : 2;
   if (int rc = ensure_device()) return rc;
   if (nblk == 0) return 0;
   size_t n = 4u << bs, obytes = (size_t)nblk*n*n*sizeof(int32_t);
@@ -377,7 +388,7 @@ int od_hip_resample_luma_420(od_coeff *pred, const od_coeff *luma, size_t luma_l
   long total = (long)nblk*n*n;
   hipLaunchKernelGGL(k_resample_luma_420, dim3((total + 255)/256), dim3(256), 0, 0,
                      (int32_t *)g_out.p, (const int32_t *)g_in.p, lstride,
-                     (const int32_t *)g_aux0.p, nblk, bs, chroma_bs);
+                     (const int32_t *)g_aux0.p, nblk, bs, chroma_bs, mode);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(pred, g_out.p, obytes, hipMemcpyDeviceToHost));
   return 0;

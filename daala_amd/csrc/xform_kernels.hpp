@@ -282,9 +282,11 @@ __global__ __launch_bounds__(SB*SB/4) void k_postfilter_clamp(PostArgs a) {
 
 // CfL luma resample for 4:2:0 (src/intra.c:72-109).  One thread per output
 // coefficient.  chroma_bs==0: 2x2 TF merge of four 4x4 luma blocks + scaling.
+// mode: 0 = 4:2:0 (od_tf_up_hv_lp + CfL scaling), 1 = horizontally decimated chroma
+// (od_tf_up_h_lp, src/tf.c:38-58), 2 = vertically decimated (od_tf_up_v_lp, :60-80).
 __global__ void k_resample_luma_420(int32_t *__restrict__ pred, const int32_t *__restrict__ luma,
                                     int lstride, const int32_t *__restrict__ luma_off,
-                                    int nblk, int bs, int chroma_bs) {
+                                    int nblk, int bs, int chroma_bs, int mode) {
   const int n = 4 << bs;
   long e = (long)blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= (long)nblk*n*n) return;
@@ -292,6 +294,24 @@ __global__ void k_resample_luma_420(int32_t *__restrict__ pred, const int32_t *_
   const int32_t *src = luma + luma_off[b];
   if (chroma_bs != 0) {
     pred[e] = src[y*lstride + x];
+    return;
+  }
+  if (mode == 1) {
+    // pair (ll, lh) = src[y][xx], src[y][xx + n]; lh = ll - lh; ll -= LIFT_HALF(lh);
+    // outputs at 2*xx + sw (ll) and 2*xx + 1 - sw (lh), sw = xx & 1
+    const int xx = x >> 1;
+    int32_t ll = src[y*lstride + xx], lh = src[y*lstride + xx + n];
+    lh = ll - lh;
+    ll -= LIFT_HALF(lh);
+    pred[e] = (((x & 1) ^ (xx & 1)) == 0) ? ll : lh;
+    return;
+  }
+  if (mode == 2) {
+    const int yy = y >> 1;
+    int32_t ll = src[yy*lstride + x], hl = src[(yy + n)*lstride + x];
+    hl = ll - hl;
+    ll -= LIFT_HALF(hl);
+    pred[e] = (((y & 1) ^ (yy & 1)) == 0) ? ll : hl;
     return;
   }
   // od_tf_up_hv_lp(dst, src, dx=n, dy=n, n): output (oy,ox) comes from the 2x2

@@ -95,6 +95,12 @@ int od_hip_filter_vectors(int n, int inverse, od_coeff *out, const od_coeff *in,
  * reference: 0 => TF-merge of the 2x2 group of 4x4 luma blocks. */
 int od_hip_resample_luma_420(od_coeff *pred, const od_coeff *luma, size_t luma_len,
  int lstride, const int32_t *luma_off, int nblk, int bs, int chroma_bs);
+/* The same for any chroma decimation (xdec, ydec in {0,1}): od_tf_up_hv_lp for 4:2:0,
+ * od_tf_up_h_lp (src/tf.c:38-58) for horizontally decimated chroma (4:2:2),
+ * od_tf_up_v_lp (:60-80) for vertically decimated chroma (4:4:0), a copy for 4:4:4. */
+int od_hip_resample_luma(od_coeff *pred, const od_coeff *luma, size_t luma_len,
+ int lstride, const int32_t *luma_off, int nblk, int bs, int chroma_bs, int xdec,
+ int ydec);
 
 /* ---------------------------------------------------------------------------
  * 3. Device-resident frame pipeline.  A context owns the HBM buffers of

@@ -571,3 +571,24 @@ def test_filters_8_16_32(hip):
     g4 = golden('filter_vectors.npz')
     assert np.array_equal(b.od_filter_vectors(4, g4['x']), g4['pre'])
     assert np.array_equal(b.od_filter_vectors(4, g4['x'], inverse=True), g4['post'])
+
+
+def test_cfl_resample_other_decimations(hip):
+    """od_resample_luma_coeffs for 4:2:2 (od_tf_up_h_lp), 4:4:0 (od_tf_up_v_lp), 4:4:4."""
+    import daala_amd.binding as b
+    g = golden('cfl_decimations.npz')
+    luma = g['luma']
+    for xdec, ydec in ((1, 0), (0, 1), (0, 0)):
+        for bs, cbs in ((0, 0), (1, 1), (2, 2)):
+            p = b.od_resample_luma_coeffs(luma, 64, [0], bs, cbs, xdec, ydec)
+            assert np.array_equal(p[0], g['p_%d%d_%d_%d' % (xdec, ydec, bs, cbs)]), (xdec, ydec, bs)
+    # many blocks at several offsets against the oracle, 4:2:2 and 4:4:0
+    o = oracle()
+    offs = [(y*8)*64 + x*4 for y in range(3) for x in range(7)]
+    for xdec, ydec in ((1, 0), (0, 1)):
+        p = b.od_resample_luma_coeffs(luma, 64, offs, 0, 0, xdec, ydec)
+        for i, off in enumerate(offs):
+            e = np.zeros((4, 4), np.int32)
+            o.orc_resample_luma_coeffs(p32(e), 4, p32(np.ascontiguousarray(luma.ravel()[off:])), 64,
+                                       xdec, ydec, 0, 0)
+            assert np.array_equal(p[i], e), (xdec, ydec, i)

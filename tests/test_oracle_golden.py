@@ -190,3 +190,16 @@ def test_filters_8_16_32_against_reference_vectors():
             assert np.array_equal(z, x)
             o.orc_post_filter_n(n, p32(y), p32(x))
             assert np.array_equal(y, b)
+
+
+def test_cfl_resample_other_decimations():
+    """A9 for 4:2:2 / 4:4:0 / 4:4:4 chroma: oracle == reference vectors."""
+    o = oracle()
+    g = load('cfl_decimations.npz')
+    luma = np.ascontiguousarray(g['luma'])
+    for xdec, ydec in ((1, 0), (0, 1), (0, 0)):
+        for bs, cbs in ((0, 0), (1, 1), (2, 2)):
+            n = 4 << bs
+            b = np.zeros((n, n), np.int32)
+            o.orc_resample_luma_coeffs(p32(b), n, p32(luma), 64, xdec, ydec, bs, cbs)
+            assert np.array_equal(b, g['p_%d%d_%d_%d' % (xdec, ydec, bs, cbs)]), (xdec, ydec, bs)

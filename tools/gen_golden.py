@@ -89,6 +89,20 @@ def filter_n_vectors():
     np.savez_compressed(os.path.join(G, 'filter_n_vectors.npz'), **out)
 
 
+def cfl_decimations():
+    """od_resample_luma_coeffs (src/intra.c:72) for the chroma decimations other than
+    4:2:0: 4:2:2 (od_tf_up_h_lp), 4:4:0 (od_tf_up_v_lp), 4:4:4 (copy)."""
+    luma = rng.integers(-3000, 3001, size=(32, 64), dtype=np.int32)
+    out = {'luma': luma}
+    for xdec, ydec in ((1, 0), (0, 1), (0, 0)):
+        for bs, cbs in ((0, 0), (1, 1), (2, 2)):
+            n = 4 << bs
+            b = np.zeros((n, n), np.int32)
+            r.od_resample_luma_coeffs(p32(b), n, p32(luma), 64, xdec, ydec, bs, cbs)
+            out['p_%d%d_%d_%d' % (xdec, ydec, bs, cbs)] = b
+    np.savez_compressed(os.path.join(G, 'cfl_decimations.npz'), **out)
+
+
 def plane_forward():
     pic_w, pic_h, fw, fh = 150, 100, 192, 128     # reference pads to multiples of 64
     nhsb, nvsb = fw//32, fh//32
@@ -257,6 +271,7 @@ if __name__ == '__main__':
     dct_vectors()
     filter_vectors()
     filter_n_vectors()
+    cfl_decimations()
     plane_forward()
     pvq_vectors()
     encoder_params()
