@@ -90,3 +90,20 @@ def test_cli_without_device_fails_loudly(tmp_path):
     with pytest.raises(SystemExit) as e:
         cli.main(['encode', y4m, str(tmp_path/'o.dhip'), '--workers', '1'])
     assert 'no HIP device' in str(e.value)
+
+
+@pytest.mark.gpu
+@needs
+def test_cli_device_path_equals_host_path(tmp_path):
+    """Y4M -> stream -> Y4M through the CLI with the device (feed + decoder tail) and with
+    --no-device: identical stream bytes, identical decoded pictures."""
+    w, h = 320, 176
+    y4m = str(tmp_path/'in.y4m')
+    write_clip(y4m, w, h, 4)
+    a, b_, pa, pb = (str(tmp_path/n) for n in ('a.dhip', 'b.dhip', 'a.y4m', 'b.y4m'))
+    cli.main(['encode', y4m, a, '-v', '20', '--workers', '2'])
+    cli.main(['encode', y4m, b_, '-v', '20', '--workers', '2', '--no-device'])
+    assert open(a, 'rb').read() == open(b_, 'rb').read()
+    cli.main(['decode', a, pa, '--workers', '2'])
+    cli.main(['decode', a, pb, '--workers', '2', '--no-device'])
+    assert open(pa, 'rb').read() == open(pb, 'rb').read()
