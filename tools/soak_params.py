@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Parameter sweep of the live encoder/decoder seams in check mode (GPU box): quantizers,
+activity masking, several picture sizes and seeds; every device answer is compared with
+the C search/transform, packets with the plain reference, pictures with the reference
+decoder.  Exit code 1 on any difference."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    import hipenc_binding as H
+    from testlib import synth_plane
+    bad = 0
+    total = dict(dev_hits=0, g2=0, fdct=0)
+    cases = [(1280, 720, q, m, s) for q in (3, 10, 20, 45, 100, 250) for m in (0, 1) for s in (0,)]
+    cases += [(w, h, 20, 1, 7) for (w, h) in ((1920, 1080), (720, 576), (854, 480), (98, 50))]
+    for (w, h, q, m, seed) in cases:
+        cw, ch = (w + 1)//2, (h + 1)//2
+        nf = 4
+        fr = [[synth_plane(w, h, seed + f), synth_plane(cw, ch, seed + f, 1), synth_plane(cw, ch, seed + f + 1, 1)]
+              for f in range(nf)]
+        buf = H.pack_frames(fr, w, h)
+        prm = H.Params(w, h, q, 7, m, 4, 1, 0)
+        n0, want, _ = H.encode(prm, buf, nf)
+        n, got, st = H.encode(prm, buf, nf, use_device=1)
+        hdr = H.headers(prm)
+        _, p0, _, _ = H.decode(prm, hdr, want)
+        _, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
+        ok = (n == n0 and got == want and st.check_fail == 0 and st.lost_sync == 0
+              and st.fdct_check_fail == 0 and np.array_equal(p0, p1))
+        total['dev_hits'] += st.dev_hits
+        total['g2'] += st.g2_mismatch
+        total['fdct'] += st.fdct_hits
+        print('%4dx%-4d q=%-3d masking=%d: %s  (hits %d, g2 %d, fdct %d, bytes %d)'
+              % (w, h, q, m, 'ok' if ok else 'MISMATCH', st.dev_hits, st.g2_mismatch, st.fdct_hits, n),
+              flush=True)
+        bad += not ok
+    print('total', total)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
