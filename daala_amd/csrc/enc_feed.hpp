@@ -170,3 +170,108 @@ int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4])
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Encoder-side deringing (include/daala_hip.h section 4c): a small per-worker object -
+// own stream, page-locked staging, three int32 input planes and three int16 output
+// planes on the device - that runs od_dering() for EVERY superblock of one frame in one
+// launch of k_decode_tail's encoder mode.
+struct od_hip_dering {
+  int device = 0, fw = 0, fh = 0, nplanes = 0, xdec[3] = {0, 0, 0};
+  hipStream_t stream = nullptr;
+  size_t psz[3] = {0, 0, 0};
+  int16_t *d_in[3] = {nullptr, nullptr, nullptr};
+  int16_t *d_out[3] = {nullptr, nullptr, nullptr};
+  uint8_t *d_bskip[3] = {nullptr, nullptr, nullptr};
+  int16_t *h_in[3] = {nullptr, nullptr, nullptr};      // pinned
+  int16_t *h_out[3] = {nullptr, nullptr, nullptr};     // pinned
+};
+
+extern "C" {
+
+void od_hip_dering_destroy(od_hip_dering *d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  for (int p = 0; p < 3; p++) {
+    if (d->d_in[p]) (void)hipFree(d->d_in[p]);
+    if (d->d_out[p]) (void)hipFree(d->d_out[p]);
+    if (d->d_bskip[p]) (void)hipFree(d->d_bskip[p]);
+    if (d->h_in[p]) (void)hipHostFree(d->h_in[p]);
+    if (d->h_out[p]) (void)hipHostFree(d->h_out[p]);
+  }
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+od_hip_dering *od_hip_dering_create(int device, int frame_width, int frame_height, int nplanes,
+                                    const int *xdec) {
+  if (!xdec || nplanes < 1 || nplanes > 3 || frame_width <= 0 || frame_height <= 0 ||
+      frame_width%32 || frame_height%32) {
+    fail(OD_HIP_EINVAL, "invalid geometry");
+    return nullptr;
+  }
+  if (ensure_device()) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) { fail(OD_HIP_ENODEV, "hipSetDevice failed"); return nullptr; }
+  od_hip_dering *d = new od_hip_dering();
+  d->device = device;
+  d->fw = frame_width;
+  d->fh = frame_height;
+  d->nplanes = nplanes;
+  bool ok = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess;
+  for (int p = 0; ok && p < nplanes; p++) {
+    d->xdec[p] = xdec[p];
+    d->psz[p] = (size_t)(frame_width >> xdec[p])*(frame_height >> xdec[p]);
+    const size_t nsk = (size_t)(frame_width/4)*(frame_height/4);
+    ok = ok && hipMalloc((void **)&d->d_in[p], d->psz[p]*2) == hipSuccess;
+    ok = ok && hipMalloc((void **)&d->d_out[p], d->psz[p]*2) == hipSuccess;
+    ok = ok && hipMalloc((void **)&d->d_bskip[p], nsk) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&d->h_in[p], d->psz[p]*2) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&d->h_out[p], d->psz[p]*2) == hipSuccess;
+  }
+  if (!ok) {
+    fail(OD_HIP_ENODEV, "dering object allocation failed");
+    od_hip_dering_destroy(d);
+    return nullptr;
+  }
+  return d;
+}
+
+int od_hip_dering_run(od_hip_dering *d, const int16_t *const in[], const unsigned char *const bskip[],
+                      int skip_stride, const int32_t *threshold, const int32_t *quantizer,
+                      int16_t *const out[]) {
+  if (!d || !in || !bskip || !threshold || !quantizer || !out) return fail(OD_HIP_EFAULT, "null pointer");
+  HIPCHK(hipSetDevice(d->device));
+  const int fw4 = d->fw/4, fh4 = d->fh/4;
+  TailArgs t;
+  memset(&t, 0, sizeof(t));
+  for (int p = 0; p < d->nplanes; p++) {
+    if (!in[p] || !bskip[p] || !out[p] || skip_stride < (fw4 >> d->xdec[p]))
+      return fail(OD_HIP_EINVAL, "bad plane");
+    memcpy(d->h_in[p], in[p], d->psz[p]*2);                      // pageable -> pinned staging
+    HIPCHK(hipMemcpyAsync(d->d_in[p], d->h_in[p], d->psz[p]*2, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemsetAsync(d->d_bskip[p], 0, (size_t)fw4*fh4, d->stream));
+    HIPCHK(hipMemcpy2DAsync(d->d_bskip[p], fw4, bskip[p], skip_stride, fw4 >> d->xdec[p],
+                            fh4 >> d->xdec[p], hipMemcpyHostToDevice, d->stream));
+    t.p16[p] = d->d_in[p];
+    t.o16[p] = d->d_out[p];
+    t.fstride[p] = d->psz[p];
+    t.bskip[p] = d->d_bskip[p];
+    t.xdec[p] = d->xdec[p];
+    t.thr[p] = threshold[p];
+    t.q[p] = quantizer[p];
+  }
+  t.flags = nullptr;                  // encoder mode: every superblock, int16 out
+  t.bskip_fstride = (size_t)fw4*fh4;
+  t.fw = d->fw; t.fh = d->fh; t.nhsb = d->fw/32; t.nvsb = d->fh/32; t.nplanes = d->nplanes;
+  t.is_keyframe = 1;
+  hipLaunchKernelGGL(k_decode_tail, dim3(t.nhsb, t.nvsb, 1), dim3(256), 0, d->stream, t);
+  HIPCHK(hipGetLastError());
+  for (int p = 0; p < d->nplanes; p++)
+    HIPCHK(hipMemcpyAsync(d->h_out[p], d->d_out[p], d->psz[p]*2, hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  for (int p = 0; p < d->nplanes; p++) memcpy(out[p], d->h_out[p], d->psz[p]*2);
+  return 0;
+}
+
+}  // extern "C"

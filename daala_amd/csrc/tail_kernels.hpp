@@ -29,6 +29,11 @@ struct TailArgs {
   int thr[3];                // (int)pow(quantizer, 0.84182)  (src/filter.c:1878)
   int q[3];
   int is_keyframe;
+  // encoder mode (od_hip_dering_run): every superblock is deringed (flags == NULL) and the
+  // result is written as int16 planes without smoothing or clamping - exactly what
+  // od_dering() hands back (src/filter.c:1835), for every superblock of the frame at once
+  int16_t *o16[3];
+  const int16_t *p16[3];     // encoder mode input: the reference's int16 etmp planes
 };
 
 __constant__ int8_t TAIL_DIR[8][3][2] = {
@@ -93,14 +98,17 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
   const int t = threadIdx.x;
   int sbx, sby, f;
   xcd_tile_coords(sbx, sby, f);        // 3-sample borders: neighbours share lines
-  const int flag = a.flags[(size_t)f*a.nhsb*a.nvsb + sby*a.nhsb + sbx];
+  const bool enc_mode = a.flags == nullptr;
+  const int flag = enc_mode ? 1 : a.flags[(size_t)f*a.nhsb*a.nvsb + sby*a.nhsb + sbx];
   const bool dering_on = a.q[0] > 0 && flag;
-  const int sb_bsize = a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];
-  const bool smooth_on = a.q[0] > 0 && a.is_keyframe && sb_bsize == 3;
+  const int sb_bsize = enc_mode ? 0 : a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];
+  const bool smooth_on = !enc_mode && a.q[0] > 0 && a.is_keyframe && sb_bsize == 3;
   for (int pli = 0; pli < a.nplanes; pli++) {
     const int xdec = a.xdec[pli], ln = 5 - xdec, n = 1 << ln;
     const int w = a.fw >> xdec;
-    const int32_t *P = a.p[pli] + (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);
+    const size_t porg = (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);
+    const int32_t *P = enc_mode ? nullptr : a.p[pli] + porg;
+    const int16_t *P16 = enc_mode ? a.p16[pli] + porg : nullptr;
     if (dering_on) {
       const int bsz = 3 - xdec, nb = n >> bsz;            // 4 blocks per side
       // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE
@@ -109,7 +117,9 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
       for (int e = t; e < TAIL_BSTRIDE*TAIL_BSTRIDE; e += 256) {
         const int i = e/TAIL_BSTRIDE - 3, j = e%TAIL_BSTRIDE - 3;
         int16_t v = TAIL_VERY_LARGE;
-        if (i >= lo_i && i < hi_i && j >= lo_j && j < hi_j) v = (int16_t)P[(ptrdiff_t)i*w + j];
+        if (i >= lo_i && i < hi_i && j >= lo_j && j < hi_j) {
+          v = enc_mode ? P16[(ptrdiff_t)i*w + j] : (int16_t)P[(ptrdiff_t)i*w + j];
+        }
         in0[e] = v;
         in1[e] = v;
       }
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
     else {
       for (int e = t; e < n*n; e += 256) {
         const int i = e >> ln, j = e & (n - 1);
-        out[e] = P[(size_t)i*w + j];
+        out[e] = enc_mode ? (int32_t)P16[(size_t)i*w + j] : P[(size_t)i*w + j];
       }
     }
     __syncthreads();
@@ -240,6 +250,15 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
         out[e] = xv - ((wq*(xv - yv) + 128) >> 8);
       }
       __syncthreads();
+    }
+    if (enc_mode) {
+      int16_t *O = a.o16[pli] + (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);
+      for (int e = t; e < n*n; e += 256) {
+        const int i = e >> ln, j = e & (n - 1);
+        O[(size_t)i*w + j] = (int16_t)out[e];
+      }
+      __syncthreads();
+      continue;
     }
     // od_coeff_to_ref_buf (src/state.c:1274-1300)
     uint8_t *R = a.rec[pli] + (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);

@@ -44,6 +44,11 @@ void od_smooth_recursive_cpu(od_coeff *c, unsigned char *bsize, int bstride, int
  int by, int bsi, int w, int xdec, int ydec, int min_bs, int quantizer, int pli);
 void od_coeff_to_ref_plane_cpu(od_state *state, od_img *dst, int pli, od_coeff *src,
  int lossless_p);
+/* hip_enc_glue.c */
+int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
+ int xstride, int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
+ int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
+ int skip_stride);
 
 static double now_s(void) {
   struct timespec ts;
@@ -104,6 +109,11 @@ void od_dering(od_state *state, int16_t *y, int ystride, int16_t *x, int xstride
  int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
  int skip_stride) {
   if (on_device()) return;
+  /* encoder threads: answered from the worker's per-frame device pass when it has one */
+  if (od_hipenc_dering_hook(state, y, ystride, x, xstride, ln, sbx, sby, nhsb, nvsb, q, xdec,
+   dir, pli, bskip, skip_stride)) {
+    return;
+  }
   od_dering_cpu(state, y, ystride, x, xstride, ln, sbx, sby, nhsb, nvsb, q, xdec, dir,
    pli, bskip, skip_stride);
 }

@@ -18,6 +18,7 @@
  * inputs depend on the serial reconstruction, stay the reference's C code.
  * No reference text lives in this file. */
 #define _GNU_SOURCE
+#include <math.h>
 #include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
@@ -62,6 +63,10 @@ typedef struct glue_tls {
   int pli;                        /* plane of the block being coded */
   daala_enc_ctx *enc;             /* encoder of the frame being coded by this thread */
   od_dct_func_2d fdct_cpu[OD_NBSIZES];   /* the context's own fdct_2d entries */
+  od_hip_dering *dr;              /* this worker's device deringing object, or NULL */
+  int16_t *dr_out[3];             /* deringed planes of the frame being coded */
+  int dr_valid;                   /* dr_out holds the current frame */
+  int dr_error;
   od_hipenc_stats st;
 } glue_tls;
 
@@ -144,6 +149,67 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
     return r;
   }
   return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
+}
+
+/* od_dering (src/filter.c:1835) as the encoder's filter on/off loop calls it
+   (src/encode.c:2597, :2662), superblock by superblock and plane by plane: the first
+   call of a frame runs od_hip_dering_run once on the three unfiltered planes
+   (state.etmp, complete before that loop starts, :2541-2549) - deringing reads only
+   those, so every superblock is independent - and every call copies its block out of
+   the result.  Called from the od_dering binding in hip_dec_glue.c; returns 1 when it
+   served the call. */
+void od_dering_cpu(od_state *state, int16_t *y, int ystride, int16_t *x, int xstride,
+ int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
+ int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
+ int skip_stride);
+
+int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
+ int xstride, int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
+ int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
+ int skip_stride) {
+  const int16_t *src;
+  int n;
+  int w;
+  int i;
+  if (T.dr == NULL || T.enc == NULL || state != &T.enc->state || T.dr_error
+   || state->frame_type != OD_I_FRAME || pli < 0 || pli > 2) {
+    return 0;
+  }
+  if (!T.dr_valid) {
+    const int16_t *in[3];
+    const unsigned char *sk[3];
+    int32_t thr[3];
+    int32_t quant[3];
+    int p;
+    for (p = 0; p < 3; p++) {
+      in[p] = state->etmp[p];
+      sk[p] = state->bskip[p];
+      quant[p] = state->quantizer[p];
+      thr[p] = (int32_t)(1.0*pow(state->quantizer[p], 0.84182));     /* src/filter.c:1876 */
+    }
+    if (od_hip_dering_run(T.dr, in, sk, state->skip_stride, thr, quant, T.dr_out) != 0) {
+      T.dr_error = 1;      /* reported as a failed frame by encode_frame: no silent C path */
+      return 0;
+    }
+    T.dr_valid = 1;
+  }
+  n = 1 << ln;
+  w = state->frame_width >> (pli > 0);
+  src = T.dr_out[pli] + (size_t)(sby << ln)*w + (sbx << ln);
+  if (T.check) {
+    int16_t ref[32*32];
+    od_dering_cpu(state, ref, n, x, xstride, ln, sbx, sby, nhsb, nvsb, q, xdec, dir, pli, bskip,
+     skip_stride);
+    for (i = 0; i < n; i++) {
+      if (memcmp(ref + i*n, src + (size_t)i*w, sizeof(int16_t)*n) != 0) {
+        T.st.dering_check_fail++;
+        break;
+      }
+    }
+  }
+  for (i = 0; i < n; i++) memcpy(y + (size_t)i*ystride, src + (size_t)i*w, sizeof(int16_t)*n);
+  T.st.dering_dev_sbs++;
+  return 1;
 }
 
 /* fdct_2d entries of the worker's vtable (struct od_state_opt_vtbl, src/state.h:106).
@@ -365,6 +431,7 @@ typedef struct job {
   const od_hip_feed_level *views;
   od_hip_ctx *ctx;
   od_hip_enc_feed *feed;
+  int device;
   int batch;
   /* phases */
   pthread_mutex_t mu;
@@ -399,6 +466,8 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->search_cpu_s += b->search_cpu_s;
   a->fdct_hits += b->fdct_hits;
   a->fdct_check_fail += b->fdct_check_fail;
+  a->dering_dev_sbs += b->dering_dev_sbs;
+  a->dering_check_fail += b->dering_check_fail;
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
@@ -441,7 +510,9 @@ static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
   }
   fill_img(&img, J->frames + J->frame_bytes*f, J->p->pic_width, J->p->pic_height);
   T.enc = enc;
+  T.dr_valid = 0;
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
+  if (T.dr_error) return -4;
   J->pkt_len[f] = 0;
   while (daala_encode_packet_out(enc, 0, &dp) > 0) {
     unsigned char *q;
@@ -510,8 +581,21 @@ static void *worker(void *arg) {
       enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
     }
   }
+  if (enc != NULL && J->ctx != NULL) {
+    int xdec[3] = {0, 1, 1};
+    int pli;
+    T.dr = od_hip_dering_create(J->device, enc->state.frame_width, enc->state.frame_height, 3, xdec);
+    for (pli = 0; pli < 3; pli++) {
+      T.dr_out[pli] = (int16_t *)malloc(sizeof(int16_t)*(size_t)(enc->state.frame_width >> (pli > 0))
+       *(enc->state.frame_height >> (pli > 0)));
+      if (T.dr_out[pli] == NULL && T.dr != NULL) {
+        od_hip_dering_destroy(T.dr);
+        T.dr = NULL;
+      }
+    }
+  }
   pthread_mutex_lock(&J->mu);
-  if (enc == NULL) J->failed = 1;
+  if (enc == NULL || (J->ctx != NULL && T.dr == NULL)) J->failed = 1;
   J->encoders_ready++;
   pthread_cond_broadcast(&J->cv);
   for (;;) {
@@ -547,6 +631,10 @@ static void *worker(void *arg) {
   add_stats(&J->st, &T.st);
   pthread_cond_broadcast(&J->cv);
   pthread_mutex_unlock(&J->mu);
+  if (T.dr != NULL) od_hip_dering_destroy(T.dr);
+  free(T.dr_out[0]);
+  free(T.dr_out[1]);
+  free(T.dr_out[2]);
   if (enc != NULL) daala_encode_free(enc);
   return NULL;
 }
@@ -575,6 +663,7 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   ch = (p->pic_height + 1) >> 1;
   J.frame_bytes = (size_t)p->pic_width*p->pic_height + 2*(size_t)cw*ch;
   J.views = views;
+  J.device = device;
   J.batch = p->batch > 0 && p->batch < nframes ? p->batch : nframes;
   if (p->batch <= 0) {
     /* default: everything at once, but keep the pinned host mirror of the feed

@@ -35,6 +35,8 @@ typedef struct od_hipenc_stats {
   double search_class_s[4];/* ... split: luma no-ref, luma with-ref, chroma no-ref, chroma with-ref */
   int64_t fdct_hits;       /* luma fdct_2d calls answered from the device pyramid */
   int64_t fdct_check_fail; /* check mode: device block != C transform (must be 0) */
+  int64_t dering_dev_sbs;  /* od_dering calls (superblock, plane) answered from the device pass */
+  int64_t dering_check_fail; /* check mode: device block != C od_dering (must be 0) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* enqueue of the device batch, wall */

@@ -276,6 +276,22 @@ int od_hip_enc_feed_set_level(od_hip_enc_feed *feed, int level, const int16_t *q
 int od_hip_enc_feed_run(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_view(od_hip_enc_feed *feed, int slot, od_hip_feed_level lev[4]);
 
+/* ---------------------------------------------------------------------------
+ * 4c. Encoder-side deringing: od_dering() (src/filter.c:1835) of EVERY 32x32 superblock of
+ *    one frame in one pass - what the encoder's filter on/off loop (src/encode.c:2552-2685)
+ *    asks for superblock by superblock.  in[pli]: the unfiltered post-filter planes
+ *    (state.etmp[pli], int16 like the reference keeps them, frame_width >> xdec samples per row); bskip / skip_stride as
+ *    state.bskip; threshold[pli] = (int)pow(quantizer[pli], 0.84182) computed by the host;
+ *    out[pli]: int16 planes of the same geometry.  One object per host worker (own stream
+ *    and staging); 4:2:0 / 4:4:4, 8 bit. */
+typedef struct od_hip_dering od_hip_dering;
+od_hip_dering *od_hip_dering_create(int device, int frame_width, int frame_height,
+ int nplanes, const int *xdec);
+void od_hip_dering_destroy(od_hip_dering *d);
+int od_hip_dering_run(od_hip_dering *d, const int16_t *const in[],
+ const unsigned char *const bskip[], int skip_stride, const int32_t *threshold,
+ const int32_t *quantizer, int16_t *const out[]);
+
 /* Stand-alone batched pieces for parity tests (host memory):
  * nvec band vectors of length n. */
 int od_hip_pvq_search_vectors(int n, int nvec, const double *x, const int32_t *k,

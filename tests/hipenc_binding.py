@@ -53,6 +53,7 @@ class Stats(ctypes.Structure):
                 ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
                 ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
                 ('fdct_hits', ctypes.c_int64), ('fdct_check_fail', ctypes.c_int64),
+                ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_total_s', ctypes.c_double)]

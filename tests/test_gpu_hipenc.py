@@ -86,6 +86,7 @@ def test_hip_encoder_packets_identical_cif(masking):
     assert got == want
     assert st.dev_hits > 0 and st.check_fail == 0 and st.lost_sync == 0
     assert st.fdct_hits > 0 and st.fdct_check_fail == 0
+    assert st.dering_dev_sbs > 0 and st.dering_check_fail == 0
     if masking == 0:
         assert st.g2_mismatch == 0
 
@@ -208,6 +209,7 @@ def test_hip_encoder_stress_content(kind, quant, masking):
     n, got, st = H.encode(prm, buf, nf, use_device=1)
     assert n == n0 and got == want
     assert st.check_fail == 0 and st.lost_sync == 0 and st.fdct_check_fail == 0
+    assert st.dering_check_fail == 0
     if masking == 0:
         assert st.g2_mismatch == 0
     hdr = H.headers(prm)

@@ -33,7 +33,8 @@ def main():
         _, p0, _, _ = H.decode(prm, hdr, want)
         _, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
         ok = (n == n0 and got == want and st.check_fail == 0 and st.lost_sync == 0
-              and st.fdct_check_fail == 0 and np.array_equal(p0, p1))
+              and st.fdct_check_fail == 0 and st.dering_check_fail == 0 and st.dering_dev_sbs > 0
+              and np.array_equal(p0, p1))
         total['dev_hits'] += st.dev_hits
         total['g2'] += st.g2_mismatch
         total['fdct'] += st.fdct_hits
