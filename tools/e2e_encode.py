@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=30)
     ap.add_argument('--workers', type=int, default=16)
-    ap.add_argument('--ref-frames', type=int, default=2)
+    ap.add_argument('--ref-frames', type=int, default=3)
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--masking', type=int, default=1)
     ap.add_argument('--size', default='1920x1080', help='picture size WxH (default: BASELINE configs[1])')
