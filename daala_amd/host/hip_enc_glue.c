@@ -212,6 +212,8 @@ int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
   return 1;
 }
 
+#define FDCT_MIN_BS_DEFAULT (1)     /* 4x4 blocks: four cache misses cost more than the transform */
+
 /* fdct_2d entries of the worker's vtable (struct od_state_opt_vtbl, src/state.h:106).
    For keyframe luma every forward transform the encoder asks for - od_block_encode in
    the block-size RDO pass (src/encode.c:1139) and od_compute_dcts (:1308) - has the
@@ -219,9 +221,17 @@ int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
    dtmp[0] plane at the block's position: exactly one block of the device's forward
    pyramid, which the feed carries.  Anything else (chroma, od_compute_dist's 8x8
    error transform into a stack buffer) runs the context's C transform. */
+static int fdct_min_bs = -1;      /* smallest block size served from the feed (HIPENC_FDCT_MIN_BS) */
+
 static void fdct_from_feed(int bs, od_coeff *y, int ystride, const od_coeff *x,
  int xstride) {
-  if (T.lev != NULL && T.enc != NULL && T.enc->state.frame_type == OD_I_FRAME) {
+  if (fdct_min_bs < 0) {
+    const char *e;
+    e = getenv("HIPENC_FDCT_MIN_BS");
+    fdct_min_bs = e != NULL ? atoi(e) : FDCT_MIN_BS_DEFAULT;
+  }
+  if (bs >= fdct_min_bs && T.lev != NULL && T.enc != NULL
+   && T.enc->state.frame_type == OD_I_FRAME) {
     const od_state *st;
     od_coeff *d0;
     int w;

@@ -54,8 +54,8 @@ def test_oracle_feed_gives_identical_packets(masking):
     assert got == want
     assert st.check_fail == 0 and st.lost_sync == 0 and st.g2_mismatch == 0
     assert st.dev_hits > 50000
-    # every luma forward transform of both passes came from the feed's pyramid
-    assert st.fdct_hits > 30000 and st.fdct_check_fail == 0
+    # the luma forward transforms of both passes (8x8 and larger) came from the feed pyramid
+    assert st.fdct_hits > 4000 and st.fdct_check_fail == 0
 
 
 def test_corrupt_feed_is_detected_not_trusted():
