@@ -124,10 +124,10 @@ def e2e_encode(frames, device, ref_mpix):
     """END-TO-END bit-exact intra encode through the batched frame seam
     (INTEGRATION.md seam 2, daala_amd/host/hip_enc_glue.c): the device feed answers
     every keyframe-luma no-reference PVQ search, N host workers run the reference
-    encoder's serial entropy/RDO stage (oracle/_ref/libdaala_hipenc.so = the reference
+    encoder's serial entropy/RDO stage (daala_amd/host/build/libdaala_hipenc.so = the reference
     compiled in the dev container + our glue).  Reported beside `value`, not as it."""
     try:
-        import hipenc_binding as H
+        import daala_amd.hipenc as H
     except ImportError:
         return None
     if not H.have_hipenc():
@@ -176,7 +176,7 @@ def e2e_encode_ranks(frames, device, world, dist, torch, red_dev='cuda'):
     with its share of the host CPUs; aggregate = all frames / slowest rank.  (No
     collective on the data path: frames are independent.)"""
     try:
-        import hipenc_binding as H
+        import daala_amd.hipenc as H
         ok = H.have_hipenc()
     except ImportError:
         ok = False

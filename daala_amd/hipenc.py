@@ -1,17 +1,17 @@
 """ctypes binding of daala_amd/host/hip_enc_glue.h: the reference encoder/decoder with
-the batched frame seam bound to libdaala_hip.so (INTEGRATION.md seam 2).
+the batched frame seam bound to libdaala_hip.so (INTEGRATION.md seam 2) - the drop-in
+behind daala_encode_img_in() / daala_decode_packet_in().
 
-The shared library (libdaala_hipenc.so) contains the reference's own compiled code
-next to our glue, so it is built in the dev container by oracle/Makefile into
-oracle/_ref/ (git-ignored; travels to the GPU box as a binary) and everything that
-loads it lives outside the product package: the tests, bench.py's `e2e_encode`
-integration measurement and tools/daala_hip_cli.py."""
+The shared library (daala_amd/host/build/libdaala_hipenc.so) links the reference's own
+host code (compiled where it lies under /root/reference by daala_amd/host/Makefile,
+never copied) with our C glue; build/ is git-ignored and travels to the GPU box as a
+binary.  Python is only the harness (tests, bench.py, tools/daala_hip_cli.py)."""
 import ctypes
 import os
 
 import numpy as np
 
-ORACLE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+HIPENC_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host', 'build', 'libdaala_hipenc.so')
 I32P = ctypes.POINTER(ctypes.c_int32)
 I16P = ctypes.POINTER(ctypes.c_int16)
 U8P = ctypes.POINTER(ctypes.c_uint8)
@@ -56,7 +56,7 @@ class Stats(ctypes.Structure):
                 ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
-                ('t_total_s', ctypes.c_double)]
+                ('t_total_s', ctypes.c_double), ('pkt_bytes_needed', ctypes.c_int64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k == 'search_class_s' else getattr(self, k))
@@ -76,16 +76,16 @@ _lib = None
 
 
 def have_hipenc():
-    return os.path.exists(os.path.join(ORACLE_DIR, '_ref', 'libdaala_hipenc.so'))
+    return os.path.exists(HIPENC_SO)
 
 
 def hipenc():
     global _lib
     if _lib is None:
         if not have_hipenc():
-            raise RuntimeError('oracle/_ref/libdaala_hipenc.so is not built (it needs the reference '
-                               'sources: `make -C oracle ref` in the dev container)')
-        lib = ctypes.CDLL(os.path.join(ORACLE_DIR, '_ref', 'libdaala_hipenc.so'))
+            raise RuntimeError('daala_amd/host/build/libdaala_hipenc.so is not built (it needs the '
+                               'reference sources: `make -C daala_amd/host` in the dev container)')
+        lib = ctypes.CDLL(HIPENC_SO)
         lib.od_hipenc_encode_frames.restype = ctypes.c_long
         lib.od_hipenc_encode_frames.argtypes = [ctypes.POINTER(Params), c_int, U8P,
                                                 ctypes.POINTER(FeedLevel), c_int, c_int, U8P,
@@ -138,9 +138,12 @@ def pad_frame(prm, frame):
     return planes
 
 
-def encode(prm, frames_buf, nframes, views=None, use_device=0, device=0):
+ENOSPC = -11
+
+
+def encode(prm, frames_buf, nframes, views=None, use_device=0, device=0, out_cap=None):
     lib = hipenc()
-    out = np.zeros(max(1 << 20, frames_buf.size), np.uint8)
+    out = np.zeros(max(1 << 20, frames_buf.size) if out_cap is None else out_cap, np.uint8)
     st = Stats()
     varr = None
     if views is not None:
@@ -150,8 +153,12 @@ def encode(prm, frames_buf, nframes, views=None, use_device=0, device=0):
                 varr[4*f + l] = views[f].levels[l]
     n = lib.od_hipenc_encode_frames(ctypes.byref(prm), nframes, pu8(frames_buf), varr,
                                     use_device, device, pu8(out), out.size, ctypes.byref(st))
+    if n == ENOSPC and out_cap is None:
+        # all-or-nothing: the call reports the size it needs (never a partial stream)
+        return encode(prm, frames_buf, nframes, views, use_device, device, int(st.pkt_bytes_needed))
     if n < 0:
         return n, None, st
+    assert st.pkt_bytes_needed == n + 4*nframes <= out.size
     return n, split_packets(out, nframes), st
 
 
@@ -170,17 +177,23 @@ def join_packets(packets):
 
 
 def decode(prm, hdr, packets, use_device=0, device=0):
-    """Decodes keyframe packets -> (frames [nframes, frame_bytes] u8, seconds, device_seconds)."""
+    """Decodes keyframe packets -> (n, frames [nframes, frame_bytes] u8, seconds, device_seconds)."""
+    return decode_blob(prm, hdr, join_packets(packets), len(packets), use_device, device)
+
+
+def decode_blob(prm, hdr, buf, nframes, use_device=0, device=0):
+    """The same on a length-prefixed packet blob as od_hipenc_encode_frames writes it."""
     lib = hipenc()
     lib.od_hipdec_decode_frames.restype = ctypes.c_long
     lib.od_hipdec_decode_frames.argtypes = [ctypes.POINTER(Params), U8P, ctypes.c_long, c_int, U8P,
                                             ctypes.c_long, c_int, c_int, U8P, F64P, F64P]
     w, h = prm.pic_width, prm.pic_height
     fb = w*h + 2*((w + 1)//2)*((h + 1)//2)
-    buf = join_packets(packets)
-    out = np.zeros((len(packets), fb), np.uint8)
+    buf = np.ascontiguousarray(buf)
+    hdr = np.ascontiguousarray(hdr)
+    out = np.zeros((nframes, fb), np.uint8)
     sec, dsec = ctypes.c_double(), ctypes.c_double()
-    n = lib.od_hipdec_decode_frames(ctypes.byref(prm), pu8(hdr), hdr.size, len(packets), pu8(buf),
+    n = lib.od_hipdec_decode_frames(ctypes.byref(prm), pu8(hdr), hdr.size, nframes, pu8(buf),
                                     buf.size, use_device, device, pu8(out), ctypes.byref(sec),
                                     ctypes.byref(dsec))
     return n, out, sec.value, dsec.value

@@ -224,12 +224,29 @@ static daala_dec_ctx *make_decoder(const djob *J) {
     daala_packet dp;
     long n;
     n = J->hdr[o] | J->hdr[o + 1] << 8 | J->hdr[o + 2] << 16 | (long)J->hdr[o + 3] << 24;
+    /* a length that runs past the caller's buffer is a corrupt container, not a packet */
+    if (n < 0 || n > J->hdr_bytes - o - 4) {
+      daala_setup_free(dsi);
+      daala_comment_clear(&dc);
+      return NULL;
+    }
     memset(&dp, 0, sizeof(dp));
     dp.packet = (unsigned char *)J->hdr + o + 4;
     dp.bytes = n;
     dp.b_o_s = o == 0;
-    if (daala_decode_header_in(&di, &dc, &dsi, &dp) < 0) return NULL;
+    if (daala_decode_header_in(&di, &dc, &dsi, &dp) < 0) {
+      daala_setup_free(dsi);
+      daala_comment_clear(&dc);
+      return NULL;
+    }
     o += 4 + n;
+  }
+  /* the pictures are copied out with the caller's dimensions (dworker): they must be the
+     stream's, or the copy would run past the decoder's planes */
+  if (di.pic_width != J->p->pic_width || di.pic_height != J->p->pic_height) {
+    daala_setup_free(dsi);
+    daala_comment_clear(&dc);
+    return NULL;
   }
   dec = daala_decode_create(&di, dsi);
   daala_setup_free(dsi);
@@ -392,6 +409,11 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
       return OD_HIP_EINVAL;
     }
     n = pkts[o] | pkts[o + 1] << 8 | pkts[o + 2] << 16 | (long)pkts[o + 3] << 24;
+    if (n < 0 || n > pkt_bytes - o - 4) {       /* truncated or corrupt packet blob */
+      free(J.pkt);
+      free(J.pkt_len);
+      return OD_HIP_EINVAL;
+    }
     J.pkt[i] = pkts + o + 4;
     J.pkt_len[i] = n;
     o += 4 + n;

@@ -660,11 +660,13 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   int ch;
   long total;
   long used;
+  int nospace;
   double t_setup0;
   double t0;
   if (p == NULL || frames == NULL || nframes < 1) return OD_HIP_EFAULT;
   nw = p->nworkers < 1 ? 1 : p->nworkers;
   if (nw > nframes) nw = nframes;
+  nospace = 0;
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;
@@ -769,9 +771,18 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
       tb = now_s();
       J.st.t_upload_s += tb - ta;
       if (J.failed) break;
-      if (od_hip_enc_feed_run(J.feed, b0 % J.nslots, J.batch_n) != 0) {
-        J.failed = 1;
-        break;
+      {
+        int rc;
+        /* ~40 launches and event waits: workers coding the previous batch must be able to
+           take J.mu meanwhile (frames [b0, b0 + batch_n) are not claimable before
+           launched_upto moves) */
+        pthread_mutex_unlock(&J.mu);
+        rc = od_hip_enc_feed_run(J.feed, b0 % J.nslots, J.batch_n);
+        pthread_mutex_lock(&J.mu);
+        if (rc != 0) {
+          J.failed = 1;
+          break;
+        }
       }
       J.st.t_launch_s += now_s() - tb;
       J.launched_upto = b0 + J.batch_n;
@@ -782,12 +793,23 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   pthread_mutex_unlock(&J.mu);
   for (i = 0; i < nw; i++) pthread_join(th[i], NULL);
   J.st.t_total_s = now_s() - t0;
+  /* All packets or none: a stream with a frame missing (or out of order) is corrupt, so
+     the space needed is summed first and a buffer that is too small fails the call. */
   total = 0;
   used = 0;
   for (i = 0; i < nframes; i++) {
     if (J.pkt[i] != NULL) {
       total += J.pkt_len[i] - 4;
-      if (pkt_out != NULL && used + J.pkt_len[i] <= pkt_cap) {
+      used += J.pkt_len[i];
+    }
+    else J.failed = 1;
+  }
+  J.st.pkt_bytes_needed = used;
+  if (pkt_out != NULL && used > pkt_cap) nospace = 1;
+  used = 0;
+  for (i = 0; i < nframes; i++) {
+    if (J.pkt[i] != NULL) {
+      if (pkt_out != NULL && !nospace && !J.failed) {
         memcpy(pkt_out + used, J.pkt[i], J.pkt_len[i]);
         used += J.pkt_len[i];
       }
@@ -803,7 +825,8 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   pthread_mutex_destroy(&J.mu);
   pthread_cond_destroy(&J.cv);
   if (stats != NULL) *stats = J.st;
-  return J.failed ? OD_HIP_EINVAL : total;
+  if (J.failed) return OD_HIP_EINVAL;
+  return nospace ? OD_HIP_ENOSPC : total;
 }
 
 /* The padded input planes daala_encode_img_in() codes for one frame (the

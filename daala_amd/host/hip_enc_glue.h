@@ -41,6 +41,7 @@ typedef struct od_hipenc_stats {
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* enqueue of the device batch, wall */
   double t_total_s;        /* wall: first frame in -> last packet out */
+  int64_t pkt_bytes_needed; /* size of the packet blob (with the 4-byte length prefixes) */
 } od_hipenc_stats;
 
 /* Encodes nframes dense 4:2:0 frames (Y then U then V, picture size) as
@@ -49,7 +50,9 @@ typedef struct od_hipenc_stats {
  * prefixed by its 4-byte little-endian length.  views: NULL, or
  * [nframes][4] host-fabricated feed views (tests); use_device: take the feed from
  * the HIP device `device` (fails loudly when there is none); neither: the plain
- * reference search on nworkers threads.  Returns total packet bytes or < 0. */
+ * reference search on nworkers threads.  Returns total packet bytes or < 0.
+ * All packets or none: when the blob (stats->pkt_bytes_needed bytes) does not fit
+ * pkt_cap nothing is written and OD_HIP_ENOSPC is returned. */
 long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
  const unsigned char *frames, const od_hip_feed_level *views, int use_device,
  int device, unsigned char *pkt_out, long pkt_cap, od_hipenc_stats *stats);

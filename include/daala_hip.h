@@ -29,6 +29,7 @@ typedef int32_t od_coeff;
 #define OD_HIP_EFAULT (-1)    /* bad pointer / argument (OD_EFAULT) */
 #define OD_HIP_EINVAL (-10)   /* invalid geometry or state (OD_EINVAL) */
 #define OD_HIP_ENODEV (-30)   /* no HIP device / HIP runtime error */
+#define OD_HIP_ENOSPC (-11)   /* caller's output buffer is too small (nothing was written) */
 
 #define OD_HIP_NPLANES_MAX (4)
 #define OD_HIP_NBSIZES (4)    /* 4x4 .. 32x32, OD_NBSIZES src/internal.h:55 */

@@ -1,4 +1,4 @@
-"""Test-side helpers on top of tests/hipenc_binding.py: an oracle-backed producer of
+"""Test-side helpers on top of daala_amd/hipenc.py: an oracle-backed producer of
 encoder-feed views (stand-in for od_hip_enc_feed_view in CPU tests, checker of the
 device feed).  Test infrastructure."""
 import ctypes
@@ -8,8 +8,8 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from hipenc_binding import *          # noqa: F401,F403
-from hipenc_binding import FeedLevel, level_params, p32, p16, pu8, pf64, I32P
+from daala_amd.hipenc import *          # noqa: F401,F403
+from daala_amd.hipenc import FeedLevel, level_params, p32, p16, pu8, pf64, I32P
 from testlib import oracle
 
 

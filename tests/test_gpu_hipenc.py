@@ -1,5 +1,5 @@
 """Batched frame seam, end to end on the device (INTEGRATION.md seam 2): the real
-reference encoder (oracle/_ref/libdaala_hipenc.so, built in the dev container, runs
+reference encoder (daala_amd/host/build/libdaala_hipenc.so, built in the dev container, runs
 here as a prebuilt binary) takes every keyframe-luma no-reference PVQ search from the
 device feed and must produce the packets of the pure-C reference, byte for byte."""
 import ctypes
@@ -12,7 +12,7 @@ from testlib import synth_plane, ref, pu8
 import hipenc_lib as H
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not H.have_hipenc(), reason='oracle/_ref/libdaala_hipenc.so not built')]
+              pytest.mark.skipif(not H.have_hipenc(), reason='daala_amd/host/build/libdaala_hipenc.so not built')]
 
 
 def frames_of(w, h, seeds):

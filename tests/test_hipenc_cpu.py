@@ -10,7 +10,7 @@ import pytest
 from testlib import synth_plane, ref, pu8
 import hipenc_lib as H
 
-pytestmark = pytest.mark.skipif(not H.have_hipenc(), reason='oracle/_ref/libdaala_hipenc.so not built')
+pytestmark = pytest.mark.skipif(not H.have_hipenc(), reason='daala_amd/host/build/libdaala_hipenc.so not built')
 
 
 def setup_frames(w, h, seeds):
@@ -144,3 +144,40 @@ def test_decoder_driver_many_frames_per_worker():
         assert nd == nf
         outs.append(out)
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_packet_buffer_too_small_is_an_error_not_a_partial_stream():
+    """od_hipenc_encode_frames is all-or-nothing: a pkt_cap that cannot hold every packet
+    fails with OD_HIP_ENOSPC, reports the size needed and writes nothing."""
+    prm = H.Params(96, 64, 20, 7, 1, 2, 0, 0)
+    frames = [[synth_plane(128, 64, 40 + f)[:64, :96], synth_plane(64, 32, 50 + f, 1)[:32, :48],
+               synth_plane(64, 32, 60 + f, 1)[:32, :48]] for f in range(3)]
+    buf = H.pack_frames(frames, 96, 64)
+    n, pk, st = H.encode(prm, buf, 3)
+    assert n > 0 and st.pkt_bytes_needed == n + 12
+    n2, pk2, st2 = H.encode(prm, buf, 3, out_cap=int(st.pkt_bytes_needed) - 1)
+    assert n2 == H.ENOSPC and pk2 is None and st2.pkt_bytes_needed == st.pkt_bytes_needed
+    n3, pk3, _ = H.encode(prm, buf, 3, out_cap=int(st.pkt_bytes_needed))
+    assert n3 == n and pk3 == pk
+
+
+def test_truncated_or_mismatched_container_is_rejected():
+    """The length-prefixed container is checked before the reference decoder sees it: a
+    packet length that runs past the blob, a truncated header blob and dimensions that
+    are not the stream's all fail with OD_HIP_EINVAL."""
+    prm = H.Params(96, 64, 20, 7, 1, 1, 0, 0)
+    frames = [[synth_plane(128, 64, 41)[:64, :96], synth_plane(64, 32, 51, 1)[:32, :48],
+               synth_plane(64, 32, 61, 1)[:32, :48]]]
+    buf = H.pack_frames(frames, 96, 64)
+    n, pk, _ = H.encode(prm, buf, 1)
+    hdr = H.headers(prm)
+    nd, pics, _, _ = H.decode(prm, hdr, pk)
+    assert nd == 1
+    blob = H.join_packets(pk)
+    assert H.decode_blob(prm, hdr, blob[:-5], 1)[0] == -10          # body shorter than its length
+    bad = blob.copy()
+    bad[0:4] = np.frombuffer((len(pk[0]) + 1000).to_bytes(4, 'little'), np.uint8)
+    assert H.decode_blob(prm, hdr, bad, 1)[0] == -10
+    assert H.decode_blob(prm, hdr[:-3], blob, 1)[0] == -10          # truncated header packet
+    other = H.Params(128, 64, 20, 7, 1, 1, 0, 0)
+    assert H.decode_blob(other, hdr, blob, 1)[0] == -10             # not the stream's picture size

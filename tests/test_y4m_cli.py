@@ -15,7 +15,7 @@ cli = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(cli)
 from daala_amd.y4m import Y4MReader, Y4MWriter, Y4MError
 
-needs = pytest.mark.skipif(not H.have_hipenc(), reason='oracle/_ref/libdaala_hipenc.so not built')
+needs = pytest.mark.skipif(not H.have_hipenc(), reason='daala_amd/host/build/libdaala_hipenc.so not built')
 
 
 def write_clip(path, w, h, nf, chroma='C420jpeg'):

@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import hipenc_binding as H                              # noqa: E402
+import daala_amd.hipenc as H                              # noqa: E402
 from daala_amd.y4m import Y4MReader, Y4MWriter          # noqa: E402
 
 MAGIC = b'DHIP1\n'

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end intra encode of BASELINE configs[1] through the batched frame seam:
 30 synthetic 1080p 4:2:0 frames, device feed + N host workers running the reference
-encoder's serial stage (oracle/_ref/libdaala_hipenc.so).  Prints one JSON object.
+encoder's serial stage (daala_amd/host/build/libdaala_hipenc.so).  Prints one JSON object.
   python tools/e2e_encode.py [--frames 30] [--workers 16] [--ref-frames 2] [--no-verify]"""
 import argparse
 import json
@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--host-only', action='store_true', help='same driver, plain C search (no device)')
     ap.add_argument('--decode', action='store_true', help='also decode the packets (device tail vs reference)')
     args = ap.parse_args()
-    import hipenc_binding as H
+    import daala_amd.hipenc as H
     import bench
     PIC_W, PIC_H = (int(v) for v in args.size.split('x'))
     if (PIC_W, PIC_H) != (bench.PIC_W, bench.PIC_H):

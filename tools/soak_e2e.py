@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--workers', type=int, default=16)
     ap.add_argument('--frames', type=int, default=30)
     a = ap.parse_args()
-    import hipenc_binding as H
+    import daala_amd.hipenc as H
     import bench
     frames = bench.make_frames(a.frames, seed0=3)
     buf = H.pack_frames(frames, bench.PIC_W, bench.PIC_H)

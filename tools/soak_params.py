@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
 def main():
-    import hipenc_binding as H
+    import daala_amd.hipenc as H
     from testlib import synth_plane
     bad = 0
     total = dict(dev_hits=0, g2=0, fdct=0)
