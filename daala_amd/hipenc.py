@@ -90,6 +90,13 @@ def hipenc():
         lib.od_hipenc_encode_frames.argtypes = [ctypes.POINTER(Params), c_int, U8P,
                                                 ctypes.POINTER(FeedLevel), c_int, c_int, U8P,
                                                 ctypes.c_long, ctypes.POINTER(Stats)]
+        lib.od_hipenc_open.restype = ctypes.c_void_p
+        lib.od_hipenc_open.argtypes = [ctypes.POINTER(Params), c_int, c_int, ctypes.POINTER(c_int)]
+        lib.od_hipenc_encode.restype = ctypes.c_long
+        lib.od_hipenc_encode.argtypes = [ctypes.c_void_p, c_int, ctypes.c_long, U8P,
+                                         ctypes.POINTER(FeedLevel), U8P, ctypes.c_long,
+                                         ctypes.POINTER(Stats)]
+        lib.od_hipenc_close.argtypes = [ctypes.c_void_p]
         lib.od_hipenc_level_params.argtypes = [ctypes.POINTER(Params), I16P, I32P, F64P]
         lib.od_hipenc_pad_frame.argtypes = [ctypes.POINTER(Params), U8P,
                                             ctypes.POINTER(U8P), ctypes.POINTER(c_int),
@@ -160,6 +167,50 @@ def encode(prm, frames_buf, nframes, views=None, use_device=0, device=0, out_cap
         return n, None, st
     assert st.pkt_bytes_needed == n + 4*nframes <= out.size
     return n, split_packets(out, nframes), st
+
+
+class Session:
+    """od_hipenc_open / od_hipenc_encode / od_hipenc_close: persistent workers + device
+    context; encode() codes one stream of independent keyframes per call."""
+
+    def __init__(self, prm, use_device=0, device=0):
+        self.lib = hipenc()
+        self.prm = prm
+        err = c_int()
+        self.h = self.lib.od_hipenc_open(ctypes.byref(prm), use_device, device, ctypes.byref(err))
+        if not self.h:
+            raise RuntimeError('od_hipenc_open failed: %d' % err.value)
+
+    def encode(self, frames_buf, nframes, views=None, frame0=0, out=None):
+        if out is None:
+            out = np.zeros(max(1 << 20, frames_buf.size), np.uint8)
+        st = Stats()
+        varr = None
+        if views is not None:
+            varr = (FeedLevel*(4*nframes))()
+            for f in range(nframes):
+                for l in range(4):
+                    varr[4*f + l] = views[f].levels[l]
+        n = self.lib.od_hipenc_encode(self.h, nframes, frame0, pu8(frames_buf), varr, pu8(out),
+                                      out.size, ctypes.byref(st))
+        if n == ENOSPC:
+            return self.encode(frames_buf, nframes, views, frame0,
+                               np.zeros(int(st.pkt_bytes_needed), np.uint8))
+        if n < 0:
+            return n, None, st
+        assert st.pkt_bytes_needed == n + 4*nframes <= out.size
+        return n, split_packets(out, nframes), st
+
+    def close(self):
+        if self.h:
+            self.lib.od_hipenc_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def headers(prm):

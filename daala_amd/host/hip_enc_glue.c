@@ -433,38 +433,57 @@ int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
 }
 
 /* ------------------------------------------------------------------------ */
+/* The pipelined multi-frame driver.  A session (od_hipenc_open) owns N host workers - one
+   reference encoder context, one device deringing object each - and, with a device, one
+   od_hip_ctx + encoder feed with `nslots` frame slots.  A job (od_hipenc_encode) is one
+   stream of independent keyframes: frame f lives in slot f % nslots; a stream that does
+   not fit the slots is cut into two half-buffers of nslots/2 frames, batch k + 1 is
+   uploaded, computed and copied while batch k is being coded. */
 typedef struct job {
-  const od_hipenc_params *p;
   int nframes;
+  long frame0;          /* stream index of frames[0] (golden-frame flag, see encode_frame) */
   const unsigned char *frames;
-  size_t frame_bytes;
   const od_hip_feed_level *views;
-  od_hip_ctx *ctx;
-  od_hip_enc_feed *feed;
-  int device;
   int batch;
-  /* phases */
-  pthread_mutex_t mu;
-  pthread_cond_t cv;
-  int encoders_ready;
-  int go;               /* 1: upload phase open, 2: encode phase open */
+  int nslots;
   int uploaded;         /* frames uploaded in the current batch */
   int batch0;           /* first frame of the current device batch */
   int batch_n;
   int next_upload;
   int next_encode;
   int encoded;          /* frames completely coded */
-  int nslots;           /* device slots: one batch, or two half-buffers of `batch` */
   unsigned char *done;  /* per frame: completely coded */
   int done_prefix;      /* frames [0, done_prefix) are all coded */
   int launched_upto;    /* frames [0, launched_upto) have a feed run enqueued */
+  int go;               /* 1: claimable */
   int failed;
-  int next_worker_id;
+  int workers_done;
   /* outputs */
   unsigned char **pkt;
   long *pkt_len;
   od_hipenc_stats st;
 } job;
+
+struct od_hipenc {
+  od_hipenc_params p;
+  int use_device;
+  int device;
+  int nw;
+  int nslots;
+  size_t frame_bytes;
+  pthread_t *th;
+  od_hip_ctx *ctx;
+  od_hip_enc_feed *feed;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int encoders_ready;
+  int setup_failed;
+  int quit;
+  int next_worker_id;
+  long job_seq;         /* number of jobs submitted so far */
+  job *J;               /* the job being worked on, or NULL */
+  double t_setup_s;
+};
 
 static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->dev_hits += b->dev_hits;
@@ -481,13 +500,13 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
-static int upload_frame(job *J, daala_enc_ctx *enc, int f) {
+static int upload_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   od_img img;
   od_img *pad;
   const unsigned char *planes[3];
   int ystride[3];
   int pli;
-  fill_img(&img, J->frames + J->frame_bytes*f, J->p->pic_width, J->p->pic_height);
+  fill_img(&img, J->frames + S->frame_bytes*f, S->p.pic_width, S->p.pic_height);
   /* the reference's own padding (od_img_copy_pad, src/encode.c:1728) */
   od_hipenc_copy_pad(enc, &img);
   pad = &enc->input_img[0];
@@ -495,30 +514,30 @@ static int upload_frame(job *J, daala_enc_ctx *enc, int f) {
     planes[pli] = pad->planes[pli].data;
     ystride[pli] = pad->planes[pli].ystride;
   }
-  return od_hip_upload_planes(J->ctx, f % J->nslots, planes, ystride);
+  return od_hip_upload_planes(S->ctx, f % J->nslots, planes, ystride);
 }
 
-static int encode_frame(job *J, daala_enc_ctx *enc, int f) {
+static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   od_img img;
   daala_packet dp;
   int left;
   od_hip_feed_level lev[4];
   T.lev = NULL;
   if (J->views != NULL) T.lev = J->views + 4*(size_t)f;
-  else if (J->feed != NULL) {
-    if (od_hip_enc_feed_view(J->feed, f % J->nslots, lev) != 0) return -1;
+  else if (S->feed != NULL) {
+    if (od_hip_enc_feed_view(S->feed, f % J->nslots, lev) != 0) return -1;
     T.lev = lev;
   }
   /* Frame f of the stream on a context that did not code frames 0..f-1: the
      only history a keyframe packet carries is the golden-frame flag
      (ip_frame_count % OD_GOLDEN_FRAME_INTERVAL, forced on while no golden
      reference exists; src/encode.c:2958-2963, :3023). */
-  enc->ip_frame_count = f;
-  if (f > 0 && enc->state.ref_imgi[OD_FRAME_GOLD] < 0) {
+  enc->ip_frame_count = (int)(J->frame0 + f);
+  if (J->frame0 + f > 0 && enc->state.ref_imgi[OD_FRAME_GOLD] < 0) {
     enc->state.ref_imgi[OD_FRAME_GOLD] = 0;
     enc->state.ref_imgi[OD_FRAME_PREV] = 0;
   }
-  fill_img(&img, J->frames + J->frame_bytes*f, J->p->pic_width, J->p->pic_height);
+  fill_img(&img, J->frames + S->frame_bytes*f, S->p.pic_width, S->p.pic_height);
   T.enc = enc;
   T.dr_valid = 0;
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
@@ -572,16 +591,17 @@ static void pin_worker(int idx) {
 }
 
 static void *worker(void *arg) {
-  job *J;
+  od_hipenc *S;
   daala_enc_ctx *enc;
-  J = (job *)arg;
+  long seen_seq;
+  S = (od_hipenc *)arg;
   memset(&T, 0, sizeof(T));
-  pthread_mutex_lock(&J->mu);
-  pin_worker(J->next_worker_id++);
-  pthread_mutex_unlock(&J->mu);
-  T.check = J->p->check;
+  pthread_mutex_lock(&S->mu);
+  pin_worker(S->next_worker_id++);
+  pthread_mutex_unlock(&S->mu);
+  T.check = S->p.check;
   T.time_cpu = 1;
-  enc = make_encoder(J->p, J->p->pic_width, J->p->pic_height);
+  enc = make_encoder(&S->p, S->p.pic_width, S->p.pic_height);
   if (enc != NULL) {
     static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
      hook_fdct32};
@@ -591,10 +611,10 @@ static void *worker(void *arg) {
       enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
     }
   }
-  if (enc != NULL && J->ctx != NULL) {
+  if (enc != NULL && S->ctx != NULL) {
     int xdec[3] = {0, 1, 1};
     int pli;
-    T.dr = od_hip_dering_create(J->device, enc->state.frame_width, enc->state.frame_height, 3, xdec);
+    T.dr = od_hip_dering_create(S->device, enc->state.frame_width, enc->state.frame_height, 3, xdec);
     for (pli = 0; pli < 3; pli++) {
       T.dr_out[pli] = (int16_t *)malloc(sizeof(int16_t)*(size_t)(enc->state.frame_width >> (pli > 0))
        *(enc->state.frame_height >> (pli > 0)));
@@ -604,43 +624,53 @@ static void *worker(void *arg) {
       }
     }
   }
-  pthread_mutex_lock(&J->mu);
-  if (enc == NULL || (J->ctx != NULL && T.dr == NULL)) J->failed = 1;
-  J->encoders_ready++;
-  pthread_cond_broadcast(&J->cv);
+  seen_seq = 0;
+  pthread_mutex_lock(&S->mu);
+  if (enc == NULL || (S->ctx != NULL && T.dr == NULL)) S->setup_failed = 1;
+  S->encoders_ready++;
+  pthread_cond_broadcast(&S->cv);
   for (;;) {
-    int f;
-    if (J->failed) break;
-    if (J->go >= 1 && J->ctx != NULL && J->next_upload < J->batch0 + J->batch_n) {
-      int rc;
-      f = J->next_upload++;
-      pthread_mutex_unlock(&J->mu);
-      rc = upload_frame(J, enc, f);
-      pthread_mutex_lock(&J->mu);
-      if (rc != 0) J->failed = 1;
-      J->uploaded++;
-      pthread_cond_broadcast(&J->cv);
-      continue;
+    job *J;
+    while (!S->quit && (S->J == NULL || S->job_seq == seen_seq)) pthread_cond_wait(&S->cv, &S->mu);
+    if (S->quit) break;
+    J = S->J;
+    seen_seq = S->job_seq;
+    memset(&T.st, 0, sizeof(T.st));
+    for (;;) {
+      int f;
+      if (J->failed || S->setup_failed) break;
+      if (J->go >= 1 && S->ctx != NULL && J->next_upload < J->batch0 + J->batch_n) {
+        int rc;
+        f = J->next_upload++;
+        pthread_mutex_unlock(&S->mu);
+        rc = upload_frame(S, J, enc, f);
+        pthread_mutex_lock(&S->mu);
+        if (rc != 0) J->failed = 1;
+        J->uploaded++;
+        pthread_cond_broadcast(&S->cv);
+        continue;
+      }
+      if (J->go >= 1 && J->next_encode < J->launched_upto) {
+        int rc;
+        f = J->next_encode++;
+        pthread_mutex_unlock(&S->mu);
+        rc = encode_frame(S, J, enc, f);
+        pthread_mutex_lock(&S->mu);
+        if (rc != 0) J->failed = 1;
+        J->encoded++;
+        J->done[f] = 1;
+        while (J->done_prefix < J->nframes && J->done[J->done_prefix]) J->done_prefix++;
+        pthread_cond_broadcast(&S->cv);
+        continue;
+      }
+      if (J->go >= 1 && J->next_encode >= J->nframes) break;
+      pthread_cond_wait(&S->cv, &S->mu);
     }
-    if (J->go >= 1 && J->next_encode < J->launched_upto) {
-      int rc;
-      f = J->next_encode++;
-      pthread_mutex_unlock(&J->mu);
-      rc = encode_frame(J, enc, f);
-      pthread_mutex_lock(&J->mu);
-      if (rc != 0) J->failed = 1;
-      J->encoded++;
-      J->done[f] = 1;
-      while (J->done_prefix < J->nframes && J->done[J->done_prefix]) J->done_prefix++;
-      pthread_cond_broadcast(&J->cv);
-      continue;
-    }
-    if (J->go >= 1 && J->next_encode >= J->nframes) break;
-    pthread_cond_wait(&J->cv, &J->mu);
+    add_stats(&J->st, &T.st);
+    J->workers_done++;
+    pthread_cond_broadcast(&S->cv);
   }
-  add_stats(&J->st, &T.st);
-  pthread_cond_broadcast(&J->cv);
-  pthread_mutex_unlock(&J->mu);
+  pthread_mutex_unlock(&S->mu);
   if (T.dr != NULL) od_hip_dering_destroy(T.dr);
   free(T.dr_out[0]);
   free(T.dr_out[1]);
@@ -649,66 +679,66 @@ static void *worker(void *arg) {
   return NULL;
 }
 
-long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
- const unsigned char *frames, const od_hip_feed_level *views, int use_device,
- int device, unsigned char *pkt_out, long pkt_cap, od_hipenc_stats *stats) {
-  job J;
-  pthread_t *th;
+void od_hipenc_close(od_hipenc *S) {
+  int i;
+  if (S == NULL) return;
+  pthread_mutex_lock(&S->mu);
+  S->quit = 1;
+  pthread_cond_broadcast(&S->cv);
+  pthread_mutex_unlock(&S->mu);
+  for (i = 0; i < S->nw; i++) pthread_join(S->th[i], NULL);
+  if (S->feed != NULL) od_hip_enc_feed_destroy(S->feed);
+  if (S->ctx != NULL) od_hip_ctx_destroy(S->ctx);
+  free(S->th);
+  pthread_mutex_destroy(&S->mu);
+  pthread_cond_destroy(&S->cv);
+  free(S);
+}
+
+od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device, int *err) {
+  od_hipenc *S;
   int nw;
   int i;
   int cw;
   int ch;
-  long total;
-  long used;
-  int nospace;
-  double t_setup0;
+  int rc;
   double t0;
-  if (p == NULL || frames == NULL || nframes < 1) return OD_HIP_EFAULT;
+  rc = 0;
+  if (err != NULL) *err = 0;
+  if (p == NULL) {
+    if (err != NULL) *err = OD_HIP_EFAULT;
+    return NULL;
+  }
+  S = (od_hipenc *)calloc(1, sizeof(*S));
+  if (S == NULL) {
+    if (err != NULL) *err = OD_HIP_EFAULT;
+    return NULL;
+  }
+  t0 = now_s();
+  S->p = *p;
+  S->use_device = use_device;
+  S->device = device;
   nw = p->nworkers < 1 ? 1 : p->nworkers;
-  if (nw > nframes) nw = nframes;
-  nospace = 0;
-  memset(&J, 0, sizeof(J));
-  J.p = p;
-  J.nframes = nframes;
-  J.frames = frames;
+  S->nw = nw;
   cw = (p->pic_width + 1) >> 1;
   ch = (p->pic_height + 1) >> 1;
-  J.frame_bytes = (size_t)p->pic_width*p->pic_height + 2*(size_t)cw*ch;
-  J.views = views;
-  J.device = device;
-  J.batch = p->batch > 0 && p->batch < nframes ? p->batch : nframes;
-  if (p->batch <= 0) {
-    /* default: everything at once, but keep the pinned host mirror of the feed
-       (about 49 bytes per padded luma sample and frame: records + pyramid) under ~6 GB */
+  S->frame_bytes = (size_t)p->pic_width*p->pic_height + 2*(size_t)cw*ch;
+  /* Device slots.  batch > 0: that many; default: as many as keep the pinned host mirror
+     of the feed (about 49 bytes per padded luma sample and frame: records + pyramid)
+     under ~6 GB, at least two per worker. */
+  if (p->batch > 0) S->nslots = p->batch;
+  else {
     double per_frame;
-    int cap;
     per_frame = 49.*((p->pic_width + 63) & ~63)*((p->pic_height + 63) & ~63);
-    cap = (int)(6e9/per_frame);
-    if (cap < 2*nw) cap = 2*nw;
-    /* longer streams: two half-buffers of cap/2 frames, batch k+1 is computed and
-       copied while batch k is being coded */
-    if (J.batch > cap) J.batch = cap/2;
+    S->nslots = (int)(6e9/per_frame);
+    if (S->nslots < 2*nw) S->nslots = 2*nw;
   }
-  /* Device slots: frame f lives in slot f % nslots.  A stream that does not fit one
-     batch uses two half-buffers; batch k (frames [k*batch, (k+1)*batch)) may be
-     uploaded and launched as soon as batch k-2, the previous user of its half, is
-     completely coded. */
-  J.nslots = J.batch >= nframes ? nframes : 2*J.batch;
-  J.done = (unsigned char *)calloc(nframes, 1);
-  J.pkt = (unsigned char **)calloc(nframes, sizeof(*J.pkt));
-  J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
-  th = (pthread_t *)calloc(nw, sizeof(*th));
-  if (J.done == NULL || J.pkt == NULL || J.pkt_len == NULL || th == NULL) {
-    free(J.done);
-    free(J.pkt);
-    free(J.pkt_len);
-    free(th);
-    return OD_HIP_EFAULT;
-  }
-  pthread_mutex_init(&J.mu, NULL);
-  pthread_cond_init(&J.cv, NULL);
-  t_setup0 = now_s();
-  if (use_device && views == NULL) {
+  if (S->nslots < 2) S->nslots = 2;
+  pthread_mutex_init(&S->mu, NULL);
+  pthread_cond_init(&S->cv, NULL);
+  S->th = (pthread_t *)calloc(nw, sizeof(*S->th));
+  if (S->th == NULL) rc = OD_HIP_EFAULT;
+  if (rc == 0 && use_device) {
     /* No device, no encode: the product path does not fall back to the C search. */
     od_hip_geometry g;
     int16_t qm[4][1024];
@@ -723,75 +753,121 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
     g.frame_height = (p->pic_height + (2*OD_BSIZE_MAX - 1)) & ~(2*OD_BSIZE_MAX - 1);
     g.nplanes = 3;
     g.xdec[1] = g.xdec[2] = 1;
-    g.nslots = J.nslots;
-    J.ctx = od_hip_ctx_create(device, &g);
-    if (J.ctx != NULL) J.feed = od_hip_enc_feed_create(J.ctx);
-    if (J.ctx == NULL || J.feed == NULL || od_hipenc_level_params(p, qm, q, beta) != 0) {
-      long rc;
-      rc = J.ctx == NULL || J.feed == NULL ? OD_HIP_ENODEV : OD_HIP_EINVAL;
-      if (J.feed != NULL) od_hip_enc_feed_destroy(J.feed);
-      if (J.ctx != NULL) od_hip_ctx_destroy(J.ctx);
-      free(J.done);
-      free(J.pkt);
-      free(J.pkt_len);
-      free(th);
-      pthread_mutex_destroy(&J.mu);
-      pthread_cond_destroy(&J.cv);
-      return rc;
-    }
-    for (l = 0; l < 4; l++) od_hip_enc_feed_set_level(J.feed, l, qm[l], q[l], beta[l]);
+    g.nslots = S->nslots;
+    S->ctx = od_hip_ctx_create(device, &g);
+    if (S->ctx != NULL) S->feed = od_hip_enc_feed_create(S->ctx);
+    if (S->ctx == NULL || S->feed == NULL) rc = OD_HIP_ENODEV;
+    else if (od_hipenc_level_params(p, qm, q, beta) != 0) rc = OD_HIP_EINVAL;
+    else for (l = 0; l < 4; l++) od_hip_enc_feed_set_level(S->feed, l, qm[l], q[l], beta[l]);
   }
-  for (i = 0; i < nw; i++) pthread_create(&th[i], NULL, worker, &J);
-  pthread_mutex_lock(&J.mu);
-  while (J.encoders_ready < nw) pthread_cond_wait(&J.cv, &J.mu);
+  if (rc != 0) {
+    S->nw = 0;
+    od_hipenc_close(S);
+    if (err != NULL) *err = rc;
+    return NULL;
+  }
+  for (i = 0; i < nw; i++) pthread_create(&S->th[i], NULL, worker, S);
+  pthread_mutex_lock(&S->mu);
+  while (S->encoders_ready < nw) pthread_cond_wait(&S->cv, &S->mu);
+  rc = S->setup_failed;
+  pthread_mutex_unlock(&S->mu);
+  S->t_setup_s = now_s() - t0;
+  if (rc) {
+    od_hipenc_close(S);
+    if (err != NULL) *err = use_device ? OD_HIP_ENODEV : OD_HIP_EINVAL;
+    return NULL;
+  }
+  return S;
+}
+
+long od_hipenc_encode(od_hipenc *S, int nframes, long frame0, const unsigned char *frames,
+ const od_hip_feed_level *views, unsigned char *pkt_out, long pkt_cap,
+ od_hipenc_stats *stats) {
+  job J;
+  int i;
+  long total;
+  long used;
+  int nospace;
+  double t0;
+  if (S == NULL || frames == NULL || nframes < 1) return OD_HIP_EFAULT;
+  if (views != NULL && S->ctx != NULL) return OD_HIP_EINVAL;
+  nospace = 0;
+  memset(&J, 0, sizeof(J));
+  J.nframes = nframes;
+  J.frame0 = frame0;
+  J.frames = frames;
+  J.views = views;
+  /* frame f lives in slot f % nslots.  A stream that does not fit the slots uses two
+     half-buffers; batch k (frames [k*batch, (k+1)*batch)) may be uploaded and launched
+     as soon as batch k-2, the previous user of its half, is completely coded. */
+  if (nframes <= S->nslots) {
+    J.batch = nframes;
+    J.nslots = nframes;
+  }
+  else {
+    J.batch = S->nslots/2;
+    J.nslots = 2*J.batch;
+  }
+  J.done = (unsigned char *)calloc(nframes, 1);
+  J.pkt = (unsigned char **)calloc(nframes, sizeof(*J.pkt));
+  J.pkt_len = (long *)calloc(nframes, sizeof(*J.pkt_len));
+  if (J.done == NULL || J.pkt == NULL || J.pkt_len == NULL) {
+    free(J.done);
+    free(J.pkt);
+    free(J.pkt_len);
+    return OD_HIP_EFAULT;
+  }
+  J.st.t_setup_s = S->t_setup_s;
+  pthread_mutex_lock(&S->mu);
   t0 = now_s();
-  J.st.t_setup_s = t0 - t_setup0;
-  if (J.ctx == NULL) {
+  S->J = &J;
+  S->job_seq++;
+  if (S->ctx == NULL) {
     /* host-only modes: everything is encodable at once */
     J.launched_upto = nframes;
-    J.go = 2;
-    pthread_cond_broadcast(&J.cv);
+    J.go = 1;
+    pthread_cond_broadcast(&S->cv);
   }
   else {
     int b0;
     for (b0 = 0; b0 < nframes && !J.failed; b0 += J.batch) {
       double ta;
       double tb;
+      int rc;
       /* this batch's half-buffer (device slots + pinned host mirror) was last used
          by batch k-2: wait until all of that batch's frames are completely coded */
-      while (!J.failed && J.done_prefix < b0 - J.batch) pthread_cond_wait(&J.cv, &J.mu);
+      while (!J.failed && J.done_prefix < b0 - J.batch) pthread_cond_wait(&S->cv, &S->mu);
       J.batch0 = b0;
       J.batch_n = nframes - b0 < J.batch ? nframes - b0 : J.batch;
       J.uploaded = 0;
       J.next_upload = b0;
       J.go = 1;
       ta = now_s();
-      pthread_cond_broadcast(&J.cv);
-      while (!J.failed && J.uploaded < J.batch_n) pthread_cond_wait(&J.cv, &J.mu);
+      pthread_cond_broadcast(&S->cv);
+      while (!J.failed && J.uploaded < J.batch_n) pthread_cond_wait(&S->cv, &S->mu);
       tb = now_s();
       J.st.t_upload_s += tb - ta;
       if (J.failed) break;
-      {
-        int rc;
-        /* ~40 launches and event waits: workers coding the previous batch must be able to
-           take J.mu meanwhile (frames [b0, b0 + batch_n) are not claimable before
-           launched_upto moves) */
-        pthread_mutex_unlock(&J.mu);
-        rc = od_hip_enc_feed_run(J.feed, b0 % J.nslots, J.batch_n);
-        pthread_mutex_lock(&J.mu);
-        if (rc != 0) {
-          J.failed = 1;
-          break;
-        }
+      /* ~40 launches and event waits: workers coding the previous batch must be able to
+         take the lock meanwhile (frames [b0, b0 + batch_n) are not claimable before
+         launched_upto moves) */
+      pthread_mutex_unlock(&S->mu);
+      rc = od_hip_enc_feed_run(S->feed, b0 % J.nslots, J.batch_n);
+      pthread_mutex_lock(&S->mu);
+      if (rc != 0) {
+        J.failed = 1;
+        break;
       }
       J.st.t_launch_s += now_s() - tb;
       J.launched_upto = b0 + J.batch_n;
-      pthread_cond_broadcast(&J.cv);
+      pthread_cond_broadcast(&S->cv);
     }
-    pthread_cond_broadcast(&J.cv);
+    if (J.failed) J.go = 1;
+    pthread_cond_broadcast(&S->cv);
   }
-  pthread_mutex_unlock(&J.mu);
-  for (i = 0; i < nw; i++) pthread_join(th[i], NULL);
+  while (J.workers_done < S->nw) pthread_cond_wait(&S->cv, &S->mu);
+  S->J = NULL;
+  pthread_mutex_unlock(&S->mu);
   J.st.t_total_s = now_s() - t0;
   /* All packets or none: a stream with a frame missing (or out of order) is corrupt, so
      the space needed is summed first and a buffer that is too small fails the call. */
@@ -816,17 +892,39 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
       free(J.pkt[i]);
     }
   }
-  if (J.feed != NULL) od_hip_enc_feed_destroy(J.feed);
-  if (J.ctx != NULL) od_hip_ctx_destroy(J.ctx);
   free(J.pkt);
   free(J.pkt_len);
   free(J.done);
-  free(th);
-  pthread_mutex_destroy(&J.mu);
-  pthread_cond_destroy(&J.cv);
   if (stats != NULL) *stats = J.st;
   if (J.failed) return OD_HIP_EINVAL;
   return nospace ? OD_HIP_ENOSPC : total;
+}
+
+long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
+ const unsigned char *frames, const od_hip_feed_level *views, int use_device,
+ int device, unsigned char *pkt_out, long pkt_cap, od_hipenc_stats *stats) {
+  od_hipenc_params q;
+  od_hipenc *S;
+  long n;
+  int err;
+  if (p == NULL || frames == NULL || nframes < 1) return OD_HIP_EFAULT;
+  q = *p;
+  if (q.nworkers > nframes) q.nworkers = nframes;
+  /* one-shot: size the slots for this stream (bounded like the session default) */
+  if (q.batch <= 0) {
+    double per_frame;
+    int cap;
+    per_frame = 49.*((p->pic_width + 63) & ~63)*((p->pic_height + 63) & ~63);
+    cap = (int)(6e9/per_frame);
+    if (cap < 2*q.nworkers) cap = 2*q.nworkers;
+    q.batch = nframes <= cap ? nframes : cap;
+  }
+  else if (q.batch < nframes) q.batch *= 2;      /* `batch` frames per half-buffer, as before */
+  S = od_hipenc_open(&q, use_device && views == NULL, device, &err);
+  if (S == NULL) return err;
+  n = od_hipenc_encode(S, nframes, 0, frames, views, pkt_out, pkt_cap, stats);
+  od_hipenc_close(S);
+  return n;
 }
 
 /* The padded input planes daala_encode_img_in() codes for one frame (the

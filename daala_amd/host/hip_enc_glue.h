@@ -21,7 +21,7 @@ typedef struct od_hipenc_params {
   int32_t masking;                 /* OD_SET_ACTIVITY_MASKING */
   int32_t nworkers;                /* host threads, one reference encoder context each */
   int32_t check;                   /* OD_CHECKGPU: run the C search as well and compare */
-  int32_t batch;                   /* frames resident on the device at once (0: all) */
+  int32_t batch;                   /* frame slots resident on the device (0: default) */
 } od_hipenc_params;
 
 typedef struct od_hipenc_stats {
@@ -56,6 +56,20 @@ typedef struct od_hipenc_stats {
 long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
  const unsigned char *frames, const od_hip_feed_level *views, int use_device,
  int device, unsigned char *pkt_out, long pkt_cap, od_hipenc_stats *stats);
+
+/* The same as a session: od_hipenc_open creates the p->nworkers host workers (one
+ * reference encoder context each) and, with use_device, the device context + encoder feed
+ * with p->batch frame slots (0: a default bounded by pinned host memory) ONCE;
+ * od_hipenc_encode codes one stream of nframes independent keyframes whose first frame
+ * has stream index frame0 (a stream longer than the slots runs through two half-buffers);
+ * views only without a device (tests).  A session codes one stream at a time.
+ * od_hipenc_open returns NULL and sets *err (OD_HIP_ENODEV: no device, no encode). */
+typedef struct od_hipenc od_hipenc;
+od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device, int *err);
+long od_hipenc_encode(od_hipenc *s, int nframes, long frame0, const unsigned char *frames,
+ const od_hip_feed_level *views, unsigned char *pkt_out, long pkt_cap,
+ od_hipenc_stats *stats);
+void od_hipenc_close(od_hipenc *s);
 
 /* The per-level PVQ parameters the device needs, read from a live reference
  * encoder context of these settings (what bench/tests pass to
