@@ -20,7 +20,7 @@ struct od_hip_enc_feed {
     double beta[11];
     // pinned host mirrors, all slots: [slot][...]
     int32_t *ncand = nullptr, *k = nullptr, *qg = nullptr, *y = nullptr;
-    double *cos_dist = nullptr, *cg = nullptr;
+    double *cos_dist = nullptr, *cg = nullptr, *g = nullptr;
     od_coeff *plane = nullptr;            // [slot][h][w] the pyramid level itself
   } lev[4];
 };
@@ -36,6 +36,7 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
     if (l.k) (void)hipHostFree(l.k);
     if (l.qg) (void)hipHostFree(l.qg);
     if (l.cg) (void)hipHostFree(l.cg);
+    if (l.g) (void)hipHostFree(l.g);
     if (l.y) (void)hipHostFree(l.y);
     if (l.cos_dist) (void)hipHostFree(l.cos_dist);
     if (l.plane) (void)hipHostFree(l.plane);
@@ -74,6 +75,7 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
     ok = ok && hipHostMalloc((void **)&L.k, ns*2*L.nrec*4) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.qg, ns*2*L.nrec*4) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.cg, ns*L.nrec*8) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.g, ns*L.nrec*8) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.cos_dist, ns*2*L.nrec*8) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.y, ns*L.ny*4) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.plane, ns*ctx->psz[0]*sizeof(od_coeff)) == hipSuccess;
@@ -130,6 +132,7 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
       PvqSoA &o = ctx->pvq[0][l];
       HIPCHK(hipMemcpyAsync(L.ncand + s*L.nrec, o.ncand + s*L.nrec, L.nrec*4, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.cg + s*L.nrec, o.cg + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(L.g + s*L.nrec, o.g + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.qg + s*2*L.nrec, o.qg + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.k + s*2*L.nrec, o.k + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.cos_dist + s*2*L.nrec, o.cos_dist + s*2*L.nrec, 2*L.nrec*8, hipMemcpyDeviceToHost, f->copy));
@@ -160,6 +163,7 @@ int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4])
     v.k = L.k + slot*2*L.nrec;
     v.qg = L.qg + slot*2*L.nrec;
     v.cg = L.cg + slot*L.nrec;
+    v.g = L.g + slot*L.nrec;
     v.cos_dist = L.cos_dist + slot*2*L.nrec;
     v.y = L.y + slot*L.ny;
     v.lev = L.plane + (size_t)slot*f->ctx->psz[0];

@@ -51,6 +51,7 @@ class Stats(ctypes.Structure):
     _fields_ = [('dev_hits', ctypes.c_int64), ('cpu_noref_luma', ctypes.c_int64),
                 ('cpu_other', ctypes.c_int64), ('g2_mismatch', ctypes.c_int64),
                 ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
+                ('pvq_check_fail', ctypes.c_int64),
                 ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
                 ('fdct_hits', ctypes.c_int64), ('fdct_check_fail', ctypes.c_int64),
                 ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
@@ -67,7 +68,7 @@ class FeedLevel(ctypes.Structure):
     """Mirror of od_hip_feed_level (include/daala_hip.h section 4b)."""
     _fields_ = [('n', c_int32), ('nbands', c_int32), ('nblk', c_int32), ('nbx', c_int32),
                 ('off', c_int32*11), ('pad', c_int32),
-                ('cg', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P),
+                ('cg', F64P), ('g', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P),
                 ('cos_dist', F64P), ('y', I32P), ('lev', I32P), ('lev_stride', c_int32),
                 ('pad2', c_int32)]
 

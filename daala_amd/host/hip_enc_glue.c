@@ -21,6 +21,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <sched.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,121 +32,34 @@
 #include "pvq_encoder.h"
 #include "partition.h"
 
-#include "hip_enc_glue.h"
+#include "hip_glue_int.h"
 
-/* kept reference definitions (see the integration build recipe, pvq_hook_tail.c, encode_tu.c) */
-double od_ref_pvq_search_rdo_double_cpu(const double *xcoeff, int n, int k,
- od_coeff *ypulse, double g2);
-int od_pvq_encode_cpu(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
- od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,
- int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
- const int16_t *qm_inv);
+__thread glue_tls od_hipenc_tls;
+#define T od_hipenc_tls
+
 void od_hipenc_copy_pad(daala_enc_ctx *enc, od_img *img);
 
-static double now_s(void) {
+double od_hipenc_now(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9*ts.tv_nsec;
 }
+#define now_s od_hipenc_now
 
-/* ------------------------------------------------------------------------ */
-/* Per-thread state: which frame's feed this worker consumes and where in the
-   call sequence of the current block it is. */
-typedef struct glue_tls {
-  const od_hip_feed_level *lev;   /* 4 views, or NULL: plain reference */
-  int active;                     /* inside od_pvq_encode of a keyframe luma block */
-  int level;
-  int blk;
-  int band;
-  int cand;
-  int check;
-  int time_cpu;
-  int pli;                        /* plane of the block being coded */
-  daala_enc_ctx *enc;             /* encoder of the frame being coded by this thread */
-  od_dct_func_2d fdct_cpu[OD_NBSIZES];   /* the context's own fdct_2d entries */
-  od_hip_dering *dr;              /* this worker's device deringing object, or NULL */
-  int16_t *dr_out[3];             /* deringed planes of the frame being coded */
-  int dr_valid;                   /* dr_out holds the current frame */
-  int dr_error;
-  od_hipenc_stats st;
-} glue_tls;
-
-static __thread glue_tls T;
-
-static int is_noref_size(int n) {
-  return n == 15 || n == 8 || n == 32 || n == 128;
-}
-
+/* pvq_search_rdo_double as the reference's own pvq_theta calls it (inter frames, and the
+   reference's od_pvq_encode in check mode): the kept C search, timed. */
 double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypulse,
  double g2) {
   double t0;
   double r;
-  int from_feed;
-  from_feed = 0;
-  if (T.active && is_noref_size(n)) {
-    const od_hip_feed_level *L;
-    size_t nrec;
-    L = &T.lev[T.level];
-    nrec = (size_t)L->nbands*L->nblk;
-    /* The no-reference loop of pvq_theta runs for every band of a keyframe luma
-       block, bands in order, candidates i = max(1,floor(cg)) .. ceil(cg) in
-       order: the next call is the next candidate the device enumerated. */
-    while (T.band < L->nbands
-     && T.cand >= L->ncand[(size_t)T.band*L->nblk + T.blk]) {
-      T.band++;
-      T.cand = 0;
-    }
-    if (T.band < L->nbands) {
-      size_t rec;
-      int nb;
-      rec = (size_t)T.band*L->nblk + T.blk;
-      nb = L->off[T.band + 1] - L->off[T.band];
-      if (nb == n && L->k[T.cand*nrec + rec] == k) {
-        if ((double)L->qg[T.cand*nrec + rec]*L->cg[rec] == g2) {
-          const int32_t *src;
-          src = L->y + (size_t)2*L->nblk*(L->off[T.band] - 1)
-           + ((size_t)T.cand*L->nblk + T.blk)*nb;
-          if (T.check) {
-            od_coeff ytmp[128];
-            double rc;
-            rc = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ytmp, g2);
-            if (rc != L->cos_dist[T.cand*nrec + rec]
-             || memcmp(ytmp, src, sizeof(od_coeff)*n) != 0) {
-              T.st.check_fail++;
-            }
-          }
-          memcpy(ypulse, src, sizeof(od_coeff)*n);
-          r = L->cos_dist[T.cand*nrec + rec];
-          T.st.dev_hits++;
-          T.cand++;
-          return r;
-        }
-        /* Same candidate, but the host's cg differs from the device's in the last
-           place (beta = 1.5 goes through libm pow): the search must see the
-           host's g2, so run it here and stay in step. */
-        T.st.g2_mismatch++;
-        T.cand++;
-      }
-      else {
-        T.st.lost_sync++;
-        T.active = 0;
-      }
-    }
-    else {
-      T.st.lost_sync++;
-      T.active = 0;
-    }
-    from_feed = 1;
-  }
-  if (from_feed) T.st.cpu_noref_luma++;
-  else T.st.cpu_other++;
+  T.st.cpu_other++;
   if (T.time_cpu) {
     double dt;
     t0 = now_s();
     r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
     dt = now_s() - t0;
     T.st.search_cpu_s += dt;
-    T.st.search_class_s[(T.pli != 0)*2 + !is_noref_size(n)] += dt;
+    T.st.search_class_s[(T.pli != 0)*2 + !(n == 15 || n == 8 || n == 32 || n == 128)] += dt;
     return r;
   }
   return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
@@ -285,52 +199,49 @@ FDCT_HOOK(hook_fdct8, 1)
 FDCT_HOOK(hook_fdct16, 2)
 FDCT_HOOK(hook_fdct32, 3)
 
+/* od_encode_checkpoint / od_encode_rollback (src/encode.c:600-608) as the block-size RDO
+   recursion calls them (several times per non-leaf block, :1124, :1571-1642): 12 KB of the
+   19.7 KB adaptation context are the Haar-wavelet CDFs, which only lossless frames touch
+   (od_wavelet_quantize, :798-898; mbctx.use_haar_wavelet, :3002) - on lossy frames neither
+   copy can differ there, so they are left out. */
+#define ADAPT_HEAD (offsetof(od_adapt_ctx, haar_coeff_cdf))
+#define ADAPT_TAIL (offsetof(od_adapt_ctx, clpf_cdf))
+static int lossy_frame(const daala_enc_ctx *enc) {
+  return !enc->use_haar_wavelet && enc->quality[0] != 0;
+}
+
+void od_encode_checkpoint(const daala_enc_ctx *enc, od_rollback_buffer *rbuf) {
+  od_ec_enc_checkpoint(&rbuf->ec, &enc->ec);
+  if (lossy_frame(enc)) {
+    memcpy(&rbuf->adapt, &enc->state.adapt, ADAPT_HEAD);
+    memcpy((char *)&rbuf->adapt + ADAPT_TAIL, (const char *)&enc->state.adapt + ADAPT_TAIL,
+     sizeof(od_adapt_ctx) - ADAPT_TAIL);
+  }
+  else OD_COPY(&rbuf->adapt, &enc->state.adapt, 1);
+}
+
+void od_encode_rollback(daala_enc_ctx *enc, const od_rollback_buffer *rbuf) {
+  od_ec_enc_rollback(&enc->ec, &rbuf->ec);
+  if (lossy_frame(enc)) {
+    memcpy(&enc->state.adapt, &rbuf->adapt, ADAPT_HEAD);
+    memcpy((char *)&enc->state.adapt + ADAPT_TAIL, (const char *)&rbuf->adapt + ADAPT_TAIL,
+     sizeof(od_adapt_ctx) - ADAPT_TAIL);
+  }
+  else OD_COPY(&enc->state.adapt, &rbuf->adapt, 1);
+}
+
+/* od_pvq_encode as od_block_encode calls it (src/encode.c:1187): keyframes go through
+   hip_pvq_host.c (the feed consumer), inter frames through the reference's definition. */
 int od_pvq_encode(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out,
  int q0, int pli, int bs, const double *beta, int robust, int is_keyframe,
  int q_scaling, int bx, int by, const int16_t *qm, const int16_t *qm_inv) {
-  int ret;
-  T.active = 0;
   T.pli = pli;
-  if (T.lev != NULL && is_keyframe && pli == 0 && bs >= 0 && bs < 4) {
-    const od_hip_feed_level *L;
-    /* bx, by arrive in 4x4 units (src/encode.c:1101-1102) */
-    T.level = 3 - bs;
-    L = &T.lev[T.level];
-    T.blk = (by >> bs)*L->nbx + (bx >> bs);
-    T.band = 0;
-    T.cand = 0;
-    T.active = T.blk >= 0 && T.blk < L->nblk;
-    if (T.active) {
-      /* The feed is band-major (the device's coalesced layout), so the records of
-         one block sit nblk entries apart: start pulling them in now, pvq_theta's
-         own arithmetic hides the latency. */
-      size_t nrec;
-      int b;
-      nrec = (size_t)L->nbands*L->nblk;
-      for (b = 0; b < L->nbands; b++) {
-        size_t rec;
-        int nb;
-        int c;
-        rec = (size_t)b*L->nblk + T.blk;
-        nb = L->off[b + 1] - L->off[b];
-        __builtin_prefetch(L->ncand + rec);
-        __builtin_prefetch(L->cg + rec);
-        for (c = 0; c < 2; c++) {
-          const int32_t *y;
-          int o;
-          __builtin_prefetch(L->k + c*nrec + rec);
-          __builtin_prefetch(L->qg + c*nrec + rec);
-          __builtin_prefetch(L->cos_dist + c*nrec + rec);
-          y = L->y + (size_t)2*L->nblk*(L->off[b] - 1) + ((size_t)c*L->nblk + T.blk)*nb;
-          for (o = 0; o < nb; o += 16) __builtin_prefetch(y + o);
-        }
-      }
-    }
+  if (T.host_pvq) {
+    return od_hip_pvq_encode_host(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe,
+     q_scaling, bx, by, qm, qm_inv);
   }
-  ret = od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust,
-   is_keyframe, q_scaling, bx, by, qm, qm_inv);
-  T.active = 0;
-  return ret;
+  return od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe,
+   q_scaling, bx, by, qm, qm_inv);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -480,6 +391,8 @@ struct od_hipenc {
   int setup_failed;
   int quit;
   int next_worker_id;
+  int host_pvq;         /* keyframe od_pvq_encode: 1 hip_pvq_host.c (default), 0 the reference's */
+  int time_cpu;         /* per-call timers around the C searches (HIPENC_TIME=1) */
   long job_seq;         /* number of jobs submitted so far */
   job *J;               /* the job being worked on, or NULL */
   double t_setup_s;
@@ -492,6 +405,7 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->g2_mismatch += b->g2_mismatch;
   a->lost_sync += b->lost_sync;
   a->check_fail += b->check_fail;
+  a->pvq_check_fail += b->pvq_check_fail;
   a->search_cpu_s += b->search_cpu_s;
   a->fdct_hits += b->fdct_hits;
   a->fdct_check_fail += b->fdct_check_fail;
@@ -600,7 +514,8 @@ static void *worker(void *arg) {
   pin_worker(S->next_worker_id++);
   pthread_mutex_unlock(&S->mu);
   T.check = S->p.check;
-  T.time_cpu = 1;
+  T.time_cpu = S->time_cpu;
+  T.host_pvq = S->host_pvq;
   enc = make_encoder(&S->p, S->p.pic_width, S->p.pic_height);
   if (enc != NULL) {
     static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
@@ -716,6 +631,13 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
   }
   t0 = now_s();
   S->p = *p;
+  {
+    const char *e;
+    e = getenv("HIPENC_HOST_PVQ");
+    S->host_pvq = e == NULL || atoi(e) != 0;
+    e = getenv("HIPENC_TIME");
+    S->time_cpu = e != NULL && atoi(e) != 0;
+  }
   S->use_device = use_device;
   S->device = device;
   nw = p->nworkers < 1 ? 1 : p->nworkers;

@@ -31,6 +31,7 @@ typedef struct od_hipenc_stats {
   int64_t g2_mismatch;     /* candidate present but host g2 != device qg*cg (libm pow, 1 ulp) */
   int64_t lost_sync;       /* blocks whose call sequence did not match the feed */
   int64_t check_fail;      /* check mode: device answer != C answer (must be 0) */
+  int64_t pvq_check_fail;  /* check mode: block result != the reference's od_pvq_encode (must be 0) */
   double search_cpu_s;     /* seconds inside the C pvq_search_rdo_double, all workers */
   double search_class_s[4];/* ... split: luma no-ref, luma with-ref, chroma no-ref, chroma with-ref */
   int64_t fdct_hits;       /* luma fdct_2d calls answered from the device pyramid */

@@ -1,0 +1,53 @@
+/* hip_glue_int.h - state shared by the files of the reference-side glue
+ * (hip_enc_glue.c, hip_pvq_host.c).  Not part of the C-ABI. */
+#ifndef HIP_GLUE_INT_H
+#define HIP_GLUE_INT_H
+
+#include "encint.h"
+#include "hip_enc_glue.h"
+
+/* Per-thread state: which frame's feed this worker consumes. */
+typedef struct glue_tls {
+  const od_hip_feed_level *lev;   /* 4 views, or NULL: plain reference */
+  int check;
+  int time_cpu;
+  int pli;                        /* plane of the block being coded */
+  int host_pvq;                   /* 1: od_pvq_encode is hip_pvq_host.c's, 0: the reference's */
+  daala_enc_ctx *enc;             /* encoder of the frame being coded by this thread */
+  od_dct_func_2d fdct_cpu[OD_NBSIZES];   /* the context's own fdct_2d entries */
+  od_hip_dering *dr;              /* this worker's device deringing object, or NULL */
+  int16_t *dr_out[3];             /* deringed planes of the frame being coded */
+  int dr_valid;                   /* dr_out holds the current frame */
+  int dr_error;
+  od_hipenc_stats st;
+} glue_tls;
+
+extern __thread glue_tls od_hipenc_tls;
+
+/* kept reference definitions (the build recipe renames them, see Makefile) */
+double od_ref_pvq_search_rdo_double_cpu(const double *xcoeff, int n, int k,
+ od_coeff *ypulse, double g2);
+int od_pvq_encode_cpu(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
+ od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,
+ int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
+ const int16_t *qm_inv);
+void od_ref_pvq_encode_partition(od_ec_enc *ec, int qg, int theta, int max_theta,
+ const od_coeff *in, int n, int k, generic_encoder model[3], od_adapt_ctx *adapt,
+ int *exg, int *ext, int nodesync, int cdf_ctx, int is_keyframe, int code_skip,
+ int skip_rest, int bs);
+double od_ref_pvq_rate(int qg, int icgr, int theta, int ts, const od_adapt_ctx *adapt,
+ const od_coeff *y0, int k, int n, int is_keyframe, int pli, int bs);
+void od_encode_checkpoint_cpu(const daala_enc_ctx *enc, od_rollback_buffer *rbuf);
+void od_encode_rollback_cpu(daala_enc_ctx *enc, const od_rollback_buffer *rbuf);
+
+double od_hipenc_now(void);
+
+/* hip_pvq_host.c */
+int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
+ od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,
+ int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
+ const int16_t *qm_inv);
+double od_hip_pvq_rate(int qg, int icgr, int theta, int ts, const od_adapt_ctx *adapt,
+ const od_coeff *y0, int k, int n, int is_keyframe, int pli, int bs);
+
+#endif

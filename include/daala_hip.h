@@ -255,6 +255,7 @@ typedef struct od_hip_feed_level {
   int32_t off[11];          /* band boundaries in coding order */
   int32_t pad;
   const double *cg;         /* [nbands*nblk] companded gain of the band */
+  const double *g;          /* [nbands*nblk] its uncompanded gain sqrt(acc) (src/pvq.c:456-464): exact */
   const int32_t *ncand;     /* [nbands*nblk] 0..2 */
   const int32_t *qg;        /* [2][nbands*nblk] gain index i; the search's g2 = qg*cg */
   const int32_t *k;         /* [2][nbands*nblk] */

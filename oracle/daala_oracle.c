@@ -1223,7 +1223,7 @@ void orc_decode_tail(coeff *const c[3], uint8_t *const rec[3], int nplanes, int 
    lev: level plane (w x h, blocks of n x n); qm: the n*n QM of this block size;
    q, beta: per band.  Arrays sized as the header says. */
 void orc_feed_level(const coeff *lev, int w, int h, int n, const int16_t *qm,
- const int *q, const double *beta, double *cg, int32_t *ncand, int32_t *qg,
+ const int *q, const double *beta, double *cg, double *gout, int32_t *ncand, int32_t *qg,
  int32_t *k, double *cos_dist, int32_t *y) {
   int off[11], nb = orc_band_offsets(n, off), nbx = w/n, nby = h/n, nblk = nbx*nby;
   int bx, by, b, c;
@@ -1241,6 +1241,7 @@ void orc_feed_level(const coeff *lev, int w, int h, int n, const int16_t *qm,
         nc = orc_pvq_noref_candidates(co + off[b], nn, q[b], beta[b], qm + off[b], 1,
          &cg[r], &g, cqg, ck, cd, dist, yy);
         ncand[r] = nc;
+        gout[r] = g;
         for (c = 0; c < 2; c++) {
           int32_t *dst = y + (size_t)2*nblk*(off[b] - 1) + ((size_t)c*nblk + blk)*nn;
           qg[c*nrec + r] = c < nc ? cqg[c] : 0;

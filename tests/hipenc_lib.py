@@ -35,19 +35,19 @@ class OracleFeed:
             nbx, nblk = fw//n, (fw//n)*(fh//n)
             nrec = nb*nblk
             ncoded = min(n*n, 512)
-            a = {'cg': np.zeros(nrec), 'ncand': np.zeros(nrec, np.int32),
+            a = {'cg': np.zeros(nrec), 'g': np.zeros(nrec), 'ncand': np.zeros(nrec, np.int32),
                  'qg': np.zeros(2*nrec, np.int32), 'k': np.zeros(2*nrec, np.int32),
                  'cos_dist': np.zeros(2*nrec), 'y': np.zeros(2*nblk*(ncoded - 1), np.int32)}
             qi = np.ascontiguousarray(q[l].astype(np.int32))
             o.orc_feed_level(p32(lev[l]), fw, fh, n, p16(np.ascontiguousarray(qm[l])),
-                             p32(qi), pf64(np.ascontiguousarray(beta[l])), pf64(a['cg']),
+                             p32(qi), pf64(np.ascontiguousarray(beta[l])), pf64(a['cg']), pf64(a['g']),
                              p32(a['ncand']), p32(a['qg']), p32(a['k']), pf64(a['cos_dist']),
                              p32(a['y']))
             v = FeedLevel()
             v.n, v.nbands, v.nblk, v.nbx = n, nb, nblk, nbx
             for i, x in enumerate(off):
                 v.off[i] = x
-            v.cg, v.ncand, v.qg, v.k = pf64(a['cg']), p32(a['ncand']), p32(a['qg']), p32(a['k'])
+            v.cg, v.g, v.ncand, v.qg, v.k = pf64(a['cg']), pf64(a['g']), p32(a['ncand']), p32(a['qg']), p32(a['k'])
             v.cos_dist, v.y = pf64(a['cos_dist']), p32(a['y'])
             v.lev, v.lev_stride = p32(lev[l]), fw
             a['lev'] = lev[l]
