@@ -38,7 +38,7 @@ class FeedLevel(ctypes.Structure):
     """od_hip_feed_level (include/daala_hip.h section 4b)."""
     _fields_ = [('n', ctypes.c_int32), ('nbands', ctypes.c_int32), ('nblk', ctypes.c_int32),
                 ('nbx', ctypes.c_int32), ('off', ctypes.c_int32*11), ('pad', ctypes.c_int32),
-                ('cg', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P), ('cos_dist', F64P),
+                ('cg', F64P), ('g', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P), ('cos_dist', F64P),
                 ('y', I32P), ('lev', I32P), ('lev_stride', ctypes.c_int32), ('pad2', ctypes.c_int32)]
 
 
@@ -371,6 +371,7 @@ class DaalaHip(object):
             out.append({'n': v.n, 'nbands': v.nbands, 'nblk': v.nblk, 'nbx': v.nbx,
                         'off': list(v.off)[:v.nbands + 1],
                         'cg': np.ctypeslib.as_array(v.cg, (nrec,)).copy(),
+                        'g': np.ctypeslib.as_array(v.g, (nrec,)).copy(),
                         'ncand': np.ctypeslib.as_array(v.ncand, (nrec,)).copy(),
                         'qg': np.ctypeslib.as_array(v.qg, (2*nrec,)).copy(),
                         'k': np.ctypeslib.as_array(v.k, (2*nrec,)).copy(),

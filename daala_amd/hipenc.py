@@ -64,13 +64,7 @@ class Stats(ctypes.Structure):
                 for k, _ in self._fields_}
 
 
-class FeedLevel(ctypes.Structure):
-    """Mirror of od_hip_feed_level (include/daala_hip.h section 4b)."""
-    _fields_ = [('n', c_int32), ('nbands', c_int32), ('nblk', c_int32), ('nbx', c_int32),
-                ('off', c_int32*11), ('pad', c_int32),
-                ('cg', F64P), ('g', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P),
-                ('cos_dist', F64P), ('y', I32P), ('lev', I32P), ('lev_stride', c_int32),
-                ('pad2', c_int32)]
+from daala_amd.binding import FeedLevel     # od_hip_feed_level: ONE mirror of the C struct
 
 
 _lib = None

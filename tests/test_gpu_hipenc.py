@@ -51,6 +51,7 @@ def test_device_feed_equals_oracle_feed(masking):
         nrec = g['nbands']*g['nblk']
         assert np.array_equal(a['lev'], g['lev']), ('pyramid plane', l)
         assert np.array_equal(a['ncand'], g['ncand'])
+        assert np.array_equal(a['g'].view(np.int64), g['g'].view(np.int64)), ('gain', l)
         assert np.array_equal(a['cg'].view(np.int64), g['cg'].view(np.int64)) or masking == 1
         if masking == 1:   # beta = 1.5: libm pow on the host, DESIGN.md section 5
             # (pow differs by <= 1 ulp in < 0.1 % of the bands; the division by q that
