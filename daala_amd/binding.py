@@ -312,6 +312,31 @@ class DaalaHip(object):
                                               pli, level, qm.ctypes.data_as(I16P), _p32(q),
                                               beta.ctypes.data_as(F64P)))
 
+    def _pvq_call(self, fn, pli, level, qm, q, beta, slot0, nslots, with_qm=True):
+        qa = np.ascontiguousarray(q, dtype=np.int32)
+        ba = np.ascontiguousarray(beta, dtype=np.float64)
+        args = [self.ctx, slot0, nslots or self.nslots - slot0, pli, level]
+        if with_qm:
+            qma = np.ascontiguousarray(qm, dtype=np.int16)
+            fn.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, c_int, I16P, I32P, F64P]
+            args.append(qma.ctypes.data_as(I16P))
+        else:
+            fn.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, c_int, I32P, F64P]
+        _chk(fn(*args, _p32(qa), ba.ctypes.data_as(F64P)))
+
+    def pvq_gains(self, pli, level, qm, q, beta, slot0=0, nslots=None):
+        """Device pass 1: exact uncompanded gains of every band (od_hip_pvq_gains)."""
+        self._pvq_call(self.lib.od_hip_pvq_gains, pli, level, qm, q, beta, slot0, nslots)
+
+    def pvq_compand_level(self, pli, level, q, beta, slot0=0, nslots=None):
+        """Host stage: g down, cg = od_gain_compand(g) with the host's libm, cg up."""
+        self._pvq_call(self.lib.od_hip_pvq_compand_level, pli, level, None, q, beta, slot0, nslots,
+                       with_qm=False)
+
+    def pvq_search(self, pli, level, qm, q, beta, slot0=0, nslots=None):
+        """Device pass 2: candidates, K, codeword searches with the uploaded cg."""
+        self._pvq_call(self.lib.od_hip_pvq_search, pli, level, qm, q, beta, slot0, nslots)
+
     def pvq_nblocks(self, pli, level):
         return _chk(self.lib.od_hip_pvq_nblocks(self.ctx, pli, level))
 

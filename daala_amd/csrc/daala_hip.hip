@@ -145,7 +145,6 @@ struct od_hip_ctx {
   uint16_t *tab[OD_HIP_NBSIZES];             // coding tables on device
   int16_t *qm_dev;                           // scratch QM (1024 int16)
   double *rsq;                               // 1/sqrt(i) table (pvq_rsqrt_tab)
-  int pvq_impl = 3;                          // 3 = register-resident, 2 = LDS-resident
   // The PVQ launches of a step (35 of them, all independent: they only read pyramid
   // levels) go round-robin over a few side streams so that the tail of one kernel - a
   // few waves with large K - overlaps the next kernels instead of idling the chip.
@@ -238,19 +237,21 @@ int check_slots(od_hip_ctx *ctx, int slot0, int nslots, bool join = true) {
 namespace {
 template <int N>
 void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk, int nslots, hipStream_t s,
-                int impl, const double *rsq) {
-  if (impl == 2 || (impl == 3 && N == 32 && PVQ_G32 == 1)) {   // N = 32, one lane per band: the LDS variant is faster
-    dim3 grid((unsigned)((nblk + 63)/64), nlist, nslots);
-    hipLaunchKernelGGL(k_pvq_noref<N>, grid, dim3(64), 0, s, a);
-  }
-  else {
-    constexpr int BPW = PvqGeom<N>::BPW;
-    PvqLevelArgs3 aa;
-    aa.a = a;
-    aa.rsq = rsq;
-    dim3 grid((unsigned)((nblk + BPW - 1)/BPW), nlist, nslots);
-    hipLaunchKernelGGL(k_pvq_noref_v3<N>, grid, dim3(64), 0, s, aa);
-  }
+                bool gain_only, const double *rsq) {
+  constexpr int BPW = PvqGeom<N>::BPW;
+  PvqLevelArgs3 aa;
+  aa.a = a;
+  aa.rsq = rsq;
+  dim3 grid((unsigned)((nblk + BPW - 1)/BPW), nlist, nslots);
+  if (gain_only) hipLaunchKernelGGL((k_pvq_noref_v3<N, true>), grid, dim3(64), 0, s, aa);
+  else hipLaunchKernelGGL((k_pvq_noref_v3<N, false>), grid, dim3(64), 0, s, aa);
+}
+
+// od_gain_compand (src/pvq.c:422-425) with the HOST's libm: the value the reference
+// computes in this very process (same expression, same pow).
+inline double host_gain_compand(double g, int q0, double beta) {
+  if (beta == 1) return g/q0;
+  return PVQ_COMPAND_SCALE*pow(g*(1./PVQ_COMPAND_SCALE), 1./beta)/q0;
 }
 }  // namespace
 
@@ -454,7 +455,6 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
     hipLaunchKernelGGL(k_pvq_fill_rsqrt, dim3(PVQ_RSQ_TAB/256), dim3(256), 0, ctx->stream, ctx->rsq);
     ok = hipGetLastError() == hipSuccess;
   }
-  if (const char *e = getenv("OD_HIP_PVQ_IMPL")) ctx->pvq_impl = atoi(e);
   if (const char *e = getenv("OD_HIP_PVQ_STREAMS")) {
     int v = atoi(e);
     ctx->naux = v < 0 ? 0 : v > od_hip_ctx::NAUX ? od_hip_ctx::NAUX : v;
@@ -775,20 +775,30 @@ int od_hip_pvq_nblocks(od_hip_ctx *ctx, int pli, int level) {
   return (ctx->pw[pli]/n)*(ctx->ph[pli]/n);
 }
 
-int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
-                            const int16_t *qm, const int32_t *q, const double *beta) {
-  if (int rc = check_slots(ctx, slot0, nslots, false)) return rc;
-  if (!qm || !q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
-  int nblk = od_hip_pvq_nblocks(ctx, pli, level);
-  if (nblk < 0) return nblk;
-  int n = (32 >> ctx->geo.xdec[pli]) >> level;
-  int bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
-  int ncoded = n*n < 512 ? n*n : 512;
-  size_t ns = ctx->geo.nslots;
+namespace {
+struct PvqCall {
   PvqLevelArgs a;
+  int nblk, n, bs;
+  size_t nrec, ny;
+  PvqSoA *o;
+};
+
+// Argument block of one (plane, level) PVQ launch group (+ lazy allocation of its outputs).
+int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, const int16_t *qm,
+                const int32_t *q, const double *beta, PvqCall &c) {
+  if (int rc = check_slots(ctx, slot0, nslots, false)) return rc;
+  if (!q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
+  c.nblk = od_hip_pvq_nblocks(ctx, pli, level);
+  if (c.nblk < 0) return c.nblk;
+  const int n = c.n = (32 >> ctx->geo.xdec[pli]) >> level;
+  const int bs = c.bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
+  const int ncoded = n*n < 512 ? n*n : 512;
+  const size_t ns = ctx->geo.nslots;
+  PvqLevelArgs &a = c.a;
   a.nbands = od_hip_band_offsets(bs, a.off);
-  size_t nrec = (size_t)a.nbands*nblk, ny = (size_t)2*nblk*(ncoded - 1);
+  const size_t nrec = c.nrec = (size_t)a.nbands*c.nblk, ny = c.ny = (size_t)2*c.nblk*(ncoded - 1);
   PvqSoA &o = ctx->pvq[pli][level];
+  c.o = &o;
   if (!ctx->pvq_alloc[pli][level]) {
     HIPCHK(hipMalloc((void **)&o.cg, ns*nrec*8));
     HIPCHK(hipMalloc((void **)&o.g, ns*nrec*8));
@@ -803,14 +813,7 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
   // one QM copy per (plane, level): kernels of earlier calls may still be running on the
   // side streams when the next call uploads its table
   int16_t *qm_d = ctx->qm_slots + ((size_t)pli*4 + level)*1024;
-  HIPCHK(hipMemcpyAsync(qm_d, qm, (size_t)n*n*sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->naux > 0) {
-    if (ctx->timing && !ctx->aux_pending && !ctx->phase_a) {
-      ctx->phase_a = get_event(ctx);
-      if (ctx->phase_a) (void)hipEventRecord(ctx->phase_a, ctx->stream);
-    }
-    HIPCHK(hipEventRecord(ctx->aux_dep, ctx->stream));   // after the pyramid + table
-  }
+  if (qm) HIPCHK(hipMemcpyAsync(qm_d, qm, (size_t)n*n*sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
   a.lev = ctx->lev[pli] + ((size_t)slot0*ctx->nlev[pli] + level)*ctx->psz[pli];
   a.lev_fstride = (size_t)ctx->nlev[pli]*ctx->psz[pli];
   a.w = ctx->pw[pli];
@@ -830,7 +833,22 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
   a.out.qg = o.qg + slot0*2*nrec;
   a.out.k = o.k + slot0*2*nrec;
   a.out.y = o.y + slot0*ny;
-  // one launch per distinct band size (the no-reference sizes are 15, 8, 32, 128)
+  return 0;
+}
+
+// One launch per distinct band size (the no-reference sizes are 15, 8, 32, 128).  The
+// search launches go round-robin over the side streams (their long tails overlap); the
+// cheap gain launches stay on the context's stream.
+int pvq_launch(od_hip_ctx *ctx, PvqCall &c, int nslots, bool gain_only) {
+  PvqLevelArgs &a = c.a;
+  const bool side = !gain_only && ctx->naux > 0;
+  if (side) {
+    if (ctx->timing && !ctx->aux_pending && !ctx->phase_a) {
+      ctx->phase_a = get_event(ctx);
+      if (ctx->phase_a) (void)hipEventRecord(ctx->phase_a, ctx->stream);
+    }
+    HIPCHK(hipEventRecord(ctx->aux_dep, ctx->stream));   // after the pyramid, the table and cg
+  }
   static const int sizes[4] = {15, 8, 32, 128};
   for (int si = 0; si < 4; si++) {
     int nlist = 0;
@@ -839,7 +857,7 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
     }
     if (!nlist) continue;
     hipStream_t ls = ctx->stream;
-    if (ctx->naux > 0) {
+    if (side) {
       // OD_HIP_PVQ_ASSIGN=1: by kernel class (128 | 32 | 15+8) instead of round-robin
       static const int by_class = getenv("OD_HIP_PVQ_ASSIGN") ? atoi(getenv("OD_HIP_PVQ_ASSIGN")) : 0;
       const int cls = sizes[si] == 128 ? 0 : sizes[si] == 32 ? 1 : 2;
@@ -847,15 +865,70 @@ int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int
       HIPCHK(hipStreamWaitEvent(ls, ctx->aux_dep, 0));
       ctx->aux_pending = true;
     }
+    const char *nm = gain_only ? (sizes[si] == 15 ? "k_pvq_gain<15>" : sizes[si] == 8 ? "k_pvq_gain<8>"
+                                  : sizes[si] == 32 ? "k_pvq_gain<32>" : "k_pvq_gain<128>")
+                               : (sizes[si] == 15 ? "k_pvq_noref<15>" : sizes[si] == 8 ? "k_pvq_noref<8>"
+                                  : sizes[si] == 32 ? "k_pvq_noref<32>" : "k_pvq_noref<128>");
+    Timed tm(ctx, nm, ls);
     switch (sizes[si]) {
-      case 15: { Timed tm(ctx, "k_pvq_noref<15>", ls); launch_pvq<15>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
-      case 8: { Timed tm(ctx, "k_pvq_noref<8>", ls); launch_pvq<8>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
-      case 32: { Timed tm(ctx, "k_pvq_noref<32>", ls); launch_pvq<32>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
-      default: { Timed tm(ctx, "k_pvq_noref<128>", ls); launch_pvq<128>(a, nlist, nblk, nslots, ls, ctx->pvq_impl, ctx->rsq); break; }
+      case 15: launch_pvq<15>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
+      case 8: launch_pvq<8>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
+      case 32: launch_pvq<32>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
+      default: launch_pvq<128>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
     }
     HIPCHK(hipGetLastError());
   }
   return 0;
+}
+}  // namespace
+
+int od_hip_pvq_compand(int count, const double *g, int q0, double beta, double *cg) {
+  if (!g || !cg) return fail(OD_HIP_EFAULT, "null pointer");
+  if (count < 0 || q0 < 1) return fail(OD_HIP_EINVAL, "bad count/quantiser");
+  for (int i = 0; i < count; i++) cg[i] = host_gain_compand(g[i], q0, beta);
+  return 0;
+}
+
+int od_hip_pvq_gains(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+                     const int16_t *qm, const int32_t *q, const double *beta) {
+  PvqCall c;
+  if (!qm) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = pvq_prepare(ctx, slot0, nslots, pli, level, qm, q, beta, c)) return rc;
+  return pvq_launch(ctx, c, nslots, true);
+}
+
+int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+                             const int32_t *q, const double *beta) {
+  PvqCall c;
+  if (int rc = pvq_prepare(ctx, slot0, nslots, pli, level, nullptr, q, beta, c)) return rc;
+  const size_t cnt = (size_t)nslots*c.nrec;
+  std::vector<double> g(cnt), cg(cnt);
+  HIPCHK(hipMemcpyAsync(g.data(), c.a.out.g, cnt*8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < nslots; s++) {
+    for (int b = 0; b < c.a.nbands; b++) {
+      const size_t o = (size_t)s*c.nrec + (size_t)b*c.nblk;
+      for (int i = 0; i < c.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(c.a.out.cg, cg.data(), cnt*8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int od_hip_pvq_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+                      const int16_t *qm, const int32_t *q, const double *beta) {
+  PvqCall c;
+  if (!qm) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = pvq_prepare(ctx, slot0, nslots, pli, level, qm, q, beta, c)) return rc;
+  return pvq_launch(ctx, c, nslots, false);
+}
+
+int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+                            const int16_t *qm, const int32_t *q, const double *beta) {
+  if (int rc = od_hip_pvq_gains(ctx, slot0, nslots, pli, level, qm, q, beta)) return rc;
+  if (int rc = od_hip_pvq_compand_level(ctx, slot0, nslots, pli, level, q, beta)) return rc;
+  return od_hip_pvq_search(ctx, slot0, nslots, pli, level, qm, q, beta);
 }
 
 int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
@@ -962,6 +1035,34 @@ int od_hip_pvq_synthesis_noref(int n, int nvec, const int32_t *y, const double *
   return 0;
 }
 
+// od_pvq_compute_max_theta / _theta / _k (src/pvq.c:476-535) on the host: the candidate
+// enumeration of pvq_theta is scalar work around acos/sin/cos, so it runs here, between
+// the two device passes.
+namespace {
+inline int host_max_theta(double qcg, double beta) {
+  int ts = (int)floor(.5 + qcg*M_PI/(2*beta));
+  if (qcg < 1.4) ts = 1;
+  return ts;
+}
+inline double host_theta(int t, int max_theta) {
+  if (max_theta != 0) return (t < max_theta - 1 ? t : max_theta - 1)*.5*M_PI/max_theta;
+  return 0;
+}
+inline int host_k(double qcg, int itheta, double theta, int noref, int n, double beta, int nodesync) {
+  if (noref) {
+    if (qcg == 0) return 0;
+    if (n == 15 && qcg == 1 && beta > 1.25) return 1;
+    const int k = (int)floor(.5 + (qcg - .2)*sqrt((n + 3)/2)/beta);
+    return k > 1 ? k : 1;
+  }
+  if (itheta == 0) return 0;
+  int k;
+  if (nodesync) k = (int)floor(.5 + (itheta - .2)*sqrt((n + 2)/2));
+  else k = (int)floor(.5 + (qcg*sin(theta) - .2)*sqrt((n + 2)/2)/beta);
+  return k > 1 ? k : 1;
+}
+}  // namespace
+
 int od_hip_pvq_theta_vectors(int n, int nvec, const od_coeff *x0, const od_coeff *r0,
                              const int16_t *qm, const int32_t *q0, double beta, int robust,
                              int is_keyframe, int pli, od_hip_pvq_theta_out *out,
@@ -974,24 +1075,122 @@ int od_hip_pvq_theta_vectors(int n, int nvec, const od_coeff *x0, const od_coeff
   if (int rc = g_in.reserve(nv*n*4)) return rc;
   if (int rc = g_aux0.reserve(nv*n*4)) return rc;
   if (int rc = g_aux1.reserve((size_t)n*2)) return rc;
-  if (int rc = g_aux2.reserve(nv*4)) return rc;
-  if (int rc = g_out.reserve(nv*sizeof(PvqThetaOut))) return rc;
+  if (int rc = g_aux2.reserve(nv*sizeof(PvqThetaPrep))) return rc;
+  if (int rc = g_aux5.reserve(nv*sizeof(PvqThetaCands))) return rc;
+  if (int rc = g_out.reserve(nv*sizeof(PvqThetaRes))) return rc;
   if (int rc = g_aux3.reserve(nv*12*n*4)) return rc;
   if (int rc = g_aux4.reserve(nv*2*n*4)) return rc;
   HIPCHK(hipMemcpy(g_in.p, x0, nv*n*4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux0.p, r0, nv*n*4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux1.p, qm, (size_t)n*2, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g_aux2.p, q0, nv*4, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(g_aux3.p, 0, nv*12*n*4));
   HIPCHK(hipMemset(g_aux4.p, 0, nv*2*n*4));
-  hipLaunchKernelGGL(k_pvq_theta_vectors, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
+  // pass 1: gains and correlation sums (exact)
+  hipLaunchKernelGGL(k_pvq_theta_prep, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
                      (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const int16_t *)g_aux1.p,
-                     (const int32_t *)g_aux2.p, beta, robust, is_keyframe, pli,
-                     (PvqThetaOut *)g_out.p, (int32_t *)g_aux3.p, (int32_t *)g_aux4.p);
+                     (PvqThetaPrep *)g_aux2.p);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(out, g_out.p, nv*sizeof(PvqThetaOut), hipMemcpyDeviceToHost));
+  std::vector<PvqThetaPrep> prep(nv);
+  std::vector<PvqThetaCands> cands(nv);
+  std::vector<PvqThetaRes> res(nv);
+  HIPCHK(hipMemcpy(prep.data(), g_aux2.p, nv*sizeof(PvqThetaPrep), hipMemcpyDeviceToHost));
+  // host stage: everything of pvq_theta (src/pvq_encoder.c:359-417, :452-462) that goes
+  // through libm, in the reference's own expressions
+  const double gain_weight = 1.4;
+  const int nodesync = robust || is_keyframe;
+  const int cfl_enabled = is_keyframe && pli != 0;
+  memset(out, 0, nv*sizeof(*out));
+  for (size_t v = 0; v < nv; v++) {
+    od_hip_pvq_theta_out &o = out[v];
+    PvqThetaCands &c = cands[v];
+    memset(&c, 0, sizeof(c));
+    const double g = prep[v].g, gr = prep[v].gr;
+    const double cg = host_gain_compand(g, q0[v], beta);
+    double cgr = host_gain_compand(gr, q0[v], beta);
+    if (cfl_enabled) cgr = 1;
+    const int icgr = (int)floor(.5 + cgr);
+    const double gain_offset = cgr - icgr;
+    double corr = prep[v].corr_sum/(1e-100 + g*gr);
+    corr = corr < 1. ? corr : 1.;
+    corr = corr > -1. ? corr : -1.;
+    o.null_dist = gain_weight*cg*cg;
+    if (is_keyframe) o.skip_dist = gain_weight*cg*cg;
+    else o.skip_dist = gain_weight*(cg - cgr)*(cg - cgr) + cgr*cg*(2 - 2*corr);
+    double theta = 0;
+    if (n <= PVQ_MAXN && !prep[v].isnull && corr > 0) {
+      o.theta_searched = c.theta_searched = 1;
+      theta = acos(corr);
+      int i = (int)floor(cg - gain_offset) - 1;
+      if (i < 1) i = 1;
+      for (; i <= (int)ceil(cg - gain_offset); i++) {
+        const double qcg = i + gain_offset;
+        const int ts = host_max_theta(qcg, beta);
+        int j = (int)floor(.5 + theta*2/M_PI*ts) - 2;
+        if (j < 0) j = 0;
+        int jhi = (int)ceil(theta*2/M_PI*ts);
+        if (jhi > ts - 1) jhi = ts - 1;
+        for (; j <= jhi; j++) {
+          const int ci = o.nref;
+          if (ci >= 12) break;
+          const double qtheta = host_theta(j, ts);
+          const int k = host_k(qcg, j, qtheta, 0, n, beta, nodesync);
+          o.ref_qg[ci] = i; o.ref_itheta[ci] = j; o.ref_ts[ci] = ts; o.ref_k[ci] = k;
+          o.ref_qtheta[ci] = qtheta;
+          c.ref_k[ci] = k;
+          c.ref_g2[ci] = qcg*cg*sin(theta)*sin(qtheta);
+          o.nref++;
+        }
+      }
+      c.nref = o.nref;
+    }
+    if (n <= PVQ_MAXN && ((is_keyframe && pli == 0) || corr < .5 || cg < 2.)) {
+      o.noref_searched = c.noref_searched = 1;
+      int i = (int)floor(cg);
+      if (i < 1) i = 1;
+      for (; i <= ceil(cg) && o.nnoref < 2; i++) {
+        const int ci = o.nnoref;
+        const double qcg = i;
+        const int k = host_k(qcg, -1, -1, 1, n, beta, nodesync);
+        o.nr_qg[ci] = i; o.nr_k[ci] = k;
+        c.nr_k[ci] = k;
+        c.nr_g2[ci] = qcg*cg;
+        o.nnoref++;
+      }
+      c.nnoref = o.nnoref;
+    }
+    o.cg = cg; o.cgr = cgr; o.g = g; o.gr = gr; o.corr = corr; o.theta = theta;
+    o.gain_offset = gain_offset; o.icgr = icgr;
+  }
+  HIPCHK(hipMemcpy(g_aux5.p, cands.data(), nv*sizeof(PvqThetaCands), hipMemcpyHostToDevice));
+  // pass 2: Householder + codeword searches (exact)
+  hipLaunchKernelGGL(k_pvq_theta_search, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
+                     (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const int16_t *)g_aux1.p,
+                     (const PvqThetaPrep *)g_aux2.p, (const PvqThetaCands *)g_aux5.p,
+                     (PvqThetaRes *)g_out.p, (int32_t *)g_aux3.p, (int32_t *)g_aux4.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(res.data(), g_out.p, nv*sizeof(PvqThetaRes), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(y_ref, g_aux3.p, nv*12*n*4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(y_noref, g_aux4.p, nv*2*n*4, hipMemcpyDeviceToHost));
+  // host stage 2: the distortions (:429-431, :465)
+  for (size_t v = 0; v < nv; v++) {
+    od_hip_pvq_theta_out &o = out[v];
+    const double cg = o.cg, theta = o.theta;
+    o.m = res[v].m;
+    o.s = res[v].s;
+    for (int ci = 0; ci < o.nref; ci++) {
+      const double qcg = o.ref_qg[ci] + o.gain_offset, qtheta = o.ref_qtheta[ci];
+      const double cos_dist = res[v].ref_cos_dist[ci];
+      const double dist_theta = 2 - 2*cos(theta - qtheta)
+                                + sin(theta)*sin(qtheta)*(2 - 2*cos_dist);
+      o.ref_cos_dist[ci] = cos_dist;
+      o.ref_dist[ci] = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*dist_theta;
+    }
+    for (int ci = 0; ci < o.nnoref; ci++) {
+      const double qcg = o.nr_qg[ci], cd = res[v].nr_cos_dist[ci];
+      o.nr_cos_dist[ci] = cd;
+      o.nr_dist[ci] = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd);
+    }
+  }
   return 0;
 }
 
@@ -1010,21 +1209,28 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
   if (int rc = g_aux1.reserve(nv*8)) return rc;
   if (int rc = g_aux2.reserve(nv*4)) return rc;
   if (int rc = g_aux3.reserve(nv*8)) return rc;
-  if (int rc = g_aux4.reserve(nv*8)) return rc;
+  if (int rc = g_aux4.reserve(nv*16)) return rc;
   if (int rc = g_aux5.reserve((size_t)n*2)) return rc;
   if (int rc = g_aux6.reserve((size_t)n*2)) return rc;
   if (int rc = g_out.reserve(nv*n*4)) return rc;
+  // sin(theta), cos(theta) of od_pvq_synthesis_partial (src/pvq.c:574-577): host libm
+  std::vector<double> sc(2*nv);
+  for (size_t v = 0; v < nv; v++) {
+    sc[v] = sin(theta[v]);
+    sc[nv + v] = cos(theta[v]);
+  }
   HIPCHK(hipMemcpy(g_in.p, y, nv*n*4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux0.p, ref, nv*n*4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux1.p, gr, nv*8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux2.p, noref, nv*4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux3.p, g, nv*8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g_aux4.p, theta, nv*8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux4.p, sc.data(), nv*16, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux5.p, qm, (size_t)n*2, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux6.p, qm_inv, (size_t)n*2, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_pvq_synthesis_vectors, dim3((nvec + 63)/64), dim3(64), 0, 0, n, nvec,
                      (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const double *)g_aux1.p,
                      (const int32_t *)g_aux2.p, (const double *)g_aux3.p, (const double *)g_aux4.p,
+                     (const double *)g_aux4.p + nv,
                      (const int16_t *)g_aux5.p, (const int16_t *)g_aux6.p, (int32_t *)g_out.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, g_out.p, nv*n*4, hipMemcpyDeviceToHost));
@@ -1069,18 +1275,31 @@ int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coe
   if (int rc = ensure_device()) return rc;
   if (nblk == 0) return 0;
   size_t n = 4u << bs, bytes = (size_t)nblk*n*n*4;
+  const size_t per = (n/8)*(n/8), nsub = (size_t)nblk*per;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_aux0.reserve(bytes)) return rc;
   if (int rc = g_aux1.reserve(64*8)) return rc;
-  if (int rc = g_out.reserve((size_t)nblk*8)) return rc;
+  if (int rc = g_out.reserve(nsub*16)) return rc;
   HIPCHK(hipMemcpy(g_in.p, x, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux0.p, y, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_aux1.p, mag2, 64*8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_compute_dist_blocks, dim3((nblk + 63)/64), dim3(64), 0, 0, (int)n, nblk,
+  hipLaunchKernelGGL(k_compute_dist_blocks, dim3((unsigned)((nsub + 63)/64)), dim3(64), 0, 0, (int)n, nblk,
                      (const int32_t *)g_in.p, (const int32_t *)g_aux0.p, (const double *)g_aux1.p,
-                     activity_masking, (double *)g_out.p);
+                     activity_masking, (double *)g_out.p, (double *)g_out.p + nsub);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(dist, g_out.p, (size_t)nblk*8, hipMemcpyDeviceToHost));
+  std::vector<double> ae(2*nsub);
+  HIPCHK(hipMemcpy(ae.data(), g_out.p, nsub*16, hipMemcpyDeviceToHost));
+  // od_compute_dist_8x8's activity (src/encode.c:997-1007, :1029) with the host's libm,
+  // sub-blocks summed in raster order (:1045-1050), then the 1.7 of :1055
+  const double calibration = activity_masking ? 1.95 : 1.62;
+  for (int b = 0; b < nblk; b++) {
+    double sum = 0;
+    for (size_t sb = 0; sb < per; sb++) {
+      const double activity = calibration*pow(ae[b*per + sb], -1./6);
+      sum += activity*activity*ae[nsub + b*per + sb];
+    }
+    dist[b] = sum*1.7;
+  }
   return 0;
 }
 
@@ -1189,7 +1408,7 @@ int od_hip_decode_tail(od_hip_ctx *ctx, int slot0, int nslots, const int32_t *th
 
 int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out) {
   if (!x || !y || !out) return fail(OD_HIP_EFAULT, "null pointer");
-  if (n < 0 || fn < 0 || fn > 7) return fail(OD_HIP_EINVAL, "bad arguments");
+  if (n < 0 || fn < 0 || fn > 5) return fail(OD_HIP_EINVAL, "bad arguments");
   if (int rc = ensure_device()) return rc;
   if (n == 0) return 0;
   size_t nb = (size_t)n*8;

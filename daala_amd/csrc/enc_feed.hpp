@@ -7,9 +7,14 @@
 struct od_hip_enc_feed {
   od_hip_ctx *ctx = nullptr;
   hipStream_t copy = nullptr;
+  hipStream_t up = nullptr;               // small transfers of the companding round trip (g down, cg up)
+  hipEvent_t gains_done = nullptr;
   hipEvent_t computed = nullptr;
   hipEvent_t transformed = nullptr;       // forward pyramid done (the level planes can be copied)
-  std::vector<hipEvent_t> ready;          // one per slot
+  std::vector<hipEvent_t> ready;          // one per slot: records landed on the host
+  std::vector<hipEvent_t> gready;         // one per slot: gains landed on the host
+  std::vector<hipEvent_t> cgup;           // one per slot: companded gains uploaded
+  std::vector<char> companded;            // slot went through od_hip_enc_feed_compand since its gains
   std::vector<char> pending;              // slot has a copy in flight / landed
   struct Lev {
     int n, bs, nb, nblk, nbx, off[11];
@@ -42,6 +47,10 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
     if (l.plane) (void)hipHostFree(l.plane);
   }
   for (auto e : f->ready) if (e) (void)hipEventDestroy(e);
+  for (auto e : f->gready) if (e) (void)hipEventDestroy(e);
+  for (auto e : f->cgup) if (e) (void)hipEventDestroy(e);
+  if (f->gains_done) (void)hipEventDestroy(f->gains_done);
+  if (f->up) { (void)hipStreamSynchronize(f->up); (void)hipStreamDestroy(f->up); }
   if (f->computed) (void)hipEventDestroy(f->computed);
   if (f->transformed) (void)hipEventDestroy(f->transformed);
   if (f->copy) (void)hipStreamDestroy(f->copy);
@@ -55,7 +64,16 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
   f->ctx = ctx;
   size_t ns = ctx->geo.nslots;
   bool ok = hipStreamCreateWithFlags(&f->copy, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&f->up, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&f->computed, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&f->gains_done, hipEventDisableTiming) == hipSuccess;
+  f->gready.assign(ns, nullptr);
+  f->cgup.assign(ns, nullptr);
+  f->companded.assign(ns, 0);
+  for (size_t s = 0; ok && s < ns; s++) {
+    ok = hipEventCreateWithFlags(&f->gready[s], hipEventDisableTiming) == hipSuccess
+      && hipEventCreateWithFlags(&f->cgup[s], hipEventDisableTiming) == hipSuccess;
+  }
   ok = ok && hipEventCreateWithFlags(&f->transformed, hipEventDisableTiming) == hipSuccess;
   f->ready.assign(ns, nullptr);
   f->pending.assign(ns, 0);
@@ -99,7 +117,9 @@ int od_hip_enc_feed_set_level(od_hip_enc_feed *f, int level, const int16_t *qm,
   return 0;
 }
 
-int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
+// Phase 1: forward pyramid + exact gains g of every band of the four luma levels; the
+// level planes and the gains start travelling to the host.
+int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
   if (!f) return fail(OD_HIP_EFAULT, "null feed");
   od_hip_ctx *ctx = f->ctx;
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
@@ -107,9 +127,11 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
   // a slot's host mirror must not be overwritten while a previous copy is in flight
   for (int s = slot0; s < slot0 + nslots; s++) {
     if (f->pending[s]) HIPCHK(hipEventSynchronize(f->ready[s]));
+    f->pending[s] = 0;
+    f->companded[s] = 0;
   }
   if (int rc = od_hip_forward_pyramid(ctx, slot0, nslots)) return rc;
-  // the level planes are final here: their copies overlap the PVQ searches
+  // the level planes are final here: their copies overlap everything that follows
   HIPCHK(hipEventRecord(f->transformed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->transformed, 0));
   for (int s = slot0; s < slot0 + nslots; s++) {
@@ -121,7 +143,57 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
   }
   for (int l = 0; l < 4; l++) {
     auto &L = f->lev[l];
-    if (int rc = od_hip_pvq_noref_search(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
+    if (int rc = od_hip_pvq_gains(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
+  }
+  HIPCHK(hipEventRecord(f->gains_done, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(f->up, f->gains_done, 0));
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    for (int l = 0; l < 4; l++) {
+      auto &L = f->lev[l];
+      HIPCHK(hipMemcpyAsync(L.g + s*L.nrec, ctx->pvq[0][l].g + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->up));
+    }
+    HIPCHK(hipEventRecord(f->gready[s], f->up));
+  }
+  return 0;
+}
+
+// Phase 2, per slot, any host thread (slots are independent): cg = od_gain_compand(g) with
+// the host's libm for every band of the slot, then the upload.
+int od_hip_enc_feed_compand(od_hip_enc_feed *f, int slot) {
+  if (!f) return fail(OD_HIP_EFAULT, "null feed");
+  od_hip_ctx *ctx = f->ctx;
+  if (slot < 0 || slot >= ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventSynchronize(f->gready[slot]));
+  for (int l = 0; l < 4; l++) {
+    auto &L = f->lev[l];
+    const double *g = L.g + slot*L.nrec;
+    double *cg = L.cg + slot*L.nrec;
+    for (int b = 0; b < L.nb; b++) {
+      const int q0 = L.q[b];
+      const double beta = L.beta[b];
+      const size_t o = (size_t)b*L.nblk;
+      for (int i = 0; i < L.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->pvq[0][l].cg + slot*L.nrec, cg, L.nrec*8, hipMemcpyHostToDevice, f->up));
+  }
+  HIPCHK(hipEventRecord(f->cgup[slot], f->up));
+  f->companded[slot] = 1;
+  return 0;
+}
+
+// Phase 3: the codeword searches with the uploaded cg, then the records travel to the host.
+int od_hip_enc_feed_search(od_hip_enc_feed *f, int slot0, int nslots) {
+  if (!f) return fail(OD_HIP_EFAULT, "null feed");
+  od_hip_ctx *ctx = f->ctx;
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    if (!f->companded[s]) return fail(OD_HIP_EINVAL, "slot was not companded (od_hip_enc_feed_compand)");
+    HIPCHK(hipStreamWaitEvent(ctx->stream, f->cgup[s], 0));
+  }
+  for (int l = 0; l < 4; l++) {
+    auto &L = f->lev[l];
+    if (int rc = od_hip_pvq_search(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
   }
   if (int rc = join_aux(ctx)) return rc;          // the PVQ launches run on side streams
   HIPCHK(hipEventRecord(f->computed, ctx->stream));
@@ -131,8 +203,6 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
       auto &L = f->lev[l];
       PvqSoA &o = ctx->pvq[0][l];
       HIPCHK(hipMemcpyAsync(L.ncand + s*L.nrec, o.ncand + s*L.nrec, L.nrec*4, hipMemcpyDeviceToHost, f->copy));
-      HIPCHK(hipMemcpyAsync(L.cg + s*L.nrec, o.cg + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->copy));
-      HIPCHK(hipMemcpyAsync(L.g + s*L.nrec, o.g + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.qg + s*2*L.nrec, o.qg + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.k + s*2*L.nrec, o.k + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
       HIPCHK(hipMemcpyAsync(L.cos_dist + s*2*L.nrec, o.cos_dist + s*2*L.nrec, 2*L.nrec*8, hipMemcpyDeviceToHost, f->copy));
@@ -142,6 +212,15 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
     f->pending[s] = 1;
   }
   return 0;
+}
+
+// The three phases back to back on the calling thread.
+int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
+  if (int rc = od_hip_enc_feed_gains(f, slot0, nslots)) return rc;
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    if (int rc = od_hip_enc_feed_compand(f, s)) return rc;
+  }
+  return od_hip_enc_feed_search(f, slot0, nslots);
 }
 
 int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4]) {

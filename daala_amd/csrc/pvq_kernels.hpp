@@ -106,61 +106,6 @@ __device__ __forceinline__ int pvq_k_noref(double qcg, int n, double beta) {
   return k > 1 ? k : 1;
 }
 
-// x^(1/1.5) rounded to nearest, for the only non-trivial beta the codec uses
-// (OD_PVQ_BETA, src/pvq.c:230: 1 or 1.5).  The reference calls libm
-// pow(x, 1./1.5); glibc's pow is accurate to < 0.52 ulp, i.e. it returns the
-// correctly rounded value except when the true result lies within ~0.02 ulp of a
-// rounding boundary.  OCML's pow is only good to ~1 ulp (measured: 24 % of results
-// differ from glibc by 1 ulp), so the value is computed here in double-double:
-//   y = 1./1.5 as a double is 2/3 - d,  d = 2^-54/1.5 ... exactly (2/3 - y);
-//   x^y = cbrt(x^2) * exp(-d*ln x),  cbrt refined by one Newton step evaluated in
-//   double-double (error ~1e-32), the exp factor is 1 - d*ln x to first order
-//   (|d*ln x| < 3e-15, second order < 1e-29).
-// Explicit fma() only builds exact products/residuals; nothing here is contracted.
-__device__ inline double pvq_pow_2_3(double x) {
-  if (!(x > 0)) return x == 0 ? 0. : pow(x, 1./1.5);
-  // exact x^2 = zh + zl
-  const double zh = x*x, zl = fma(x, x, -zh);
-  const double c0 = cbrt(zh);
-  // c0^2 = ph + pl, c0^3 = th + tl (tl to first order)
-  const double ph = c0*c0, pl = fma(c0, c0, -ph);
-  const double th = ph*c0, tl = fma(ph, c0, -th) + pl*c0;
-  // residual r = (zh + zl) - (th + tl), the leading terms cancel exactly
-  const double r = ((zh - th) - tl) + zl;
-  const double e = r/(3.*ph);                       // Newton correction, |e| < 2 ulp(c0)
-  // exponent correction: y = 1./1.5 is 2/3 - d with d = (2/3 - y) exactly:
-  // 1./1.5 = 0x3FE5555555555555 => d = 2/3 - y = 2^-54 * (2/3) ... = 3.700743415417188e-17
-  const double d = 3.7007434154171883e-17;
-  const double corr = e - c0*(d*log(x));
-  return c0 + corr;
-}
-
-// x^(-1./6) rounded to nearest for od_compute_dist's activity factor
-// (pow(.25 + var_stat/256, -1./6), src/encode.c:1002).  Same idea as pvq_pow_2_3: seed
-// y0, then ONE Newton step whose residual 1 - x*y0^6 is evaluated in double-double
-// (y0^2 exact, cubed and multiplied by x with first-order tails: error ~1e-31), and the
-// first-order correction for the exponent being the double c = -1./6 = -1/6 + d,
-// d = 2^-55/3: x^c = x^(-1/6) * (1 + d ln x).
-__device__ inline double pvq_pow_m1_6(double x) {
-  if (!(x > 0) || x > 1e300) return pow(x, -1./6);
-  const double y0 = 1./sqrt(cbrt(x));
-  const double ph = y0*y0, pl = fma(y0, y0, -ph);                       // y0^2
-  const double qh = ph*ph, ql = fma(ph, ph, -qh) + 2*ph*pl;             // y0^4
-  const double sh = qh*ph, sl = fma(qh, ph, -sh) + qh*pl + ql*ph;       // y0^6
-  const double th = x*sh, tl = fma(x, sh, -th) + x*sl;                  // x*y0^6 ~ 1
-  const double r = (1. - th) - tl;
-  const double d = 9.251858538542970e-18;                               // 2^-55/3
-  return y0 + y0*(r*(1./6) + d*log(x));
-}
-
-// od_gain_compand (src/pvq.c:422-425).
-__device__ __forceinline__ double pvq_gain_compand(double g, int q0, double beta) {
-  if (beta == 1) return g/q0;
-  const double x = g*(1./PVQ_COMPAND_SCALE);
-  const double p = beta == 1.5 ? pvq_pow_2_3(x) : pow(x, 1./beta);
-  return PVQ_COMPAND_SCALE*p/q0;
-}
-
 __global__ void k_pvq_search_vectors(int n, int nvec, const double *__restrict__ x,
                                      const int32_t *__restrict__ k,
                                      const double *__restrict__ g2,
@@ -228,173 +173,6 @@ struct PvqLevelArgs {
   size_t rec_fstride;      // nbands*nblk (elements between frames of the record arrays)
   size_t y_fstride;        // 2*nblk*(ncoded-1)
 };
-
-// No-reference candidates of every (block, band) of one pyramid level for the
-// bands of size N: the state-free part of pvq_theta (src/pvq_encoder.c:352-357,
-// :452-481).  One wave per workgroup; lane = block, so a wave holds the same
-// band of 64 consecutive blocks.  Per-lane vectors live in LDS as [j][lane]
-// (stride 65: conflict free both for the per-lane scans and for the transposed
-// cooperative output): P = x0[j]*qm[j] (the reference's int*int product, :455),
-// Y = pulses.  |x_j| is recomputed as fabs((double)P*S) where needed, so a 128-
-// coefficient band costs 66.5 KB of LDS per wave (2 waves per CU).
-template <int N>
-__global__ __launch_bounds__(64) void k_pvq_noref(PvqLevelArgs a) {
-  constexpr int LD = 65;
-  __shared__ int32_t P[N*LD];
-  __shared__ int32_t Y[N*LD];
-  const int lane = threadIdx.x;
-  const long blk0 = (long)blockIdx.x*64;
-  const long blk = blk0 + lane;
-  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
-  const long nblk = (long)a.nbx*a.nby;
-  const bool live = blk < nblk;
-  const int o0 = a.off[band];
-  const int16_t *qm = a.qm + o0;
-  const int q0 = a.q[band];
-  const double beta = a.beta[band];
-  // scalar arrays: [frame][band][block]; per-candidate arrays: [frame][cand][band][block]
-  const size_t rin = (size_t)band*nblk + (live ? blk : 0);
-  const size_t rec = (size_t)f*a.rec_fstride + rin;
-  const size_t rec2 = (size_t)f*2*a.rec_fstride + rin;
-  const size_t recs = a.rec_fstride;
-  double acc = 0;
-  if (live) {
-    const int bx = blk%a.nbx, by = blk/a.nbx;
-    const int32_t *src = a.lev + (size_t)f*a.lev_fstride + (size_t)(by*a.n)*a.w + bx*a.n;
-    for (int i = 0; i < N; i++) {
-      const int ro = a.tab[o0 + i];
-      const int32_t c = src[(size_t)(ro/a.n)*a.w + (ro%a.n)];
-      const int qi = qm[i];
-      // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
-      acc += c*(double)c*qi*PVQ_QM_SCALE_1*qi*PVQ_QM_SCALE_1;
-      P[i*LD + lane] = c*qi;
-    }
-  }
-  const double g = sqrt(acc);
-  const double cg = pvq_gain_compand(g, q0, beta);
-  // |x|, sum of squares and L1 norm are the same for both gain candidates
-  double xx = 0, l1 = 0;
-  if (live) {
-    for (int j = 0; j < N; j++) {
-      const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
-      xx += xj*xj;
-      l1 += xj;
-    }
-  }
-  const double norm_1 = 1./sqrt(1e-30 + xx);
-  const double l1_inv = 1./(l1 > 1e-100 ? l1 : 1e-100);
-  const double delta_rate = 3./N;
-  int nc = 0;
-  int i0 = (int)floor(cg);
-  if (i0 < 1) i0 = 1;
-  const int i1 = live ? (int)ceil(cg) : 0;       // loop bound `i <= ceil(cg)`
-  for (int c = 0; c < 2; c++) {
-    const int gi = i0 + c;
-    const bool has = live && gi <= i1;           // wave-uniform loop, lanes masked
-    int k = 0;
-    double xy = 0, yy = 0, lambda = 0, qcg = gi;
-    int i = 0;
-    if (has) {
-      k = pvq_k_noref(qcg, N, beta);
-      lambda = PVQ_LAMBDA/(1e-30 + qcg*cg);
-      if (k > 2) {
-        for (int j = 0; j < N; j++) {
-          const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
-          int p = (int)floor(k*xj*l1_inv);
-          p = p > 0 ? p : 0;
-          Y[j*LD + lane] = p;
-          xy += xj*p;
-          yy += p*p;
-          i += p;
-        }
-      }
-      else {
-        for (int j = 0; j < N; j++) Y[j*LD + lane] = 0;
-      }
-    }
-    const int rdo_pulses = 1 + k/4;
-    // greedy phase (src/pvq_encoder.c:168-190)
-    for (; i < k - rdo_pulses; i++) {
-      int pos = 0;
-      double best_xy = -10, best_yy = 1;
-#pragma unroll 4
-      for (int j = 0; j < N; j++) {
-        const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
-        double txy = xy + xj;
-        const double tyy = yy + 2*Y[j*LD + lane] + 1;
-        txy *= txy;
-        if (j == 0 || txy*best_yy > best_xy*tyy) {
-          best_xy = txy;
-          best_yy = tyy;
-          pos = j;
-        }
-      }
-      const int yp = Y[pos*LD + lane];
-      xy = xy + fabs(P[pos*LD + lane]*PVQ_QM_SCALE_1);
-      yy = yy + 2*yp + 1;
-      Y[pos*LD + lane] = yp + 1;
-    }
-    // RDO phase (src/pvq_encoder.c:195-220); the reference tabulates
-    // rsqrt(yy + 2y + 1) for y = 0..3 per pulse (:205) - same values, same here.
-    for (; i < k; i++) {
-      int pos = 0;
-      double best_cost = -1e5;
-      const double r0 = pvq_rsqrt_small((int)(yy + 1)), r1 = pvq_rsqrt_small((int)(yy + 3));
-      const double r2 = pvq_rsqrt_small((int)(yy + 5)), r3 = pvq_rsqrt_small((int)(yy + 7));
-#pragma unroll 4
-      for (int j = 0; j < N; j++) {
-        const double xj = fabs(P[j*LD + lane]*PVQ_QM_SCALE_1);
-        const int yj = Y[j*LD + lane];
-        double txy = xy + xj;
-        const double rs = yj == 0 ? r0 : yj == 1 ? r1 : yj == 2 ? r2 : yj == 3 ? r3
-                          : pvq_rsqrt_small((int)(yy + 2*yj + 1));
-        txy = 2*txy*norm_1*rs - lambda*j*delta_rate;
-        if (j == 0 || txy > best_cost) {
-          best_cost = txy;
-          pos = j;
-        }
-      }
-      const int yp = Y[pos*LD + lane];
-      xy = xy + fabs(P[pos*LD + lane]*PVQ_QM_SCALE_1);
-      yy = yy + 2*yp + 1;
-      Y[pos*LD + lane] = yp + 1;
-    }
-    if (has) {
-      const double cd = xy/(1e-100 + sqrt(xx*yy));
-      a.out.qg[c*recs + rec2] = gi;
-      a.out.k[c*recs + rec2] = k;
-      a.out.cos_dist[c*recs + rec2] = cd;
-      a.out.dist[c*recs + rec2] = 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd);
-      nc++;
-    }
-    else if (live) {
-      a.out.qg[c*recs + rec2] = 0;
-      a.out.k[c*recs + rec2] = 0;
-      a.out.cos_dist[c*recs + rec2] = 0;
-      a.out.dist[c*recs + rec2] = 0;
-      for (int j = 0; j < N; j++) Y[j*LD + lane] = 0;
-    }
-    __syncthreads();
-    // cooperative, coalesced store of the signed pulses of this candidate:
-    // [cand][block][N] is contiguous over the wave's 64 blocks.
-    {
-      int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) +
-                    ((size_t)c*nblk + blk0)*N;
-      const long lim = (nblk - blk0 < 64 ? nblk - blk0 : 64)*N;
-      for (int e = lane; e < lim; e += 64) {
-        const int b = e/N, j = e%N;
-        const int v = Y[j*LD + b];
-        yo[e] = P[j*LD + b] < 0 ? -v : v;
-      }
-    }
-    __syncthreads();
-  }
-  if (live) {
-    a.out.cg[rec] = cg;
-    a.out.g[rec] = g;
-    a.out.ncand[rec] = nc;
-  }
-}
 
 // ===========================================================================
 // v3: register-resident search.  A band of N coefficients is owned by G lanes
@@ -689,7 +467,12 @@ struct PvqLevelArgs3 {
 #ifndef PVQ_V3_WAVES
 #define PVQ_V3_WAVES(N) 3     /* min waves/SIMD: 3 measured best for every N (4+ spills, 1-2 starves) */
 #endif
-template <int N>
+// Two launches per level: GAIN_ONLY computes the exact uncompanded gain g = sqrt(acc) of
+// every band (A13 up to the companding); the host then turns g into cg with ITS libm
+// (od_gain_compand's pow, src/pvq.c:422 - the one operation on this path that is not
+// +,-,*,/,sqrt,floor, and the only one whose result depends on the libm in use) and the
+// search launch reads cg back: the device never evaluates a transcendental.
+template <int N, bool GAIN_ONLY>
 __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelArgs3 aa) {
   const PvqLevelArgs &a = aa.a;
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
@@ -761,12 +544,15 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     }
     __syncthreads();
   }
-  // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
-  const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
-    return cf[j]*(double)cf[j]*qi[j]*PVQ_QM_SCALE_1*qi[j]*PVQ_QM_SCALE_1;
-  });
-  const double gain = sqrt(acc);
-  const double cg = pvq_gain_compand(gain, q0, beta);
+  if (GAIN_ONLY) {
+    // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
+    const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
+      return cf[j]*(double)cf[j]*qi[j]*PVQ_QM_SCALE_1*qi[j]*PVQ_QM_SCALE_1;
+    });
+    if (live && g == 0) a.out.g[rec] = sqrt(acc);
+    return;
+  }
+  const double cg = a.out.cg[rec];                 // companded on the host from out.g
   PvqVec<N> v;
   v.neg = 0;
 #pragma unroll
@@ -810,9 +596,7 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     }
     __syncthreads();
   }
-  if (live && g == 0) {
-    a.out.cg[rec] = cg;
-    a.out.g[rec] = gain;
-    a.out.ncand[rec] = nc;
-  }
+  if (live && g == 0) a.out.ncand[rec] = nc;
+  (void)q0;
+  (void)beta;
 }

@@ -51,12 +51,13 @@ class Stats(ctypes.Structure):
     _fields_ = [('dev_hits', ctypes.c_int64), ('cpu_noref_luma', ctypes.c_int64),
                 ('cpu_other', ctypes.c_int64), ('g2_mismatch', ctypes.c_int64),
                 ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
-                ('pvq_check_fail', ctypes.c_int64),
+                ('resampled', ctypes.c_int64), ('pvq_check_fail', ctypes.c_int64),
                 ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
                 ('fdct_hits', ctypes.c_int64), ('fdct_check_fail', ctypes.c_int64),
                 ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
+                ('t_compand_s', ctypes.c_double),
                 ('t_total_s', ctypes.c_double), ('pkt_bytes_needed', ctypes.c_int64)]
 
     def as_dict(self):

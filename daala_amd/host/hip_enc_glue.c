@@ -361,6 +361,9 @@ typedef struct job {
   int batch0;           /* first frame of the current device batch */
   int batch_n;
   int next_upload;
+  int next_compand;     /* frames of the current batch whose gains are on the host: claimable for companding */
+  int compand_upto;
+  int companded;
   int next_encode;
   int encoded;          /* frames completely coded */
   unsigned char *done;  /* per frame: completely coded */
@@ -393,6 +396,7 @@ struct od_hipenc {
   int next_worker_id;
   int host_pvq;         /* keyframe od_pvq_encode: 1 hip_pvq_host.c (default), 0 the reference's */
   int time_cpu;         /* per-call timers around the C searches (HIPENC_TIME=1) */
+  int sample_every;     /* HIPENC_SAMPLE: re-search every n-th feed candidate (default 256, 0 off) */
   long job_seq;         /* number of jobs submitted so far */
   job *J;               /* the job being worked on, or NULL */
   double t_setup_s;
@@ -406,6 +410,7 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->lost_sync += b->lost_sync;
   a->check_fail += b->check_fail;
   a->pvq_check_fail += b->pvq_check_fail;
+  a->resampled += b->resampled;
   a->search_cpu_s += b->search_cpu_s;
   a->fdct_hits += b->fdct_hits;
   a->fdct_check_fail += b->fdct_check_fail;
@@ -516,6 +521,7 @@ static void *worker(void *arg) {
   T.check = S->p.check;
   T.time_cpu = S->time_cpu;
   T.host_pvq = S->host_pvq;
+  T.sample_every = S->sample_every;
   enc = make_encoder(&S->p, S->p.pic_width, S->p.pic_height);
   if (enc != NULL) {
     static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
@@ -562,6 +568,19 @@ static void *worker(void *arg) {
         pthread_mutex_lock(&S->mu);
         if (rc != 0) J->failed = 1;
         J->uploaded++;
+        pthread_cond_broadcast(&S->cv);
+        continue;
+      }
+      if (J->go >= 1 && S->ctx != NULL && J->next_compand < J->compand_upto) {
+        int rc;
+        /* cg = od_gain_compand(g) of every band of this frame with this process's libm
+           (the one transcendental of the feed; include/daala_hip.h section 4) */
+        f = J->next_compand++;
+        pthread_mutex_unlock(&S->mu);
+        rc = od_hip_enc_feed_compand(S->feed, f % J->nslots);
+        pthread_mutex_lock(&S->mu);
+        if (rc != 0) J->failed = 1;
+        J->companded++;
         pthread_cond_broadcast(&S->cv);
         continue;
       }
@@ -635,6 +654,8 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     const char *e;
     e = getenv("HIPENC_HOST_PVQ");
     S->host_pvq = e == NULL || atoi(e) != 0;
+    e = getenv("HIPENC_SAMPLE");
+    S->sample_every = e != NULL ? atoi(e) : 256;
     e = getenv("HIPENC_TIME");
     S->time_cpu = e != NULL && atoi(e) != 0;
   }
@@ -774,7 +795,22 @@ long od_hipenc_encode(od_hipenc *S, int nframes, long frame0, const unsigned cha
          take the lock meanwhile (frames [b0, b0 + batch_n) are not claimable before
          launched_upto moves) */
       pthread_mutex_unlock(&S->mu);
-      rc = od_hip_enc_feed_run(S->feed, b0 % J.nslots, J.batch_n);
+      rc = od_hip_enc_feed_gains(S->feed, b0 % J.nslots, J.batch_n);
+      pthread_mutex_lock(&S->mu);
+      if (rc != 0) {
+        J.failed = 1;
+        break;
+      }
+      /* the workers compand the batch, frame by frame */
+      J.companded = 0;
+      J.next_compand = b0;
+      J.compand_upto = b0 + J.batch_n;
+      pthread_cond_broadcast(&S->cv);
+      while (!J.failed && J.companded < J.batch_n) pthread_cond_wait(&S->cv, &S->mu);
+      if (J.failed) break;
+      J.st.t_compand_s += now_s() - tb;
+      pthread_mutex_unlock(&S->mu);
+      rc = od_hip_enc_feed_search(S->feed, b0 % J.nslots, J.batch_n);
       pthread_mutex_lock(&S->mu);
       if (rc != 0) {
         J.failed = 1;

@@ -31,6 +31,7 @@ typedef struct od_hipenc_stats {
   int64_t g2_mismatch;     /* candidate present but host g2 != device qg*cg (libm pow, 1 ulp) */
   int64_t lost_sync;       /* blocks whose call sequence did not match the feed */
   int64_t check_fail;      /* check mode: device answer != C answer (must be 0) */
+  int64_t resampled;       /* feed candidates re-searched on the host and compared (check_fail counts mismatches) */
   int64_t pvq_check_fail;  /* check mode: block result != the reference's od_pvq_encode (must be 0) */
   double search_cpu_s;     /* seconds inside the C pvq_search_rdo_double, all workers */
   double search_class_s[4];/* ... split: luma no-ref, luma with-ref, chroma no-ref, chroma with-ref */
@@ -40,7 +41,8 @@ typedef struct od_hipenc_stats {
   int64_t dering_check_fail; /* check mode: device block != C od_dering (must be 0) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
-  double t_launch_s;       /* enqueue of the device batch, wall */
+  double t_launch_s;       /* upload done -> device batch enqueued (includes t_compand_s), wall */
+  double t_compand_s;      /* upload done -> every frame's gains companded by the host's libm, wall */
   double t_total_s;        /* wall: first frame in -> last packet out */
   int64_t pkt_bytes_needed; /* size of the packet blob (with the 4-byte length prefixes) */
 } od_hipenc_stats;

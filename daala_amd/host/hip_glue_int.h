@@ -12,6 +12,8 @@ typedef struct glue_tls {
   int check;
   int time_cpu;
   int pli;                        /* plane of the block being coded */
+  int sample_every;               /* re-search every n-th feed candidate on the host (0: off) */
+  int sample_ctr;
   int host_pvq;                   /* 1: od_pvq_encode is hip_pvq_host.c's, 0: the reference's */
   daala_enc_ctx *enc;             /* encoder of the frame being coded by this thread */
   od_dct_func_2d fdct_cpu[OD_NBSIZES];   /* the context's own fdct_2d entries */

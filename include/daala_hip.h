@@ -217,9 +217,27 @@ typedef struct od_hip_pvq_band {
 int od_hip_band_offsets(int bs, int off[11]);
 
 /* Runs the search for pyramid level `level` of plane pli for slots
- * [slot0, slot0+nslots).  Results stay in HBM until downloaded. */
+ * [slot0, slot0+nslots).  Results stay in HBM until downloaded.
+ *
+ * The device evaluates NO transcendental: the one libm call on this path, pow() in
+ * od_gain_compand (src/pvq.c:422-425, beta = 1.5 with activity masking), is made by the
+ * HOST's libm - glibc's pow is not correctly rounded, so only the host's own libm gives
+ * the reference's bits.  Hence three steps:
+ *   od_hip_pvq_gains          device: exact g = sqrt(sum) of every band (src/pvq.c:456-464)
+ *   od_hip_pvq_compand_level  host: g down, cg = od_gain_compand(g, q[band], beta[band])
+ *                             with this process's libm, cg up (synchronous)
+ *   od_hip_pvq_search         device: candidates, K, codeword search, distortion
+ * od_hip_pvq_noref_search = the three in a row.  od_hip_pvq_compand is the bare host loop
+ * (cg[i] = od_gain_compand(g[i], q0, beta)). */
 int od_hip_pvq_noref_search(od_hip_ctx *ctx, int slot0, int nslots, int pli,
  int level, const int16_t *qm, const int32_t *q, const double *beta);
+int od_hip_pvq_gains(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+ const int16_t *qm, const int32_t *q, const double *beta);
+int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+ const int32_t *q, const double *beta);
+int od_hip_pvq_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
+ const int16_t *qm, const int32_t *q, const double *beta);
+int od_hip_pvq_compand(int count, const double *g, int q0, double beta, double *cg);
 
 /* Number of blocks of that level in one frame; the y array of one slot holds
  * nblocks * 2 * ncoded int32 (ncoded = min(n*n, 512)), block-major, then
@@ -237,7 +255,12 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
  *    block-size RDO pass and by the final pass is known before the entropy coder
  *    starts.  od_hip_enc_feed_run = od_hip_forward_pyramid + od_hip_pvq_noref_search
  *    of the 4 luma levels for the slots, then asynchronous copies of the results
- *    into pinned host memory on a second stream, one completion event per slot;
+ *    into pinned host memory on a second stream, one completion event per slot.
+ *    It is the sequence of three phases that a multi-threaded driver calls itself:
+ *      od_hip_enc_feed_gains(slot0, nslots)   device: pyramid + exact gains, g -> host
+ *      od_hip_enc_feed_compand(slot)          host, any thread, slot by slot: cg with the
+ *                                             host's libm (see section 4), cg -> device
+ *      od_hip_enc_feed_search(slot0, nslots)  device: searches, records -> host;
  *    od_hip_enc_feed_view blocks until that slot has landed and returns host
  *    pointers in the device's own band-major layout (no repacking):
  *      record r = band*nblk + block (blocks in raster order of the level)
@@ -254,7 +277,7 @@ typedef struct od_hip_feed_level {
   int32_t nbx;              /* blocks per row */
   int32_t off[11];          /* band boundaries in coding order */
   int32_t pad;
-  const double *cg;         /* [nbands*nblk] companded gain of the band */
+  const double *cg;         /* [nbands*nblk] companded gain of the band (the host's od_gain_compand of g) */
   const double *g;          /* [nbands*nblk] its uncompanded gain sqrt(acc) (src/pvq.c:456-464): exact */
   const int32_t *ncand;     /* [nbands*nblk] 0..2 */
   const int32_t *qg;        /* [2][nbands*nblk] gain index i; the search's g2 = qg*cg */
@@ -276,6 +299,9 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *feed);
 int od_hip_enc_feed_set_level(od_hip_enc_feed *feed, int level, const int16_t *qm,
  const int32_t *q, const double *beta);
 int od_hip_enc_feed_run(od_hip_enc_feed *feed, int slot0, int nslots);
+int od_hip_enc_feed_gains(od_hip_enc_feed *feed, int slot0, int nslots);
+int od_hip_enc_feed_compand(od_hip_enc_feed *feed, int slot);
+int od_hip_enc_feed_search(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_view(od_hip_enc_feed *feed, int slot, od_hip_feed_level lev[4]);
 
 /* ---------------------------------------------------------------------------
@@ -347,8 +373,9 @@ int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coe
 
 /* Diagnostic: the device's pow/acos/sin/cos/sqrt/divide on n doubles, so tests can
  * quantify agreement with the host libm the reference uses.
- * fn: 0 pow(x,y), 1 acos(x), 2 sin(x), 3 cos(x), 4 sqrt(x), 5 x/y, 6 the device's
- * x^(1/1.5) (gain companding), 7 the device's x^(-1/6) (od_compute_dist activity). */
+ * fn: 0 pow(x,y), 1 acos(x), 2 sin(x), 3 cos(x) (OCML; no product kernel calls them: the
+ * transcendentals of the path are evaluated by the host's libm between device passes),
+ * 4 sqrt(x), 5 x/y (used everywhere: must be identical to the host's). */
 int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *out);
 
 /* Profiling aid: streams a `bytes`-sized device buffer once with the access width

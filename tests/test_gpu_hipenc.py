@@ -52,12 +52,8 @@ def test_device_feed_equals_oracle_feed(masking):
         assert np.array_equal(a['lev'], g['lev']), ('pyramid plane', l)
         assert np.array_equal(a['ncand'], g['ncand'])
         assert np.array_equal(a['g'].view(np.int64), g['g'].view(np.int64)), ('gain', l)
-        assert np.array_equal(a['cg'].view(np.int64), g['cg'].view(np.int64)) or masking == 1
-        if masking == 1:   # beta = 1.5: libm pow on the host, DESIGN.md section 5
-            # (pow differs by <= 1 ulp in < 0.1 % of the bands; the division by q that
-            # follows can widen that to 2 ulp of cg)
-            ulp = np.abs(a['cg'].view(np.int64) - g['cg'].view(np.int64))
-            assert ulp.max() <= 2 and np.mean(ulp == 0) > 0.995
+        # beta = 1.5 too: the companding pow is the host's libm between the device passes
+        assert np.array_equal(a['cg'].view(np.int64), g['cg'].view(np.int64)), ('cg', l)
         for c in range(2):
             live = a['ncand'] > c
             for key in ('qg', 'k'):

@@ -71,6 +71,38 @@ def test_corrupt_feed_is_detected_not_trusted():
     assert got == want and st.lost_sync > 0
 
 
+def test_corrupt_pulses_are_detected_not_trusted():
+    """A pulse vector that is not a K-pulse codeword (or a cosine outside [0, 1]) fails the
+    integrity check of the feed consumer: the band is searched on the host (packets stay
+    identical) and counted."""
+    w, h = 352, 288
+    buf = setup_frames(w, h, [3])
+    want = reference_packets(buf, w, h, 1, 1)
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
+    view = H.OracleFeed(prm, H.pad_frame(prm, buf)[0])
+    y = view.keep[2]['y']
+    y[np.flatnonzero(y)[::5]] += 1                       # K no longer matches
+    view.keep[0]['cos_dist'][::11] = 1.5
+    n, got, st = H.encode(prm, buf, 1, [view])
+    assert got == want and st.lost_sync > 100
+
+
+def test_plausible_but_wrong_feed_is_caught_by_the_sampled_research(monkeypatch):
+    """A cosine distance that is wrong but plausible passes the integrity checks; the
+    sampled re-search (HIPENC_SAMPLE, here every 4th candidate) reports it."""
+    w, h = 352, 288
+    buf = setup_frames(w, h, [3])
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
+    view = H.OracleFeed(prm, H.pad_frame(prm, buf)[0])
+    monkeypatch.setenv('HIPENC_SAMPLE', '4')
+    n, got, st = H.encode(prm, buf, 1, [view])
+    assert st.resampled > 1000 and st.check_fail == 0
+    cd = view.keep[1]['cos_dist']
+    cd[cd > 0] *= 0.999
+    n, got, st = H.encode(prm, buf, 1, [view])
+    assert st.check_fail > 100
+
+
 def test_corrupt_pyramid_is_caught_by_check_mode():
     """The transform coefficients are taken from the feed without an independent host
     value (unlike K): the OD_CHECKASM-style check mode is what catches a wrong pyramid."""
