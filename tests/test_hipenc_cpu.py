@@ -81,7 +81,8 @@ def test_corrupt_pulses_are_detected_not_trusted():
     prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
     view = H.OracleFeed(prm, H.pad_frame(prm, buf)[0])
     y = view.keep[2]['y']
-    y[np.flatnonzero(y)[::5]] += 1                       # K no longer matches
+    idx = np.flatnonzero(y)[::5]
+    y[idx] += np.sign(y[idx])                            # one pulse too many: no K-pulse codeword
     view.keep[0]['cos_dist'][::11] = 1.5
     n, got, st = H.encode(prm, buf, 1, [view])
     assert got == want and st.lost_sync > 100
