@@ -44,6 +44,10 @@ void od_encode_rollback_cpu(daala_enc_ctx *enc, const od_rollback_buffer *rbuf);
 
 double od_hipenc_now(void);
 
+/* hip_pvq_search.c: pvq_search_rdo_double, four coefficients at a time, bit-identical */
+double od_hip_pvq_search_host(const double *xcoeff, int n, int k, od_coeff *ypulse,
+ double g2);
+
 /* hip_pvq_host.c */
 int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
  od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,

@@ -277,7 +277,20 @@ double od_hip_pvq_rate(int qg, int icgr, int theta, int ts, const od_adapt_ctx *
   }
   else rate = 0;
   if (qg > 0 && theta >= 0) {
-    rate += .9*OD_LOG2(ts);
+    /* .9*OD_LOG2(ts): ts is a small integer, the libm value is cached per thread (same
+       call, same bits) */
+    static __thread double log2_ts[64];
+    static __thread unsigned char have_ts[64];
+    double l2;
+    if (ts >= 0 && ts < 64) {
+      if (!have_ts[ts]) {
+        log2_ts[ts] = OD_LOG2(ts);
+        have_ts[ts] = 1;
+      }
+      l2 = log2_ts[ts];
+    }
+    else l2 = OD_LOG2(ts);
+    rate += .9*l2;
     if (is_keyframe && pli == 0) rate += 6;
     if (qg == icgr) rate -= .5;
   }
@@ -416,7 +429,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         qtheta = od_pvq_compute_theta(j, ts);
         k = od_pvq_compute_k(qcg, j, qtheta, 0, n, beta, 1);
         t0 = T.time_cpu ? od_hipenc_now() : 0;
-        cos_dist = od_ref_pvq_search_rdo_double_cpu(x, n - 1, k, y_tmp,
+        cos_dist = od_hip_pvq_search_host(x, n - 1, k, y_tmp,
          qcg*cg*sin(theta)*sin(qtheta));
         if (T.time_cpu) {
           double dt;
@@ -428,6 +441,12 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         dist_theta = 2 - 2*cos(theta - qtheta)
          + sin(theta)*sin(qtheta)*(2 - 2*cos_dist);
         dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*dist_theta;
+        /* The codeword's bits are >= 0 and floating-point + and * are monotonic, so the
+           cost is at least the cost with the codeword bits left out (k = 0 below: only the
+           theta/gain terms of od_pvq_rate, which can be negative).  A candidate that cannot
+           beat the incumbent even so is not priced. */
+        if (!(dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, NULL, 0, n, 1, pli, bs)
+         < best_cost)) continue;
         cost = dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, y_tmp, k, n, 1, pli, bs);
         if (cost < best_cost) {
           best_cost = cost;
@@ -502,6 +521,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         }
         T.st.dev_hits++;
         dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
+        if (!(dist <= best_cost)) continue;         /* no-reference rate = codeword bits >= 0 */
         cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, yc, k, n, 1, pli, bs);
         if (cost <= best_cost) {
           best_cost = cost;
@@ -526,7 +546,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         qcg = i;
         k = od_pvq_compute_k(qcg, -1, -1, 1, n, beta, 1);
         t0 = T.time_cpu ? od_hipenc_now() : 0;
-        cos_dist = od_ref_pvq_search_rdo_double_cpu(x1, n, k, y_tmp, qcg*cg);
+        cos_dist = od_hip_pvq_search_host(x1, n, k, y_tmp, qcg*cg);
         if (T.time_cpu) {
           double dt;
           dt = od_hipenc_now() - t0;
@@ -536,6 +556,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         if (L != NULL) T.st.cpu_noref_luma++;
         else T.st.cpu_other++;
         dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
+        if (!(dist <= best_cost)) continue;
         cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, y_tmp, k, n, 1, pli, bs);
         if (cost <= best_cost) {
           best_cost = cost;

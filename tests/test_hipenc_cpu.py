@@ -214,3 +214,34 @@ def test_truncated_or_mismatched_container_is_rejected():
     assert H.decode_blob(prm, hdr[:-3], blob, 1)[0] == -10          # truncated header packet
     other = H.Params(128, 64, 20, 7, 1, 1, 0, 0)
     assert H.decode_blob(other, hdr, blob, 1)[0] == -10             # not the stream's picture size
+
+
+def test_host_codeword_search_equals_reference_search():
+    """od_hip_pvq_search_host (hip_pvq_search.c: lane-wise scans + verified winner) against
+    the reference's pvq_search_rdo_double on the sizes the host searches (with-reference
+    bands have n - 1 coefficients), including inputs full of exact ties."""
+    lib = H.hipenc()
+    F64P, I32P = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    for f in (lib.od_hip_pvq_search_host, lib.od_ref_pvq_search_rdo_double_cpu):
+        f.restype = ctypes.c_double
+        f.argtypes = [F64P, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_double]
+    rng = np.random.default_rng(7)
+    for n in (7, 8, 14, 15, 31, 32, 127, 128):
+        for trial in range(400):
+            kind = trial % 4
+            x = rng.laplace(0, 1, n)*rng.choice([.01, 1, 30, 900])
+            if kind == 1:
+                x = np.round(x)                      # integers: many exact ties and zeros
+            elif kind == 2:
+                x[rng.random(n) < .6] = 0
+            elif kind == 3:
+                x = np.full(n, x[0] if x[0] else 1.)  # everything tied
+                x[rng.integers(n)] *= -1
+            k = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 120]))
+            g2 = float(rng.uniform(.01, 50))
+            x = np.ascontiguousarray(x)
+            ya, yb = np.zeros(n, np.int32), np.zeros(n, np.int32)
+            ca = lib.od_hip_pvq_search_host(x.ctypes.data_as(F64P), n, k, ya.ctypes.data_as(I32P), g2)
+            cb = lib.od_ref_pvq_search_rdo_double_cpu(x.ctypes.data_as(F64P), n, k,
+                                                      yb.ctypes.data_as(I32P), g2)
+            assert np.array_equal(ya, yb) and ca == cb, (n, trial, k)
