@@ -217,12 +217,12 @@ def test_truncated_or_mismatched_container_is_rejected():
 
 
 def test_host_codeword_search_equals_reference_search():
-    """od_hip_pvq_search_host (hip_pvq_search.c: lane-wise scans + verified winner) against
+    """od_hip_pvq_search_lanes (hip_pvq_search.c: lane-wise scans + verified winner) against
     the reference's pvq_search_rdo_double on the sizes the host searches (with-reference
     bands have n - 1 coefficients), including inputs full of exact ties."""
     lib = H.hipenc()
     F64P, I32P = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
-    for f in (lib.od_hip_pvq_search_host, lib.od_ref_pvq_search_rdo_double_cpu):
+    for f in (lib.od_hip_pvq_search_lanes, lib.od_ref_pvq_search_rdo_double_cpu):
         f.restype = ctypes.c_double
         f.argtypes = [F64P, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_double]
     rng = np.random.default_rng(7)
@@ -241,7 +241,7 @@ def test_host_codeword_search_equals_reference_search():
             g2 = float(rng.uniform(.01, 50))
             x = np.ascontiguousarray(x)
             ya, yb = np.zeros(n, np.int32), np.zeros(n, np.int32)
-            ca = lib.od_hip_pvq_search_host(x.ctypes.data_as(F64P), n, k, ya.ctypes.data_as(I32P), g2)
+            ca = lib.od_hip_pvq_search_lanes(x.ctypes.data_as(F64P), n, k, ya.ctypes.data_as(I32P), g2)
             cb = lib.od_ref_pvq_search_rdo_double_cpu(x.ctypes.data_as(F64P), n, k,
                                                       yb.ctypes.data_as(I32P), g2)
             assert np.array_equal(ya, yb) and ca == cb, (n, trial, k)
