@@ -44,48 +44,84 @@ __constant__ int8_t TAIL_DIR[8][3][2] = {
 __constant__ int16_t TAIL_THRESH_Q8[18] = {128, 134, 150, 168, 188, 210, 234, 262, 292,
   327, 365, 408, 455, 509, 569, 635, 710, 768};
 
-// od_dir_find8 (src/filter.c:1655-1708) on an 8x8 block of the TAIL_BSTRIDE tile.
-__device__ inline int tail_dir_find8(const int16_t *img, int32_t *var) {
-  int cost[8], partial[8][15];
-  for (int d = 0; d < 8; d++) { cost[d] = 0; for (int k = 0; k < 15; k++) partial[d][k] = 0; }
-  for (int i = 0; i < 8; i++) {
-    for (int j = 0; j < 8; j++) {
-      const int x = img[i*TAIL_BSTRIDE + j] >> 4;
-      partial[0][i + j] += x;
-      partial[1][i + j/2] += x;
-      partial[2][i] += x;
-      partial[3][3 + i - j/2] += x;
-      partial[4][7 + i - j] += x;
-      partial[5][3 - i/2 + j] += x;
-      partial[6][j] += x;
-      partial[7][i/2 + j] += x;
+// od_dir_find8 (src/filter.c:1655-1708) for the 16 8x8 blocks of a 32x32 luma tile, by
+// the whole workgroup.  The reference accumulates, per block and direction d, the sums of
+// the pixels along the <= 15 lines of that direction (partial[d][line]); integer sums are
+// associative, so they are built here by 1024 (block, direction, row) work items - 4 per
+// thread - that add their row's 8 pixels into LDS counters (pixels that fall on the same
+// line are merged in registers first), instead of 16 threads walking 64 pixels x 8
+// directions with a 120-entry private array.  part: [16][8][16] zero-initialised.
+__device__ __forceinline__ void tail_dir_accumulate(const int16_t *in, int32_t *part, int t) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int item = t + 256*r;
+    const int blk = item >> 6, d = (item >> 3) & 7, i = item & 7;
+    const int16_t *row = in + (8*(blk >> 2) + i)*TAIL_BSTRIDE + 8*(blk & 3);
+    int x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = row[j] >> 4;
+    int32_t *p = part + (blk*8 + d)*16;
+    switch (d) {
+      case 0:
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&p[i + j], x[j]);
+        break;
+      case 1:
+#pragma unroll
+        for (int j = 0; j < 4; j++) atomicAdd(&p[i + j], x[2*j] + x[2*j + 1]);
+        break;
+      case 2:
+        atomicAdd(&p[i], x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7]);
+        break;
+      case 3:
+#pragma unroll
+        for (int j = 0; j < 4; j++) atomicAdd(&p[3 + i - j], x[2*j] + x[2*j + 1]);
+        break;
+      case 4:
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&p[7 + i - j], x[j]);
+        break;
+      case 5:
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&p[3 - i/2 + j], x[j]);
+        break;
+      case 6:
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&p[j], x[j]);
+        break;
+      default:
+#pragma unroll
+        for (int j = 0; j < 8; j++) atomicAdd(&p[i/2 + j], x[j]);
+        break;
     }
   }
-  for (int i = 0; i < 8; i++) {
-    cost[2] += partial[2][i]*partial[2][i] >> 3;
-    cost[6] += partial[6][i]*partial[6][i] >> 3;
+}
+
+// cost of one (block, direction) from its line sums (src/filter.c:1676-1697)
+__device__ __forceinline__ int tail_dir_cost(const int32_t *p, int d) {
+  int cost = 0;
+  if (d == 2 || d == 6) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) cost += p[i]*p[i] >> 3;
   }
-  for (int i = 0; i < 7; i++) {
-    cost[0] += (int)((uint32_t)(partial[0][i]*partial[0][i])/(uint32_t)(i + 1))
-               + (int)((uint32_t)(partial[0][14 - i]*partial[0][14 - i])/(uint32_t)(i + 1));
-    cost[4] += (int)((uint32_t)(partial[4][i]*partial[4][i])/(uint32_t)(i + 1))
-               + (int)((uint32_t)(partial[4][14 - i]*partial[4][14 - i])/(uint32_t)(i + 1));
+  else if (d == 0 || d == 4) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      cost += (int)((uint32_t)(p[i]*p[i])/(uint32_t)(i + 1))
+              + (int)((uint32_t)(p[14 - i]*p[14 - i])/(uint32_t)(i + 1));
+    }
+    cost += p[7]*p[7] >> 3;
   }
-  cost[0] += partial[0][7]*partial[0][7] >> 3;
-  cost[4] += partial[4][7]*partial[4][7] >> 3;
-  for (int i = 1; i < 8; i += 2) {
-    for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j]*partial[i][3 + j] >> 3;
+  else {
+#pragma unroll
+    for (int j = 0; j < 5; j++) cost += p[3 + j]*p[3 + j] >> 3;
+#pragma unroll
     for (int j = 0; j < 3; j++) {
-      cost[i] += (int)((uint32_t)(partial[i][j]*partial[i][j])/(uint32_t)(2*j + 2))
-                 + (int)((uint32_t)(partial[i][10 - j]*partial[i][10 - j])/(uint32_t)(2*j + 2));
+      cost += (int)((uint32_t)(p[j]*p[j])/(uint32_t)(2*j + 2))
+              + (int)((uint32_t)(p[10 - j]*p[10 - j])/(uint32_t)(2*j + 2));
     }
   }
-  int best_cost = 0, best_dir = 0;
-  for (int i = 0; i < 8; i++) {
-    if (cost[i] > best_cost) { best_cost = cost[i]; best_dir = i; }
-  }
-  *var = best_cost - cost[(best_dir + 4) & 7];
-  return best_dir;
+  return cost;
 }
 
 __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
@@ -93,6 +129,7 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
   __shared__ int16_t in1[TAIL_BSTRIDE*TAIL_BSTRIDE];   // border + direction-filtered interior
   __shared__ int32_t out[32*32];
   __shared__ int32_t rowsum[32];
+  __shared__ int32_t part[16*8*16];                    // line sums, then costs in [..][0]
   __shared__ int dirs[16], vars[16], thresh[16];
   __shared__ int sh_w;
   const int t = threadIdx.x;
@@ -126,11 +163,25 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
       __syncthreads();
       const int16_t *in = in0 + 3*TAIL_BSTRIDE + 3;
       if (pli == 0) {
+        for (int e = t; e < 16*8*16; e += 256) part[e] = 0;
+        __syncthreads();
+        tail_dir_accumulate(in, part, t);
+        __syncthreads();
+        int cost = 0;
+        if (t < 128) cost = tail_dir_cost(part + t*16, t & 7);
+        __syncthreads();
+        if (t < 128) part[t*16] = cost;
+        __syncthreads();
         if (t < 16) {
-          const int by = t >> 2, bx = t & 3;
-          int32_t v;
-          dirs[t] = tail_dir_find8(in + (8*by)*TAIL_BSTRIDE + 8*bx, &v);
-          vars[t] = v;
+          // first direction with the largest cost (strict '>' scan from best_cost = 0)
+          int best_cost = 0, best_dir = 0;
+#pragma unroll
+          for (int d = 0; d < 8; d++) {
+            const int c = part[(t*8 + d)*16];
+            if (c > best_cost) { best_cost = c; best_dir = d; }
+          }
+          dirs[t] = best_dir;
+          vars[t] = best_cost - part[(t*8 + ((best_dir + 4) & 7))*16];
         }
         __syncthreads();
         if (t < 16) {
