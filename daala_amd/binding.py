@@ -150,6 +150,14 @@ def od_haar_blocks(bs, blocks, inverse=False):
     return y
 
 
+def od_coding_order_blocks(bs, blocks, to_raster=False, dst=None):
+    """A11 gather (raster -> coding order) / scatter (coding order -> raster) of dense blocks."""
+    x = _c32(blocks)
+    y = np.zeros_like(x) if dst is None else _c32(dst).copy()
+    _chk(load().od_hip_coding_order_blocks(bs, int(to_raster), _p32(y), _p32(x), x.shape[0]))
+    return y
+
+
 def od_pre_filter4(vectors):
     x = _c32(vectors)
     y = np.empty_like(x)

@@ -322,6 +322,47 @@ int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in, i
   return 0;
 }
 
+// A11: od_raster_to_coding_order / od_coding_order_to_raster (src/partition.c:144-194) for
+// nblocks dense n x n blocks.  One thread per (block, coding index).
+__global__ void k_coding_order_blocks(int nn, int ncoded, long total, int to_raster,
+                                      const uint16_t *__restrict__ tab,
+                                      const int32_t *__restrict__ in, int32_t *__restrict__ out) {
+  const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long b = t/ncoded;
+  const int i = (int)(t - b*ncoded);
+  if (to_raster) out[b*nn + tab[i]] = in[b*nn + i];
+  else out[b*nn + i] = in[b*nn + tab[i]];
+}
+
+int od_hip_coding_order_blocks(int bs, int to_raster, od_coeff *inout_dst, const od_coeff *src,
+                               int nblocks) {
+  if (!inout_dst || !src) return fail(OD_HIP_EFAULT, "null pointer");
+  if (bs < 0 || bs >= OD_HIP_NBSIZES || nblocks < 0) return fail(OD_HIP_EINVAL, "bad bs/nblocks");
+  if (int rc = ensure_device()) return rc;
+  if (nblocks == 0) return 0;
+  const uint16_t *tabs[4] = {CODING_TO_RASTER_4, CODING_TO_RASTER_8, CODING_TO_RASTER_16,
+                             CODING_TO_RASTER_32};
+  const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
+  const int n = 4 << bs, nn = n*n, ncoded = tabn[bs];
+  const size_t bytes = (size_t)nblocks*nn*4;
+  if (int rc = g_in.reserve(bytes)) return rc;
+  if (int rc = g_out.reserve(bytes)) return rc;
+  if (int rc = g_aux0.reserve((size_t)ncoded*2)) return rc;
+  HIPCHK(hipMemcpy(g_in.p, src, bytes, hipMemcpyHostToDevice));
+  // positions the permutation does not touch (a 32x32 block codes 512 of its 1024
+  // coefficients) keep the caller's values, as in the reference (src/encode.c:1219-1220)
+  HIPCHK(hipMemcpy(g_out.p, inout_dst, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, tabs[bs], (size_t)ncoded*2, hipMemcpyHostToDevice));
+  const long total = (long)nblocks*ncoded;
+  hipLaunchKernelGGL(k_coding_order_blocks, dim3((unsigned)((total + 255)/256)), dim3(256), 0, 0, nn,
+                     ncoded, total, to_raster, (const uint16_t *)g_aux0.p, (const int32_t *)g_in.p,
+                     (int32_t *)g_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(inout_dst, g_out.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int od_hip_filter4_vectors(int inverse, od_coeff *out, const od_coeff *in, int nvec) {
   if (!out || !in) return fail(OD_HIP_EFAULT, "null pointer");
   if (nvec < 0) return fail(OD_HIP_EINVAL, "bad nvec");

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
   __shared__ int32_t rowsum[32];
   __shared__ int32_t part[16*8*16];                    // line sums, then costs in [..][0]
   __shared__ int dirs[16], vars[16], thresh[16];
+  __shared__ int doff[16*3];                           // tap offsets of each block's direction
   __shared__ int sh_w;
   const int t = threadIdx.x;
   int sbx, sby, f;
@@ -184,6 +185,12 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
           vars[t] = best_cost - part[(t*8 + ((best_dir + 4) & 7))*16];
         }
         __syncthreads();
+        // the three tap offsets of every block's direction, once per superblock (chroma
+        // reuses them): keeps the per-pixel loop free of constant-memory gathers
+        if (t < 48) {
+          const int blk = t/3, k = t - 3*blk;
+          doff[t] = TAIL_DIR[dirs[blk]][k][0]*TAIL_BSTRIDE + TAIL_DIR[dirs[blk]][k][1];
+        }
         if (t < 16) {
           int varsum = 0;
           for (int k = 0; k < 16; k++) varsum += vars[k];
@@ -220,12 +227,12 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
       for (int e = t; e < n*n; e += 256) {
         const int i = e >> ln, j = e & (n - 1);
         const int blk = (i >> bsz)*4 + (j >> bsz);
-        const int th = thresh[blk], dir = dirs[blk];
+        const int th = thresh[blk];
         const int xx = in[i*TAIL_BSTRIDE + j];
         int sum = 0;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const int off = TAIL_DIR[dir][k][0]*TAIL_BSTRIDE + TAIL_DIR[dir][k][1];
+          const int off = doff[blk*3 + k];
           const int tap = k == 0 ? 3 : 2;
           const int p0 = in[i*TAIL_BSTRIDE + j + off] - xx;
           const int p1 = in[i*TAIL_BSTRIDE + j - off] - xx;

@@ -355,6 +355,14 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
  const double *gr, const int32_t *noref, const double *g, const double *theta,
  const int16_t *qm, const int16_t *qm_inv, od_coeff *out);
 
+/* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
+ * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks
+ * (n = 4 << bs).  dst is in/out: entries the permutation does not write (a 32x32 block
+ * codes 512 of its 1024 coefficients) keep the caller's values, like the reference's
+ * buffers (od_init_skipped_coeffs before the scatter, src/encode.c:1219-1220). */
+int od_hip_coding_order_blocks(int bs, int to_raster, od_coeff *inout_dst, const od_coeff *src,
+ int nblocks);
+
 /* Keyframe luma predictor of od_encode_compute_pred (src/encode.c:732-737):
  * OD_CLEAR + od_hv_intra_pred (src/intra.c:37-61) for nblk blocks of size bs at
  * 4x4-unit positions (bx[i], by[i]) of the w x h coefficient plane d.

@@ -543,3 +543,24 @@ def test_cfl_resample_other_decimations(hip):
             o.orc_resample_luma_coeffs(p32(e), 4, p32(np.ascontiguousarray(luma.ravel()[off:])), 64,
                                        xdec, ydec, 0, 0)
             assert np.array_equal(p[i], e), (xdec, ydec, i)
+
+
+def test_coding_order_gather_and_scatter(hip):
+    """A11 both directions on the device vs the oracle (the reference's permutation tables):
+    od_raster_to_coding_order and od_coding_order_to_raster; a 32x32 block moves 512 of its
+    1024 coefficients, the rest of the destination keeps the caller's values."""
+    o = oracle()
+    rng = np.random.default_rng(77)
+    for bs in range(4):
+        n = 4 << bs
+        x = rng.integers(-5000, 5001, size=(40, n, n), dtype=np.int32)
+        base = rng.integers(-9, 10, size=(40, n*n), dtype=np.int32)
+        got = hip.od_coding_order_blocks(bs, x.reshape(40, n*n), dst=base)
+        back = hip.od_coding_order_blocks(bs, got, to_raster=True, dst=base)
+        for b in range(40):
+            e = base[b].copy()
+            o.orc_raster_to_coding_order(p32(e), n, p32(np.ascontiguousarray(x[b])), n)
+            assert np.array_equal(got[b], e), (bs, b)
+            r = np.ascontiguousarray(base[b].reshape(n, n).copy())
+            o.orc_coding_order_to_raster(p32(r), n, p32(np.ascontiguousarray(got[b])), n)
+            assert np.array_equal(back[b].reshape(n, n), r), (bs, b)
