@@ -150,6 +150,35 @@ def od_haar_blocks(bs, blocks, inverse=False):
     return y
 
 
+class McBlock(ctypes.Structure):
+    """od_hip_mc_block (include/daala_hip.h)."""
+    _fields_ = [('x', ctypes.c_int32), ('y', ctypes.c_int32), ('log_xblk_sz', ctypes.c_int32),
+                ('log_yblk_sz', ctypes.c_int32), ('ref', ctypes.c_int32*4),
+                ('mvx', ctypes.c_int32*4), ('mvy', ctypes.c_int32*4), ('oc', ctypes.c_int32),
+                ('s', ctypes.c_int32)]
+
+
+def od_mc_predict_blocks(refs, org_x, org_y, blocks, dst):
+    """F3: OBMC prediction of a list of blocks.  refs: list of equal-shape padded u8 planes;
+    blocks: list of dicts (x, y, lx, ly, ref[4], mvx[4], mvy[4], oc, s); dst: u8 plane (copy)."""
+    refs = [np.ascontiguousarray(r, dtype=np.uint8) for r in refs]
+    out = np.ascontiguousarray(dst, dtype=np.uint8).copy()
+    arr = (McBlock*len(blocks))()
+    for i, b in enumerate(blocks):
+        arr[i].x, arr[i].y, arr[i].log_xblk_sz, arr[i].log_yblk_sz = b['x'], b['y'], b['lx'], b['ly']
+        for k in range(4):
+            arr[i].ref[k], arr[i].mvx[k], arr[i].mvy[k] = int(b['ref'][k]), int(b['mvx'][k]), int(b['mvy'][k])
+        arr[i].oc, arr[i].s = b['oc'], b['s']
+    ptrs = (U8P*len(refs))(*[r.ctypes.data_as(U8P) for r in refs])
+    lib = load()
+    lib.od_hip_mc_predict_blocks.argtypes = [c_int, ctypes.POINTER(U8P), c_int, c_int, c_int, c_int,
+                                             ctypes.POINTER(McBlock), c_int, U8P, c_int, c_int]
+    _chk(lib.od_hip_mc_predict_blocks(len(refs), ptrs, refs[0].shape[1], refs[0].shape[0], org_x, org_y,
+                                      arr, len(blocks), out.ctypes.data_as(U8P), out.shape[1],
+                                      out.shape[0]))
+    return out
+
+
 def od_coding_order_blocks(bs, blocks, to_raster=False, dst=None):
     """A11 gather (raster -> coding order) / scatter (coding order -> raster) of dense blocks."""
     x = _c32(blocks)

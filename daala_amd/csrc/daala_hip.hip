@@ -14,6 +14,7 @@
 #include "coding_order_tables.h"
 #include "pvq_kernels.hpp"
 #include "pvq_theta_kernels.hpp"
+#include "mc_kernels.hpp"
 #include "xform_kernels.hpp"
 #include "xform_rt_kernels.hpp"
 #include "tail_kernels.hpp"
@@ -319,6 +320,51 @@ int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in, i
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, g_out.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// F3: OBMC prediction of a list of blocks (mc_kernels.hpp).
+int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int ref_stride, int ref_h,
+                             int org_x, int org_y, const od_hip_mc_block *blocks, int nblocks,
+                             unsigned char *dst, int dst_stride, int dst_h) {
+  if (!refs || !blocks || !dst) return fail(OD_HIP_EFAULT, "null pointer");
+  if (nref < 1 || nref > 8 || ref_stride < 1 || ref_h < 1 || nblocks < 0 || dst_stride < 1 || dst_h < 1)
+    return fail(OD_HIP_EINVAL, "bad geometry");
+  for (int k = 0; k < nref; k++) if (!refs[k]) return fail(OD_HIP_EFAULT, "null reference plane");
+  // operand shapes are checked on the host before anything is launched
+  for (int b = 0; b < nblocks; b++) {
+    const od_hip_mc_block &m = blocks[b];
+    if (m.log_xblk_sz < 2 || m.log_xblk_sz > 5 || m.log_yblk_sz < 2 || m.log_yblk_sz > 5 || m.x < 0 || m.y < 0
+        || m.x + (1 << m.log_xblk_sz) > dst_stride || m.y + (1 << m.log_yblk_sz) > dst_h
+        || m.oc < 0 || m.oc > 3 || m.s < 0 || m.s > 3)
+      return fail(OD_HIP_EINVAL, "bad prediction block");
+    for (int k = 0; k < 4; k++) if (m.ref[k] < 0 || m.ref[k] >= nref) return fail(OD_HIP_EINVAL, "bad reference index");
+  }
+  if (int rc = ensure_device()) return rc;
+  if (nblocks == 0) return 0;
+  static_assert(sizeof(McBlock) == sizeof(od_hip_mc_block), "McBlock mirrors od_hip_mc_block");
+  const size_t plane = (size_t)ref_stride*ref_h, dbytes = (size_t)dst_stride*dst_h;
+  if (int rc = g_in.reserve(plane*nref)) return rc;
+  if (int rc = g_aux0.reserve((size_t)nblocks*sizeof(McBlock))) return rc;
+  if (int rc = g_out.reserve(dbytes)) return rc;
+  for (int k = 0; k < nref; k++)
+    HIPCHK(hipMemcpy((uint8_t *)g_in.p + plane*k, refs[k], plane, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_aux0.p, blocks, (size_t)nblocks*sizeof(McBlock), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_out.p, dst, dbytes, hipMemcpyHostToDevice));     // blocks need not cover the plane
+  McArgs a;
+  a.refs = (const uint8_t *)g_in.p;
+  a.ref_plane = plane;
+  a.ref_stride = ref_stride;
+  a.ref_h = ref_h;
+  a.org_x = org_x;
+  a.org_y = org_y;
+  a.blocks = (const McBlock *)g_aux0.p;
+  a.nblocks = nblocks;
+  a.dst = (uint8_t *)g_out.p;
+  a.dst_stride = dst_stride;
+  hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(64), 0, 0, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(dst, g_out.p, dbytes, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -355,6 +355,29 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
  const double *gr, const int32_t *noref, const double *g, const double *theta,
  const int16_t *qm, const int16_t *qm_inv, od_coeff *out);
 
+/* F3 (inter frames, first kernel): overlapped block motion compensation of a list of
+ * prediction blocks = the leaves od_state_mc_predict (src/state.c:993) visits through
+ * od_state_pred_block -> od_state_pred_block_from_setup (:689) -> od_mc_predict
+ * (src/mc.c:2006): per block four od_mc_predict1fmv8_c predictions (src/mc.c:94), one per
+ * corner motion vector, blended by od_mc_blend_full8_c (s == 3, :352) or
+ * od_mc_blend_full_split8_c (:1104).  8-bit references.
+ *   refs[k]: reference plane k, ref_h rows of ref_stride bytes, the picture's (0, 0) at
+ *            (org_x, org_y) - the reference keeps OD_UMV padding around its frames;
+ *   block:   (x, y) in the picture, 2^log_xblk_sz x 2^log_yblk_sz samples (4..32), corner k
+ *            reads reference ref[k] with vector (mvx[k], mvy[k]) in 1/8 sample of THIS plane
+ *            (the host applies OD_DIV_POW2_RE for chroma, :719-720); oc, s as the reference;
+ *   dst:     in/out plane, dst_h rows of dst_stride bytes; only the blocks are written. */
+typedef struct od_hip_mc_block {
+  int32_t x, y;
+  int32_t log_xblk_sz, log_yblk_sz;
+  int32_t ref[4];
+  int32_t mvx[4], mvy[4];
+  int32_t oc, s;
+} od_hip_mc_block;
+int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int ref_stride,
+ int ref_h, int org_x, int org_y, const od_hip_mc_block *blocks, int nblocks,
+ unsigned char *dst, int dst_stride, int dst_h);
+
 /* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
  * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks
  * (n = 4 << bs).  dst is in/out: entries the permutation does not write (a 32x32 block

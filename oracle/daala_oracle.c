@@ -1332,3 +1332,126 @@ void orc_post_filter_n(int n, coeff *x, const coeff *y) {
   for (i = 0; i < h; i++) x[i] = t[i];
   for (i = 0; i < h; i++) x[n - 1 - i] = t[i] - t[n - 1 - i];
 }
+
+/* ------------------------------------------------------------------------ */
+/* F3: overlapped block motion compensation of one prediction block,
+   8-bit references.  Restates od_mc_predict1fmv8_c (reference src/mc.c:94-203),
+   od_mc_blend_full8_c (:352-377), od_mc_setup_s_split + od_mc_blend_full_split8_c
+   (:1056-1151) and od_mc_predict / od_mc_blend (:1938-2034; the multiresolution branch is
+   compiled out there by `0 &&`). */
+static const int16_t ORC_SUBPEL[8][6] = {      /* OD_SUBPEL_FILTER_SET, src/mc.c:66-77 */
+  {0, 0, 128, 0, 0, 0}, {1, -9, 122, 18, -5, 1}, {3, -15, 112, 37, -11, 2},
+  {3, -18, 97, 58, -15, 3}, {4, -20, 80, 80, -20, 4}, {3, -15, 58, 97, -18, 3},
+  {2, -11, 37, 112, -15, 3}, {1, -5, 18, 122, -9, 1}};
+
+static int orc_clamp255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+/* dst: xblk x yblk, dense (stride xblk) */
+void orc_mc_predict1fmv8(uint8_t *dst, const uint8_t *src, int systride, int32_t mvx,
+ int32_t mvy, int log_xblk_sz, int log_yblk_sz) {
+  int xblk = 1 << log_xblk_sz, yblk = 1 << log_yblk_sz, i, j, k;
+  int mvxf = mvx & 7, mvyf = mvy & 7;
+  const int16_t *fx = ORC_SUBPEL[mvxf], *fy = ORC_SUBPEL[mvyf];
+  int16_t buff[(32 + 5)*32];
+  const uint8_t *sp = src + (mvx >> 3) + (mvy >> 3)*systride;
+  if (mvxf || mvyf) {
+    int16_t *bp = buff;
+    sp -= systride*2;
+    for (j = -2; j < yblk + 3; j++) {
+      for (i = 0; i < xblk; i++) {
+        if (mvxf) {
+          int32_t sum = 0;
+          for (k = 0; k < 6; k++) sum += sp[i + k - 2]*fx[k];
+          bp[i] = (int16_t)(sum - (128 << 7));
+        }
+        else bp[i] = (int16_t)((sp[i] << 7) - (128 << 7));
+      }
+      sp += systride;
+      bp += xblk;
+    }
+    bp = buff + xblk*2;
+    for (j = 0; j < yblk; j++) {
+      for (i = 0; i < xblk; i++) {
+        if (mvyf) {
+          int32_t sum = 0;
+          for (k = 0; k < 6; k++) sum += bp[i + (k - 2)*xblk]*fy[k];
+          dst[i] = (uint8_t)orc_clamp255((sum + (1 << 13) + (128 << 14)) >> 14);
+        }
+        else dst[i] = (uint8_t)orc_clamp255((bp[i] + (1 << 6) + (128 << 7)) >> 7);
+      }
+      bp += xblk;
+      dst += xblk;
+    }
+  }
+  else {
+    for (j = 0; j < yblk; j++) {
+      for (i = 0; i < xblk; i++) dst[j*xblk + i] = sp[j*systride + i];
+    }
+  }
+}
+
+void orc_mc_blend_full8(uint8_t *dst, int dystride, const uint8_t *const src[4],
+ int log_xblk_sz, int log_yblk_sz) {
+  int xblk = 1 << log_xblk_sz, yblk = 1 << log_yblk_sz, l2 = log_xblk_sz + log_yblk_sz;
+  int round = 1 << (l2 - 1), i, j;
+  for (j = 0; j < yblk; j++) {
+    for (i = 0; i < xblk; i++) {
+      int32_t a = src[0][j*xblk + i], b = src[3][j*xblk + i];
+      a = (a << log_xblk_sz) + (src[1][j*xblk + i] - a)*i;
+      b = (b << log_xblk_sz) + (src[2][j*xblk + i] - b)*i;
+      dst[j*dystride + i] = (uint8_t)(((a << log_yblk_sz) + (b - a)*j + round) >> l2);
+    }
+  }
+}
+
+void orc_mc_blend_full_split8(uint8_t *dst, int dystride, const uint8_t *const src[4], int oc,
+ int s, int log_xblk_sz, int log_yblk_sz) {
+  int xblk = 1 << log_xblk_sz, yblk = 1 << log_yblk_sz, l2 = log_xblk_sz + log_yblk_sz;
+  int s0[4], dsdi[4], dsdj[4], dd[4], sw[4], i, j, k, round = 1 << l2;
+  s0[0] = 2 << l2; s0[1] = s0[2] = s0[3] = 0;
+  dsdi[0] = -(2 << log_xblk_sz); dsdi[1] = 2 << log_xblk_sz; dsdi[2] = dsdi[3] = 0;
+  dsdj[0] = -(2 << log_yblk_sz); dsdj[1] = dsdj[2] = 0; dsdj[3] = 2 << log_yblk_sz;
+  dd[0] = dd[2] = 2; dd[1] = dd[3] = -2;
+  for (k = 0; k < 2; k++) {
+    /* an unsplit edge hands half of the neighbouring corner's weight to the outside corner */
+    int on = k == 0 ? !(s & 1) : !(s & 2), c = k == 0 ? (oc + 1) & 3 : (oc + 3) & 3;
+    if (on) {
+      s0[c] >>= 1; s0[oc] += s0[c];
+      dsdi[c] >>= 1; dsdi[oc] += dsdi[c];
+      dsdj[c] >>= 1; dsdj[oc] += dsdj[c];
+      dd[c] >>= 1; dd[oc] += dd[c];
+    }
+  }
+  for (k = 0; k < 4; k++) sw[k] = s0[k];
+  for (j = 0; j < yblk; j++) {
+    for (i = 0; i < xblk; i++) {
+      int32_t a = src[0][j*xblk + i];
+      int32_t b = (src[1][j*xblk + i] - a)*sw[1];
+      int32_t c = (src[2][j*xblk + i] - a)*sw[2];
+      int32_t d = (src[3][j*xblk + i] - a)*sw[3];
+      dst[j*dystride + i] = (uint8_t)(((a << (l2 + 1)) + b + c + d + round) >> (l2 + 1));
+      for (k = 0; k < 4; k++) sw[k] += dsdi[k];
+    }
+    for (k = 0; k < 4; k++) {
+      s0[k] += dsdj[k];
+      sw[k] = s0[k];
+      dsdi[k] += dd[k];
+    }
+  }
+}
+
+/* od_mc_predict: four single-vector predictions (one per corner of the block, each from its
+   own reference) blended by position. */
+void orc_mc_predict(uint8_t *dst, int dystride, const uint8_t *const src[4], int systride,
+ const int32_t mvx[4], const int32_t mvy[4], int oc, int s, int log_xblk_sz,
+ int log_yblk_sz) {
+  uint8_t pred[4][32*32];
+  const uint8_t *p[4];
+  int k;
+  for (k = 0; k < 4; k++) {
+    orc_mc_predict1fmv8(pred[k], src[k], systride, mvx[k], mvy[k], log_xblk_sz, log_yblk_sz);
+    p[k] = pred[k];
+  }
+  if (s == 3) orc_mc_blend_full8(dst, dystride, p, log_xblk_sz, log_yblk_sz);
+  else orc_mc_blend_full_split8(dst, dystride, p, oc, s, log_xblk_sz, log_yblk_sz);
+}

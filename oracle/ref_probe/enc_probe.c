@@ -281,3 +281,22 @@ int probe_dering(int16_t *y, int ystride, int16_t *x, int xstride, int ln, int s
   daala_encode_free(enc);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* od_mc_predict (src/mc.c:2006) of one block through a live context's vtable (C entries:
+   od_mc_predict1fmv8_c, od_mc_blend_full8_c, od_mc_blend_full_split8_c).  src[k]: pointer
+   to the block's position in the k-th corner's reference plane. */
+int probe_mc_predict(unsigned char *dst, int dystride, const unsigned char *src0,
+ const unsigned char *src1, const unsigned char *src2, const unsigned char *src3,
+ int systride, const int32_t *mvx, const int32_t *mvy, int oc, int s, int log_xblk_sz,
+ int log_yblk_sz) {
+  daala_enc_ctx *enc;
+  const unsigned char *src[4];
+  enc = make_encoder(64, 64, 20, 7, 1, 1);
+  if (enc == NULL) return -1;
+  src[0] = src0; src[1] = src1; src[2] = src2; src[3] = src3;
+  od_mc_predict(&enc->state, dst, dystride, src, systride, mvx, mvy, oc, s, log_xblk_sz,
+   log_yblk_sz);
+  daala_encode_free(enc);
+  return 0;
+}

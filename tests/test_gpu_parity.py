@@ -564,3 +564,40 @@ def test_coding_order_gather_and_scatter(hip):
             r = np.ascontiguousarray(base[b].reshape(n, n).copy())
             o.orc_coding_order_to_raster(p32(r), n, p32(np.ascontiguousarray(got[b])), n)
             assert np.array_equal(back[b].reshape(n, n), r), (bs, b)
+
+
+def test_obmc_prediction_blocks(hip):
+    """F3, first inter kernel: od_hip_mc_predict_blocks against the reference's od_mc_predict
+    outputs (tests/golden/mc_blocks.npz: 117 blocks of 4x4..32x32, one to three references,
+    full and fractional vectors, every (oc, s)) and against the oracle on a random list."""
+    import ctypes
+    g = golden('mc_blocks.npz')
+    refs, pad, dst = g['refs'], int(g['pad']), g['dst']
+    blocks = [dict(x=int(b[0]), y=int(b[1]), lx=int(b[2]), ly=int(b[3]), ref=b[4:8], mvx=b[8:12],
+                   mvy=b[12:16], oc=int(b[16]), s=int(b[17])) for b in g['blocks']]
+    got = hip.od_mc_predict_blocks(list(refs), pad, pad, blocks, np.zeros_like(dst))
+    assert np.array_equal(got, dst)
+    # random (also non-square) blocks vs the oracle
+    o = oracle()
+    rng = np.random.default_rng(9)
+    H, W, P = 96, 128, 40
+    rr = [rng.integers(0, 256, size=(H + 2*P, W + 2*P), dtype=np.uint8) for _ in range(2)]
+    rw = W + 2*P
+    U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+    bl, want = [], np.zeros((H, W), np.uint8)
+    for y in range(0, H, 32):
+        for x in range(0, W, 32):
+            lx, ly = int(rng.integers(2, 6)), int(rng.integers(2, 6))
+            mvx = rng.integers(-8*(P - 6), 8*(P - 6), size=4).astype(np.int32) | 1
+            mvy = rng.integers(-8*(P - 6), 8*(P - 6), size=4).astype(np.int32)
+            ks = rng.integers(0, 2, size=4)
+            oc, s = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            bl.append(dict(x=x, y=y, lx=lx, ly=ly, ref=ks, mvx=mvx, mvy=mvy, oc=oc, s=s))
+            n, m = 1 << lx, 1 << ly
+            out = np.zeros((m, n), np.uint8)
+            srcs = (U8P*4)(*[ctypes.cast(rr[int(k)].ctypes.data + (P + y)*rw + P + x, U8P) for k in ks])
+            o.orc_mc_predict(pu8(out), n, srcs, rw, mvx.ctypes.data_as(I32P), mvy.ctypes.data_as(I32P),
+                             oc, s, lx, ly)
+            want[y:y + m, x:x + n] = out
+    got = hip.od_mc_predict_blocks(rr, P, P, bl, np.zeros((H, W), np.uint8))
+    assert np.array_equal(got, want)

@@ -203,3 +203,25 @@ def test_cfl_resample_other_decimations():
             b = np.zeros((n, n), np.int32)
             o.orc_resample_luma_coeffs(p32(b), n, p32(luma), 64, xdec, ydec, bs, cbs)
             assert np.array_equal(b, g['p_%d%d_%d_%d' % (xdec, ydec, bs, cbs)]), (xdec, ydec, bs)
+
+
+def test_obmc_blocks_golden():
+    """F3: the oracle's OBMC block prediction against the reference outputs stored in
+    tests/golden/mc_blocks.npz (od_mc_predict through a live context, tools/gen_golden.py)."""
+    import ctypes
+    g = load('mc_blocks.npz')
+    o = oracle()
+    refs, pad, dst = g['refs'], int(g['pad']), g['dst']
+    rw = refs.shape[2]
+    U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+    got = np.zeros_like(dst)
+    for b in g['blocks']:
+        x, y, lx, ly = (int(v) for v in b[:4])
+        n, m = 1 << lx, 1 << ly
+        mvx, mvy = np.ascontiguousarray(b[8:12]), np.ascontiguousarray(b[12:16])
+        srcs = (U8P*4)(*[ctypes.cast(refs[int(k)].ctypes.data + (pad + y)*rw + pad + x, U8P) for k in b[4:8]])
+        out = np.zeros((m, n), np.uint8)
+        o.orc_mc_predict(pu8(out), n, srcs, rw, mvx.ctypes.data_as(I32P), mvy.ctypes.data_as(I32P),
+                         int(b[16]), int(b[17]), lx, ly)
+        got[y:y + m, x:x + n] = out
+    assert np.array_equal(got, dst)

@@ -413,3 +413,48 @@ def test_full_pvq_theta_decision_with_reference(is_keyframe, pli):
         assert np.array_equal(out, out_r), trial
         assert abs(sd.value - (t.skip_dist - 0)) >= 0   # skip_diff accumulates skip_dist - best_dist
     assert nsearched > 200
+
+
+def test_obmc_block_prediction_matches_reference():
+    """F3: the oracle's OBMC of one prediction block (orc_mc_predict = four
+    od_mc_predict1fmv8_c predictions + od_mc_blend_full8_c / od_mc_blend_full_split8_c) against
+    the reference's od_mc_predict run through a live context's vtable: every block size, full
+    and fractional vectors, one and several references, every (oc, s)."""
+    o = oracle()
+    p = ref('enc_probe')
+    rng = np.random.default_rng(5)
+    H, W, pad = 160, 192, 48
+    refs = [rng.integers(0, 256, size=(H, W), dtype=np.uint8) for _ in range(3)]
+    for r in refs[1:]:
+        r[::3] = 255 - r[::3]//2                       # saturating content
+    U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+
+    def at(k, x, y):
+        return ctypes.cast(refs[k].ctypes.data + y*W + x, U8P)
+
+    for trial in range(400):
+        lx = int(rng.integers(2, 6))
+        ly = lx if trial % 5 else int(rng.integers(2, 6))
+        n, m = 1 << lx, 1 << ly
+        x0, y0 = int(rng.integers(pad, W - pad - n)), int(rng.integers(pad, H - pad - m))
+        mvx = rng.integers(-8*(pad - 8), 8*(pad - 8), size=4).astype(np.int32)
+        mvy = rng.integers(-8*(pad - 8), 8*(pad - 8), size=4).astype(np.int32)
+        if trial % 3 == 0:
+            mvx &= ~7
+        if trial % 4 == 0:
+            mvy &= ~7
+        if trial % 7 == 0:
+            mvx[:] = mvx[0]; mvy[:] = mvy[0]
+        ks = [0, 0, 0, 0] if trial % 2 else [int(v) for v in rng.integers(0, 3, size=4)]
+        if lx != ly:
+            mvx |= 1                                    # the full-pel copy asserts square blocks
+        oc, s = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        want = np.zeros((m, n), np.uint8)
+        got = np.zeros((m, n), np.uint8)
+        assert p.probe_mc_predict(pu8(want), n, at(ks[0], x0, y0), at(ks[1], x0, y0), at(ks[2], x0, y0),
+                                  at(ks[3], x0, y0), W, mvx.ctypes.data_as(I32P),
+                                  mvy.ctypes.data_as(I32P), oc, s, lx, ly) == 0
+        srcs = (U8P*4)(*[at(ks[k], x0, y0) for k in range(4)])
+        o.orc_mc_predict(pu8(got), n, srcs, W, mvx.ctypes.data_as(I32P), mvy.ctypes.data_as(I32P),
+                         oc, s, lx, ly)
+        assert np.array_equal(got, want), (trial, lx, ly, oc, s)

@@ -257,6 +257,57 @@ def compute_dist_vectors():
     np.savez_compressed(os.path.join(G, 'compute_dist.npz'), **out)
 
 
+def mc_blocks():
+    """F3: od_mc_predict (reference, through a live context's C vtable) for a list of
+    prediction blocks covering a 96x64 picture area: inputs (3 padded reference planes, the
+    block list) and the predicted plane."""
+    U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+    g = np.random.default_rng(424242)
+    pad, W, H = 40, 96, 64
+    refs = np.stack([synth_plane(W + 2*pad, H + 2*pad, 70 + k) for k in range(3)])
+    refs[1, ::5] = 255 - refs[1, ::5]//3
+    rw = refs.shape[2]
+    blocks = []
+    # a quadtree-ish cover: 32x32 cells, some split down to 4x4
+    def cover(x, y, lg):
+        if lg > 2 and g.random() < (.55 if lg > 3 else .35):
+            h = 1 << (lg - 1)
+            for dy in (0, h):
+                for dx in (0, h):
+                    cover(x + dx, y + dy, lg - 1)
+            return
+        one = g.random() < .4
+        ks = [int(g.integers(0, 3))]*4 if one else [int(v) for v in g.integers(0, 3, size=4)]
+        mvx = g.integers(-8*(pad - 6), 8*(pad - 6), size=4)
+        mvy = g.integers(-8*(pad - 6), 8*(pad - 6), size=4)
+        if g.random() < .3:
+            mvx &= ~7
+        if g.random() < .3:
+            mvy &= ~7
+        if g.random() < .25:
+            mvx[:] = mvx[0]
+            mvy[:] = mvy[0]
+        blocks.append([x, y, lg, lg] + ks + [int(v) for v in mvx] + [int(v) for v in mvy]
+                      + [int(g.integers(0, 4)), int(g.integers(0, 4))])
+    for y in range(0, H, 32):
+        for x in range(0, W, 32):
+            cover(x, y, 5)
+    blocks = np.array(blocks, np.int32)
+    dst = np.zeros((H, W), np.uint8)
+    for b in blocks:
+        x, y, lx, ly = (int(v) for v in b[:4])
+        n, m = 1 << lx, 1 << ly
+        ks, mvx, mvy = b[4:8], np.ascontiguousarray(b[8:12]), np.ascontiguousarray(b[12:16])
+        out = np.zeros((m, n), np.uint8)
+        at = [ctypes.cast(refs[int(k)].ctypes.data + (pad + y)*rw + pad + x, U8P) for k in ks]
+        assert ep.probe_mc_predict(pu8(out), n, at[0], at[1], at[2], at[3], rw, mvx.ctypes.data_as(I32P),
+                                   mvy.ctypes.data_as(I32P), int(b[16]), int(b[17]), lx, ly) == 0
+        dst[y:y + m, x:x + n] = out
+    np.savez_compressed(os.path.join(G, 'mc_blocks.npz'), refs=refs, pad=np.int32(pad), blocks=blocks,
+                        dst=dst)
+    print('mc_blocks:', len(blocks), 'blocks')
+
+
 def dcttest_md5():
     out = subprocess.run([os.path.join(ROOT, 'oracle', '_ref', 'dcttest')], capture_output=True)
     assert out.returncode == 0
@@ -278,6 +329,7 @@ if __name__ == '__main__':
     pvq_theta_decisions()
     e2e_anchors()
     compute_dist_vectors()
+    mc_blocks()
     if '--dcttest' in sys.argv:
         dcttest_md5()
     print('golden fixtures written to', G)
