@@ -228,6 +228,13 @@ def decode(prm, hdr, packets, use_device=0, device=0):
     return decode_blob(prm, hdr, join_packets(packets), len(packets), use_device, device)
 
 
+def mc_stats():
+    """(inter frames predicted on the device, check-mode mismatches) of the last decode."""
+    out = (ctypes.c_long*2)()
+    hipenc().od_hipdec_mc_stats(out)
+    return int(out[0]), int(out[1])
+
+
 def decode_blob(prm, hdr, buf, nframes, use_device=0, device=0):
     """The same on a length-prefixed packet blob as od_hipenc_encode_frames writes it."""
     lib = hipenc()

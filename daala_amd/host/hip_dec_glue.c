@@ -44,7 +44,10 @@ void od_smooth_recursive_cpu(od_coeff *c, unsigned char *bsize, int bstride, int
  int by, int bsi, int w, int xdec, int ydec, int min_bs, int quantizer, int pli);
 void od_coeff_to_ref_plane_cpu(od_state *state, od_img *dst, int pli, od_coeff *src,
  int lossless_p);
+void od_state_mc_predict_cpu(od_state *state, od_img *img_dst);
 /* hip_enc_glue.c */
+int od_hipenc_device_thread(void);
+int od_hipenc_check_mode(void);
 int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
  int xstride, int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
  int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
@@ -65,6 +68,7 @@ typedef struct dec_tls {
   od_coeff *stage[3];       /* page-locked staging copies of the coefficient planes */
   long idct_skipped;
   int failed;
+  int check;
   double t_device;
 } dec_tls;
 
@@ -264,6 +268,7 @@ static void *dworker(void *arg) {
    hook_idct32};
   J = (djob *)arg;
   memset(&D, 0, sizeof(D));
+  D.check = J->p->check;
   dec = make_decoder(J);
   st = dec != NULL ? &((od_dec_ctx *)dec)->state : NULL;
   if (dec != NULL && J->use_device) {
@@ -353,6 +358,9 @@ static void *dworker(void *arg) {
     if (rc < 0) J->failed = 1;
   }
   J->t_device += D.t_device;
+  g_mc_dev_frames += mc_dev_frames;
+  g_mc_check_fail += mc_check_fail;
+  mc_dev_frames = mc_check_fail = 0;
   {
     double t;
     t = now_s();
@@ -370,6 +378,192 @@ static void *dworker(void *arg) {
   return NULL;
 }
 
+/* ------------------------------------------------------------------------ */
+/* od_state_mc_predict (src/state.c:993): the motion-compensated prediction of a whole
+   inter frame.  It is a pure function of the motion vector grid and the reference frames,
+   both final when the decoder (src/decode.c:1248) or the encoder (src/encode.c:2219) asks
+   for it, so every leaf of the grid's quadtree (od_state_pred_block, :735-786) becomes one
+   entry of a block list and od_hip_mc_predict_blocks predicts each plane in one launch. */
+typedef struct mc_list {
+  od_hip_mc_block *b;
+  int n;
+  int cap;
+} mc_list;
+
+static int mc_push(mc_list *L, const od_hip_mc_block *m) {
+  if (L->n == L->cap) {
+    od_hip_mc_block *q;
+    L->cap = L->cap ? 2*L->cap : 1024;
+    q = (od_hip_mc_block *)realloc(L->b, sizeof(*q)*L->cap);
+    if (q == NULL) return -1;
+    L->b = q;
+  }
+  L->b[L->n++] = *m;
+  return 0;
+}
+
+/* od_state_pred_block + od_state_pred_block_from_setup (src/state.c:689-786), the leaf
+   recorded instead of predicted */
+static int mc_collect(od_state *state, mc_list *L, int pli, int xdec, int ydec, int vx,
+ int vy, int log_mvb_sz) {
+  int half;
+  half = 1 << log_mvb_sz >> 1;
+  if (log_mvb_sz > 0 && state->mv_grid[vy + half][vx + half].valid) {
+    if (mc_collect(state, L, pli, xdec, ydec, vx, vy, log_mvb_sz - 1)) return -1;
+    if (mc_collect(state, L, pli, xdec, ydec, vx + half, vy, log_mvb_sz - 1)) return -1;
+    if (mc_collect(state, L, pli, xdec, ydec, vx, vy + half, log_mvb_sz - 1)) return -1;
+    return mc_collect(state, L, pli, xdec, ydec, vx + half, vy + half, log_mvb_sz - 1);
+  }
+  else {
+    od_hip_mc_block m;
+    const int *dxp;
+    const int *dyp;
+    int oc;
+    int sp;
+    int k;
+    if (log_mvb_sz < OD_LOG_MVB_DELTA0) {
+      int mask;
+      mask = (1 << (log_mvb_sz + 1)) - 1;
+      oc = !!(vx & mask);
+      if (vy & mask) oc = 3 - oc;
+      sp = state->mv_grid[vy + (OD_VERT_DY[(oc + 1) & 3] << log_mvb_sz)]
+       [vx + (OD_VERT_DX[(oc + 1) & 3] << log_mvb_sz)].valid
+       | state->mv_grid[vy + (OD_VERT_DY[(oc + 3) & 3] << log_mvb_sz)]
+       [vx + (OD_VERT_DX[(oc + 3) & 3] << log_mvb_sz)].valid << 1;
+    }
+    else {
+      oc = 0;
+      sp = 3;
+    }
+    dxp = OD_VERT_SETUP_DX[oc][sp];
+    dyp = OD_VERT_SETUP_DY[oc][sp];
+    memset(&m, 0, sizeof(m));
+    m.x = vx << (OD_LOG_MVBSIZE_MIN - xdec);
+    m.y = vy << (OD_LOG_MVBSIZE_MIN - ydec);
+    m.log_xblk_sz = log_mvb_sz + OD_LOG_MVBSIZE_MIN - xdec;
+    m.log_yblk_sz = log_mvb_sz + OD_LOG_MVBSIZE_MIN - ydec;
+    m.oc = oc;
+    m.s = sp;
+    for (k = 0; k < 4; k++) {
+      const od_mv_grid_pt *g;
+      int mvx;
+      int mvy;
+      g = state->mv_grid[vy + dyp[k]*(1 << log_mvb_sz)] + vx + dxp[k]*(1 << log_mvb_sz);
+      if (g->ref == OD_FRAME_NEXT) {
+        mvx = g->mv1[0];
+        mvy = g->mv1[1];
+      }
+      else {
+        mvx = g->mv[0];
+        mvy = g->mv[1];
+      }
+      m.mvx[k] = (int32_t)OD_DIV_POW2_RE(mvx, xdec);
+      m.mvy[k] = (int32_t)OD_DIV_POW2_RE(mvy, ydec);
+      m.ref[k] = state->ref_imgi[g->ref];        /* index into state->ref_imgs */
+      if (m.ref[k] < 0 || m.ref[k] > OD_FRAME_MAX) return -1;
+    }
+    return mc_push(L, &m);
+  }
+}
+
+static int mc_predict_device(od_state *state, od_img *img_dst) {
+  mc_list L;
+  int pli;
+  int rc;
+  rc = 0;
+  memset(&L, 0, sizeof(L));
+  if (state->full_precision_references) return -1;
+  for (pli = 0; pli < img_dst->nplanes && rc == 0; pli++) {
+    const unsigned char *refs[OD_FRAME_MAX + 1];
+    od_img_plane *dp;
+    int xdec;
+    int ydec;
+    int px;
+    int py;
+    int stride;
+    int rh;
+    int vx;
+    int vy;
+    int k;
+    dp = img_dst->planes + pli;
+    xdec = dp->xdec;
+    ydec = dp->ydec;
+    if (dp->xstride != 1) {
+      rc = -1;
+      break;
+    }
+    /* the reference frames' plane buffers (od_state_ref_imgs_init, src/state.c:236-300):
+       OD_BUFFER_PADDING >> dec samples of padding on every side of the frame */
+    px = OD_BUFFER_PADDING >> xdec;
+    py = OD_BUFFER_PADDING >> ydec;
+    stride = state->ref_imgs[0].planes[pli].ystride;
+    rh = (state->frame_height + 2*OD_BUFFER_PADDING) >> ydec;
+    for (k = 0; k <= OD_FRAME_MAX; k++) {
+      refs[k] = state->ref_imgs[k].planes[pli].data - (ptrdiff_t)py*stride - px;
+    }
+    L.n = 0;
+    for (vy = 0; vy < state->nvmvbs && rc == 0; vy += OD_MVB_DELTA0) {
+      for (vx = 0; vx < state->nhmvbs && rc == 0; vx += OD_MVB_DELTA0) {
+        rc = mc_collect(state, &L, pli, xdec, ydec, vx, vy, OD_LOG_MVB_DELTA0);
+      }
+    }
+    if (rc == 0) {
+      rc = od_hip_mc_predict_blocks(OD_FRAME_MAX + 1, refs, stride, rh, px, py, L.b, L.n,
+       dp->data, dp->ystride, state->frame_height >> ydec);
+    }
+  }
+  free(L.b);
+  return rc;
+}
+
+static __thread long mc_dev_frames;
+static __thread long mc_check_fail;
+static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
+static long g_mc_check_fail;
+
+void od_hipdec_mc_stats(long out[2]) {
+  out[0] = g_mc_dev_frames;
+  out[1] = g_mc_check_fail;
+}
+
+void od_state_mc_predict(od_state *state, od_img *img_dst) {
+  if ((D.ctx != NULL || od_hipenc_device_thread()) && !D.failed) {
+    if (mc_predict_device(state, img_dst) == 0) {
+      mc_dev_frames++;
+      if (D.check || od_hipenc_check_mode()) {
+        /* OD_CHECKASM: the reference's own prediction of the same frame; its result stays */
+        unsigned char *keep[3];
+        int pli;
+        for (pli = 0; pli < img_dst->nplanes && pli < 3; pli++) {
+          od_img_plane *dp;
+          size_t bytes;
+          dp = img_dst->planes + pli;
+          bytes = (size_t)dp->ystride*(state->frame_height >> dp->ydec);
+          keep[pli] = (unsigned char *)malloc(bytes);
+          if (keep[pli] != NULL) memcpy(keep[pli], dp->data, bytes);
+        }
+        od_state_mc_predict_cpu(state, img_dst);
+        for (pli = 0; pli < img_dst->nplanes && pli < 3; pli++) {
+          od_img_plane *dp;
+          int y;
+          dp = img_dst->planes + pli;
+          for (y = 0; keep[pli] != NULL && y < state->frame_height >> dp->ydec; y++) {
+            if (memcmp(keep[pli] + (size_t)y*dp->ystride, dp->data + (size_t)y*dp->ystride,
+             state->frame_width >> dp->xdec) != 0) {
+              mc_check_fail++;
+              break;
+            }
+          }
+          free(keep[pli]);
+        }
+      }
+      return;
+    }
+    D.failed = 1;          /* reported by the driver: no silent C path */
+  }
+  od_state_mc_predict_cpu(state, img_dst);
+}
+
 long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr,
  long hdr_bytes, int nframes, const unsigned char *pkts, long pkt_bytes,
  int use_device, int device, unsigned char *frames_out, double *seconds,
@@ -383,6 +577,7 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
     return OD_HIP_EFAULT;
   }
   if (use_device && od_hip_device_count() <= device) return OD_HIP_ENODEV;
+  g_mc_dev_frames = g_mc_check_fail = 0;
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;

@@ -65,6 +65,16 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
   return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
 }
 
+/* for the bindings in hip_dec_glue.c that serve encoder threads too (od_dering,
+   od_state_mc_predict): is this thread a worker of a device session / in check mode */
+int od_hipenc_device_thread(void) {
+  return T.dr != NULL;
+}
+
+int od_hipenc_check_mode(void) {
+  return T.check;
+}
+
 /* od_dering (src/filter.c:1835) as the encoder's filter on/off loop calls it
    (src/encode.c:2597, :2662), superblock by superblock and plane by plane: the first
    call of a frame runs od_hip_dering_run once on the three unfiltered planes

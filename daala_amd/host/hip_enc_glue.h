@@ -103,6 +103,11 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
  int use_device, int device, unsigned char *frames_out, double *seconds,
  double *device_seconds);
 
+/* After od_hipdec_decode_frames: out[0] = inter frames whose motion-compensated prediction
+ * (od_state_mc_predict, src/state.c:993) came from the device, out[1] = check-mode mismatches
+ * against the reference's own prediction (must be 0). */
+void od_hipdec_mc_stats(long out[2]);
+
 #ifdef __cplusplus
 }
 #endif

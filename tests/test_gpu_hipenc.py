@@ -213,3 +213,23 @@ def test_hip_encoder_stress_content(kind, quant, masking):
     nd0, pics0, _, _ = H.decode(prm, hdr, got, use_device=0)
     nd1, pics1, _, _ = H.decode(prm, hdr, got, use_device=1)
     assert nd0 == nf and nd1 == nf and np.array_equal(pics0, pics1)
+
+
+def test_inter_stream_motion_compensation_on_the_device():
+    """configs[3], first live step: an inter stream from the pure reference encoder decoded by
+    one worker with the device - keyframes through od_hip_decode_tail, every P frame's
+    od_state_mc_predict (OBMC of the whole frame) through od_hip_mc_predict_blocks, in check
+    mode (the reference's own prediction is computed beside it and compared).  Pictures must
+    equal the plain reference decode, the last one the encoder's reconstruction."""
+    from test_hipenc_cpu import inter_stream
+    w, h, nf = 352, 288, 6
+    pk, rec = inter_stream(w, h, nf, keyrate=4)
+    prm = H.Params(w, h, 20, 7, 1, 1, 1, 0)
+    hdr = H.headers(prm)
+    n0, want, _, _ = H.decode(prm, hdr, pk)
+    nd, got, sec, dsec = H.decode(prm, hdr, pk, use_device=1)
+    assert n0 == nf and nd == nf
+    frames, bad = H.mc_stats()
+    assert frames == 4 and bad == 0          # frames 1, 2, 3 and 5 are P frames
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[-1], rec)

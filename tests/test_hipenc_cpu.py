@@ -245,3 +245,35 @@ def test_host_codeword_search_equals_reference_search():
             cb = lib.od_ref_pvq_search_rdo_double_cpu(x.ctypes.data_as(F64P), n, k,
                                                       yb.ctypes.data_as(I32P), g2)
             assert np.array_equal(ya, yb) and ca == cb, (n, trial, k)
+
+
+def inter_stream(w, h, nf, keyrate=4):
+    """A short inter stream (keyframe every `keyrate` frames) from the pure reference encoder,
+    of content that moves between frames, plus the encoder's reconstruction of the last frame."""
+    base = [synth_plane(w + 64, h + 64, 31), synth_plane(w//2 + 32, h//2 + 32, 32, 1),
+            synth_plane(w//2 + 32, h//2 + 32, 33, 1)]
+    frames = [[base[0][2*f:2*f + h, 3*f:3*f + w], base[1][f:f + h//2, (3*f)//2:(3*f)//2 + w//2],
+               base[2][f:f + h//2, (3*f)//2:(3*f)//2 + w//2]] for f in range(nf)]
+    buf = H.pack_frames(frames, w, h)
+    lib = ref('enc_probe')
+    lib.probe_encode_frames_vtbl.restype = ctypes.c_long
+    out = np.zeros(1 << 22, np.uint8)
+    rec = np.zeros(w*h*3//2, np.uint8)
+    fnv, s = ctypes.c_uint(), ctypes.c_double()
+    n = lib.probe_encode_frames_vtbl(w, h, nf, 20, 7, 1, keyrate, pu8(buf), ctypes.byref(fnv),
+                                     ctypes.byref(s), pu8(out), out.size, None, None, pu8(rec))
+    assert n > 0
+    return H.split_packets(out, nf), rec
+
+
+def test_inter_stream_through_the_decoder_driver_host_path():
+    """configs[3] plumbing: an inter stream (P frames: od_dec_mv_unpack + od_state_mc_predict +
+    residual) decoded sequentially by one worker of od_hipdec_decode_frames; without a device
+    every bound entry point (od_state_mc_predict among them) forwards to the reference's code,
+    and the last picture equals the encoder's own reconstruction (OD_ENCODER_CHECK's invariant)."""
+    w, h, nf = 96, 64, 5
+    pk, rec = inter_stream(w, h, nf)
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
+    nd, out, sec, dsec = H.decode(prm, H.headers(prm), pk)
+    assert nd == nf
+    assert np.array_equal(out[-1], rec)
