@@ -74,6 +74,16 @@ typedef struct dec_tls {
 
 static __thread dec_tls D;
 
+static __thread long mc_dev_frames;
+static __thread long mc_check_fail;
+static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
+static long g_mc_check_fail;
+
+void od_hipdec_mc_stats(long out[2]) {
+  out[0] = g_mc_dev_frames;
+  out[1] = g_mc_check_fail;
+}
+
 /* Device decode applies to DCT keyframes only (what the stage was verified for):
    frame type and quantizers are known before the first block is parsed
    (src/decode.c:1195, :989-993). */
@@ -516,15 +526,7 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
   return rc;
 }
 
-static __thread long mc_dev_frames;
-static __thread long mc_check_fail;
-static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
-static long g_mc_check_fail;
 
-void od_hipdec_mc_stats(long out[2]) {
-  out[0] = g_mc_dev_frames;
-  out[1] = g_mc_check_fail;
-}
 
 void od_state_mc_predict(od_state *state, od_img *img_dst) {
   if ((D.ctx != NULL || od_hipenc_device_thread()) && !D.failed) {
