@@ -334,7 +334,7 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
   // operand shapes are checked on the host before anything is launched
   for (int b = 0; b < nblocks; b++) {
     const od_hip_mc_block &m = blocks[b];
-    if (m.log_xblk_sz < 2 || m.log_xblk_sz > 5 || m.log_yblk_sz < 2 || m.log_yblk_sz > 5 || m.x < 0 || m.y < 0
+    if (m.log_xblk_sz < 2 || m.log_xblk_sz > 6 || m.log_yblk_sz < 2 || m.log_yblk_sz > 6 || m.x < 0 || m.y < 0
         || m.x + (1 << m.log_xblk_sz) > dst_stride || m.y + (1 << m.log_yblk_sz) > dst_h
         || m.oc < 0 || m.oc > 3 || m.s < 0 || m.s > 3)
       return fail(OD_HIP_EINVAL, "bad prediction block");
@@ -362,7 +362,7 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
   a.nblocks = nblocks;
   a.dst = (uint8_t *)g_out.p;
   a.dst_stride = dst_stride;
-  hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(64), 0, 0, a);
+  hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(MC_THREADS), 0, 0, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(dst, g_out.p, dbytes, hipMemcpyDeviceToHost));
   return 0;

@@ -7,7 +7,7 @@
 // edge of the block is not split).  The leaf list is a pure function of the decoded motion
 // vector grid and the reference frames, so the whole prediction of a frame is one launch.
 //
-// One wave per block (blocks are 4x4 .. 32x32).  Per corner: horizontal pass of the
+// One workgroup of two waves per block (blocks are 4x4 .. 64x64: OD_MVBSIZE_MAX, src/internal.h:64).  Per corner: horizontal pass of the
 // (yblk + 5) rows into an int16 LDS tile, vertical pass into a u8 LDS tile; corners that
 // share reference and vector with an earlier corner reuse its tile (the reference's own
 // shortcut, src/mc.c:1979-1999).  Then one blending pass writes the block.  All integer.
@@ -38,9 +38,10 @@ __constant__ int16_t MC_SUBPEL[8][6] = {     // OD_SUBPEL_FILTER_SET (src/mc.c:6
   {3, -18, 97, 58, -15, 3}, {4, -20, 80, 80, -20, 4}, {3, -15, 58, 97, -18, 3},
   {2, -11, 37, 112, -15, 3}, {1, -5, 18, 122, -9, 1}};
 
-__global__ __launch_bounds__(64) void k_mc_predict_blocks(McArgs a) {
-  __shared__ int16_t buff[(32 + 5)*32];
-  __shared__ uint8_t pred[4][32*32];
+#define MC_THREADS 128
+__global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
+  __shared__ int16_t buff[(64 + 5)*64];
+  __shared__ uint8_t pred[4][64*64];
   const int lane = threadIdx.x;
   const int bidx = blockIdx.x;
   if (bidx >= a.nblocks) return;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64) void k_mc_predict_blocks(McArgs a) {
     if (mvxf || mvyf) {
       // 1st stage: rows -2 .. yblk + 2 (src/mc.c:145-172)
       const int nrow = yblk + 5;
-      for (int e = lane; e < nrow*xblk; e += 64) {
+      for (int e = lane; e < nrow*xblk; e += MC_THREADS) {
         const int j = (e >> lx) - 2, i = e & (xblk - 1);
         int v;
         if (mvxf) {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64) void k_mc_predict_blocks(McArgs a) {
       }
       __syncthreads();
       // 2nd stage (src/mc.c:174-198)
-      for (int e = lane; e < npix; e += 64) {
+      for (int e = lane; e < npix; e += MC_THREADS) {
         const int j = e >> lx, i = e & (xblk - 1);
         int v;
         if (mvyf) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64) void k_mc_predict_blocks(McArgs a) {
       __syncthreads();
     }
     else {
-      for (int e = lane; e < npix; e += 64) pred[k][e] = (uint8_t)px(sy0 + (e >> lx), sx0 + (e & (xblk - 1)));
+      for (int e = lane; e < npix; e += MC_THREADS) pred[k][e] = (uint8_t)px(sy0 + (e >> lx), sx0 + (e & (xblk - 1)));
       __syncthreads();
     }
   }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64) void k_mc_predict_blocks(McArgs a) {
   if (blk.s == 3) {
     // od_mc_blend_full8_c
     const int round = 1 << (l2 - 1);
-    for (int e = lane; e < npix; e += 64) {
+    for (int e = lane; e < npix; e += MC_THREADS) {
       const int j = e >> lx, i = e & (xblk - 1);
       int av = p0[e], bv = p3[e];
       av = (av << lx) + (p1[e] - av)*i;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void k_mc_predict_blocks(McArgs a) {
       }
     }
     const int round = 1 << l2;
-    for (int e = lane; e < npix; e += 64) {
+    for (int e = lane; e < npix; e += MC_THREADS) {
       const int j = e >> lx, i = e & (xblk - 1);
       const int w1 = s0[1] + j*dsdj[1] + i*(dsdi[1] + j*dd[1]);
       const int w2 = s0[2] + j*dsdj[2] + i*(dsdi[2] + j*dd[2]);

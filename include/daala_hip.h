@@ -363,7 +363,7 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
  * od_mc_blend_full_split8_c (:1104).  8-bit references.
  *   refs[k]: reference plane k, ref_h rows of ref_stride bytes, the picture's (0, 0) at
  *            (org_x, org_y) - the reference keeps OD_UMV padding around its frames;
- *   block:   (x, y) in the picture, 2^log_xblk_sz x 2^log_yblk_sz samples (4..32), corner k
+ *   block:   (x, y) in the picture, 2^log_xblk_sz x 2^log_yblk_sz samples (4..64), corner k
  *            reads reference ref[k] with vector (mvx[k], mvy[k]) in 1/8 sample of THIS plane
  *            (the host applies OD_DIV_POW2_RE for chroma, :719-720); oc, s as the reference;
  *   dst:     in/out plane, dst_h rows of dst_stride bytes; only the blocks are written. */

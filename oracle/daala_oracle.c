@@ -1352,7 +1352,7 @@ void orc_mc_predict1fmv8(uint8_t *dst, const uint8_t *src, int systride, int32_t
   int xblk = 1 << log_xblk_sz, yblk = 1 << log_yblk_sz, i, j, k;
   int mvxf = mvx & 7, mvyf = mvy & 7;
   const int16_t *fx = ORC_SUBPEL[mvxf], *fy = ORC_SUBPEL[mvyf];
-  int16_t buff[(32 + 5)*32];
+  int16_t buff[(64 + 5)*64];
   const uint8_t *sp = src + (mvx >> 3) + (mvy >> 3)*systride;
   if (mvxf || mvyf) {
     int16_t *bp = buff;
@@ -1445,7 +1445,7 @@ void orc_mc_blend_full_split8(uint8_t *dst, int dystride, const uint8_t *const s
 void orc_mc_predict(uint8_t *dst, int dystride, const uint8_t *const src[4], int systride,
  const int32_t mvx[4], const int32_t mvy[4], int oc, int s, int log_xblk_sz,
  int log_yblk_sz) {
-  uint8_t pred[4][32*32];
+  static __thread uint8_t pred[4][64*64];
   const uint8_t *p[4];
   int k;
   for (k = 0; k < 4; k++) {

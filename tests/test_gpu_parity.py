@@ -580,14 +580,14 @@ def test_obmc_prediction_blocks(hip):
     # random (also non-square) blocks vs the oracle
     o = oracle()
     rng = np.random.default_rng(9)
-    H, W, P = 96, 128, 40
+    H, W, P = 128, 192, 40
     rr = [rng.integers(0, 256, size=(H + 2*P, W + 2*P), dtype=np.uint8) for _ in range(2)]
     rw = W + 2*P
     U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
     bl, want = [], np.zeros((H, W), np.uint8)
-    for y in range(0, H, 32):
-        for x in range(0, W, 32):
-            lx, ly = int(rng.integers(2, 6)), int(rng.integers(2, 6))
+    for y in range(0, H, 64):
+        for x in range(0, W, 64):
+            lx, ly = int(rng.integers(2, 7)), int(rng.integers(2, 7))
             mvx = rng.integers(-8*(P - 6), 8*(P - 6), size=4).astype(np.int32) | 1
             mvy = rng.integers(-8*(P - 6), 8*(P - 6), size=4).astype(np.int32)
             ks = rng.integers(0, 2, size=4)

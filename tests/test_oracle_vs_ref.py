@@ -423,7 +423,7 @@ def test_obmc_block_prediction_matches_reference():
     o = oracle()
     p = ref('enc_probe')
     rng = np.random.default_rng(5)
-    H, W, pad = 160, 192, 48
+    H, W, pad = 224, 256, 48
     refs = [rng.integers(0, 256, size=(H, W), dtype=np.uint8) for _ in range(3)]
     for r in refs[1:]:
         r[::3] = 255 - r[::3]//2                       # saturating content
@@ -433,8 +433,8 @@ def test_obmc_block_prediction_matches_reference():
         return ctypes.cast(refs[k].ctypes.data + y*W + x, U8P)
 
     for trial in range(400):
-        lx = int(rng.integers(2, 6))
-        ly = lx if trial % 5 else int(rng.integers(2, 6))
+        lx = int(rng.integers(2, 7))
+        ly = lx if trial % 5 else int(rng.integers(2, 7))
         n, m = 1 << lx, 1 << ly
         x0, y0 = int(rng.integers(pad, W - pad - n)), int(rng.integers(pad, H - pad - m))
         mvx = rng.integers(-8*(pad - 8), 8*(pad - 8), size=4).astype(np.int32)
