@@ -116,6 +116,25 @@ KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel nam
 }
 
 
+def measured_pmc(names):
+    """SQ counter figures of the PVQ search kernels from the newest committed PMC profile
+    (profiles/*_pmc.json, tools/pmc_round.sh + tools/summarize_pmc.py): VALU instructions per
+    wave, share of wave time with the VALU active / parked, VALU issue utilisation."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        t = json.load(f)['kernels']
+    out = {'source': os.path.basename(files[-1])}
+    for label, sym in names.items():
+        for k, v in t.items():
+            if sym in k:
+                out[label] = {n: round(v[n], 4) for n in ('valu_per_wave', 'valu_active_of_wave',
+                                                          'parked_of_wave', 'valu_pipe_utilisation') if n in v}
+    return out
+
+
 def measured_traffic(label):
     """HBM bytes per launch of a kernel from the newest committed PMC profile
     (profiles/*_traffic.json: FETCH_SIZE and WRITE_SIZE from separate rocprofv3
@@ -251,7 +270,13 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
                       'bands_per_frame': bands,
                       'ms_per_step': round(tot_ms/steps, 3),
                       'share_of_device_time': round(tot_ms/(tot_ms + other_ms), 4),
-                      'concurrent_side_streams': bool(concurrent)}
+                      'concurrent_side_streams': bool(concurrent),
+                      # FP64-VALU bound, not HBM bound: utilisation from the SQ
+                      # counters of the committed PMC passes (4-cycle wave64 FP64 issue)
+                      'sq_counters': measured_pmc({'k_pvq_noref<128>': 'k_pvq_noref_v3<128, false>',
+                                                   'k_pvq_noref<32>': 'k_pvq_noref_v3<32, false>',
+                                                   'k_pvq_noref<15>': 'k_pvq_noref_v3<15, false>',
+                                                   'k_pvq_noref<8>': 'k_pvq_noref_v3<8, false>'})}
     if world == 1:
         # the decoder's pixel-domain tail on the same 30 frames (iDCT + post-filters +
         # deringing on every superblock + smoothing + clamp)
@@ -350,7 +375,17 @@ def main():
     frames = make_frames(FRAMES, seed0=1 + rank)
     buf = H.pack_frames(frames, PIC_W, PIC_H)
     budget = host_cpu_budget()
-    nw = args.workers if args.workers > 0 else max(1, min(FRAMES, budget//world))
+    # Host workers: one reference encoder context each.  The boxes give a job a CPU-time
+    # quota (cgroup cpu.max, 16 CPUs per GPU) on a machine with many more hardware threads:
+    # one worker per frame of the step keeps every frame moving at once and avoids the
+    # two-rounds-of-16 quantisation of 30 frames (measured +6 %); the CPU time used is
+    # bounded by the quota either way, which is the core count stated in the line.
+    if args.workers > 0:
+        nw = args.workers
+    elif (os.cpu_count() or 1) >= 2*budget:
+        nw = FRAMES
+    else:
+        nw = max(1, min(FRAMES, budget//world))
     prm = H.Params(PIC_W, PIC_H, 20, 7, 1, nw, 0, FRAMES)
     out = np.zeros(buf.size, np.uint8)
     ses = H.Session(prm, use_device=1, device=local_rank)     # no device -> raises
