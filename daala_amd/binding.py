@@ -150,6 +150,32 @@ def od_haar_blocks(bs, blocks, inverse=False):
     return y
 
 
+def comm_unique_id():
+    """The 128-byte RCCL id rank 0 creates and every rank passes to Comm()."""
+    buf = (ctypes.c_ubyte*128)()
+    _chk(load().od_hip_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm(object):
+    """od_hip_comm: an RCCL communicator over the ranks of a superblock-row sharded frame."""
+
+    def __init__(self, device, world, rank, uid):
+        lib = load()
+        lib.od_hip_comm_create.restype = ctypes.c_void_p
+        lib.od_hip_comm_create.argtypes = [c_int, c_int, c_int, ctypes.c_char_p]
+        lib.od_hip_comm_destroy.argtypes = [ctypes.c_void_p]
+        self.lib = lib
+        self.h = lib.od_hip_comm_create(device, world, rank, uid)
+        if not self.h:
+            raise HipError(lib.od_hip_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.od_hip_comm_destroy(self.h)
+            self.h = None
+
+
 class McBlock(ctypes.Structure):
     """od_hip_mc_block (include/daala_hip.h)."""
     _fields_ = [('x', ctypes.c_int32), ('y', ctypes.c_int32), ('log_xblk_sz', ctypes.c_int32),
@@ -373,6 +399,15 @@ class DaalaHip(object):
     def pvq_search(self, pli, level, qm, q, beta, slot0=0, nslots=None):
         """Device pass 2: candidates, K, codeword searches with the uploaded cg."""
         self._pvq_call(self.lib.od_hip_pvq_search, pli, level, qm, q, beta, slot0, nslots)
+
+    def set_strip(self, sb_row0, sb_row1):
+        """Restrict the forward pyramid and the PVQ passes to superblock rows [r0, r1)."""
+        _chk(self.lib.od_hip_set_strip(self.ctx, sb_row0, sb_row1))
+
+    def gather_strips(self, comm, slot, sb_rows, with_pvq=True):
+        rows = np.ascontiguousarray(sb_rows, dtype=np.int32)
+        self.lib.od_hip_gather_strips.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_int, I32P, c_int]
+        _chk(self.lib.od_hip_gather_strips(self.ctx, comm.h, slot, _p32(rows), int(with_pvq)))
 
     def pvq_nblocks(self, pli, level):
         return _chk(self.lib.od_hip_pvq_nblocks(self.ctx, pli, level))

@@ -167,6 +167,9 @@ struct od_hip_ctx {
   std::map<std::string, std::vector<Span>> spans;
   std::vector<hipEvent_t> pool;
   bool timing = false;
+  // strip window (od_hip_set_strip): superblock rows [strip0, strip1) are computed by the
+  // forward pyramid and the PVQ passes; the whole frame by default
+  int strip0 = 0, strip1 = 0;
 };
 
 namespace {
@@ -237,9 +240,12 @@ int check_slots(od_hip_ctx *ctx, int slot0, int nslots, bool join = true) {
 
 namespace {
 template <int N>
-void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk, int nslots, hipStream_t s,
+void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk_unused, int nslots, hipStream_t s,
                 bool gain_only, const double *rsq) {
   constexpr int BPW = PvqGeom<N>::BPW;
+  const long nblk = a.blk_end - a.blk_first;
+  if (nblk <= 0) return;
+  (void)nblk_unused;
   PvqLevelArgs3 aa;
   aa.a = a;
   aa.rsq = rsq;
@@ -505,6 +511,8 @@ od_hip_ctx *od_hip_ctx_create(int device, const od_hip_geometry *geo) {
   ctx->device = device;
   ctx->nhsb = geo->frame_width/32;
   ctx->nvsb = geo->frame_height/32;
+  ctx->strip0 = 0;
+  ctx->strip1 = ctx->nvsb;
   memset(ctx->pix, 0, sizeof(ctx->pix));
   memset(ctx->lev, 0, sizeof(ctx->lev));
   memset(ctx->d, 0, sizeof(ctx->d));
@@ -685,21 +693,33 @@ static FwdArgs fwd_args(od_hip_ctx *ctx, int p, int slot0, bool known, int keyfr
   a.pic_h = ctx->geo.pic_height;
   a.dec = ctx->geo.xdec[p];
   a.keyframe = keyframe;
+  a.sby0 = 0;
   return a;
+}
+
+int od_hip_set_strip(od_hip_ctx *ctx, int sb_row0, int sb_row1) {
+  if (!ctx) return fail(OD_HIP_EFAULT, "null context");
+  if (sb_row0 < 0 || sb_row1 < sb_row0 || sb_row1 > ctx->nvsb) return fail(OD_HIP_EINVAL, "bad strip");
+  ctx->strip0 = sb_row0;
+  ctx->strip1 = sb_row1;
+  return 0;
 }
 
 int od_hip_forward_pyramid(od_hip_ctx *ctx, int slot0, int nslots) {
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  const int rows = ctx->strip1 - ctx->strip0;
+  if (rows <= 0) return 0;                             // an empty strip (more ranks than SB rows)
   for (int p = 0; p < ctx->geo.nplanes; p++) {
     FwdArgs a = fwd_args(ctx, p, slot0, false, 0);
+    a.sby0 = ctx->strip0;
     if (a.dec == 0) {
       Timed tm(ctx, "k_forward_pyramid_luma");
-      hipLaunchKernelGGL((k_forward_rt<32, 4, false>), dim3((ctx->nhsb + 1)/2, ctx->nvsb, nslots),
+      hipLaunchKernelGGL((k_forward_rt<32, 4, false>), dim3((ctx->nhsb + 1)/2, rows, nslots),
                            dim3(128), 0, ctx->stream, a);
     }
     else {
       Timed tm(ctx, "k_forward_pyramid_chroma");
-      hipLaunchKernelGGL((k_forward_rt<16, 3, false>), dim3((ctx->nhsb + 3)/4, ctx->nvsb, nslots),
+      hipLaunchKernelGGL((k_forward_rt<16, 3, false>), dim3((ctx->nhsb + 3)/4, rows, nslots),
                            dim3(128), 0, ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
@@ -920,6 +940,12 @@ int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, cons
   a.out.qg = o.qg + slot0*2*nrec;
   a.out.k = o.k + slot0*2*nrec;
   a.out.y = o.y + slot0*ny;
+  // the strip's blocks of this level: block rows are superblock rows times 32/n (luma units)
+  {
+    const int per_sb = (32 >> ctx->geo.xdec[pli])/n;
+    a.blk_first = (long)ctx->strip0*per_sb*a.nbx;
+    a.blk_end = (long)ctx->strip1*per_sb*a.nbx;
+  }
   return 0;
 }
 
@@ -995,7 +1021,7 @@ int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, in
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
       const size_t o = (size_t)s*c.nrec + (size_t)b*c.nblk;
-      for (int i = 0; i < c.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
+      for (long i = c.a.blk_first; i < c.a.blk_end; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
     }
   }
   HIPCHK(hipMemcpyAsync(c.a.out.cg, cg.data(), cnt*8, hipMemcpyHostToDevice, ctx->stream));
@@ -1584,3 +1610,4 @@ int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches, double
 }  // extern "C"
 
 #include "enc_feed.hpp"
+#include "comm.hpp"

@@ -172,6 +172,7 @@ struct PvqLevelArgs {
   PvqSoA out;              // frame 0
   size_t rec_fstride;      // nbands*nblk (elements between frames of the record arrays)
   size_t y_fstride;        // 2*nblk*(ncoded-1)
+  long blk_first, blk_end; // blocks [blk_first, blk_end) of the level are processed (a strip of SB rows)
 };
 
 // ===========================================================================
@@ -480,11 +481,11 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
   __shared__ int32_t Org[64];
   const int lane = threadIdx.x;
   const int g = lane%G, inst = lane/G;
-  const long blk0 = (long)blockIdx.x*BPW;
+  const long blk0 = a.blk_first + (long)blockIdx.x*BPW;
   const long blk = blk0 + inst;
   const int band = a.band_list[blockIdx.y], f = blockIdx.z;
   const long nblk = (long)a.nbx*a.nby;
-  const bool live = blk < nblk;
+  const bool live = blk < a.blk_end;
   const int o0 = a.off[band];
   const int q0 = a.q[band];
   const double beta = a.beta[band];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
   }
   else {
     const int32_t *plane = a.lev + (size_t)f*a.lev_fstride;
-    const int nb_here = (int)(nblk - blk0 < BPW ? nblk - blk0 : BPW);
+    const int nb_here = (int)(a.blk_end - blk0 < BPW ? a.blk_end - blk0 : BPW);
     if (lane < nb_here) {                          // block origins: one division per block
       const long bb = blk0 + lane;
       const int bx = bb%a.nbx, by = bb/a.nbx;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     {
       int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) +
                     ((size_t)c*nblk + blk0)*N;
-      const long lim = (nblk - blk0 < BPW ? nblk - blk0 : BPW)*N;
+      const long lim = (a.blk_end - blk0 < BPW ? a.blk_end - blk0 : BPW)*N;
       for (int e = lane; e < lim; e += 64) yo[e] = Yst[e];
     }
     __syncthreads();

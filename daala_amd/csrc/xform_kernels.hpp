@@ -197,6 +197,7 @@ struct FwdArgs {
   int pic_w, pic_h;        // LUMA picture size (quirk, src/encode.c:1318-1320)
   int dec;
   int keyframe;
+  int sby0;                // first superblock row of the launch (a strip of the frame; 0: whole frame)
 };
 
 struct InvArgs {

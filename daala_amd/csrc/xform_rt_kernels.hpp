@@ -152,6 +152,7 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
   int tx, sby, f;
   rt_tile_coords(tx, sby, f);
+  sby += a.sby0;                                       // strip launches cover rows sby0 .. sby0 + gridDim.y
   const int x0 = tx*T::W, y0 = sby*SB;
   const int sbx0 = tx*T::NSB;                          // first superblock of the tile
   const int nsb = min(T::NSB, a.nhsb - sbx0);          // superblocks really present

@@ -355,6 +355,26 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
  const double *gr, const int32_t *noref, const double *g, const double *theta,
  const int16_t *qm, const int16_t *qm_inv, od_coeff *out);
 
+/* ---------------------------------------------------------------------------
+ * Superblock-row sharding of one frame over the GPUs of a node (BASELINE
+ * configs[2]).  One process per GPU, each with the whole input frame in its slot.
+ *   od_hip_set_strip(ctx, r0, r1)   restricts od_hip_forward_pyramid and the PVQ passes
+ *       (od_hip_pvq_gains / _compand_level / _search / _noref_search) to superblock rows
+ *       [r0, r1); the kernels read their lapping halo from the pixels, so a strip needs
+ *       nothing from its neighbours.  (0, nvsb) - the default - is the whole frame.
+ *   od_hip_comm_unique_id / od_hip_comm_create   an RCCL communicator over the ranks (the
+ *       128-byte id travels by whatever the launcher offers, e.g. torch.distributed);
+ *   od_hip_gather_strips   device-to-device gather over xGMI: afterwards every rank's slot
+ *       holds the complete pyramid (and PVQ records), sb_rows[r] .. sb_rows[r + 1] being
+ *       rank r's strip.  The only collective of the path; nothing crosses the host. */
+typedef struct od_hip_comm od_hip_comm;
+int od_hip_set_strip(od_hip_ctx *ctx, int sb_row0, int sb_row1);
+int od_hip_comm_unique_id(unsigned char id[128]);
+od_hip_comm *od_hip_comm_create(int device, int world, int rank, const unsigned char id[128]);
+void od_hip_comm_destroy(od_hip_comm *comm);
+int od_hip_gather_strips(od_hip_ctx *ctx, od_hip_comm *comm, int slot, const int *sb_rows,
+ int with_pvq);
+
 /* F3 (inter frames, first kernel): overlapped block motion compensation of a list of
  * prediction blocks = the leaves od_state_mc_predict (src/state.c:993) visits through
  * od_state_pred_block -> od_state_pred_block_from_setup (:689) -> od_mc_predict

@@ -601,3 +601,46 @@ def test_obmc_prediction_blocks(hip):
             want[y:y + m, x:x + n] = out
     got = hip.od_mc_predict_blocks(rr, P, P, bl, np.zeros((H, W), np.uint8))
     assert np.array_equal(got, want)
+
+
+def test_superblock_row_strips_in_c_equal_the_full_frame(hip):
+    """SURVEY 8e in C: od_hip_set_strip restricts the forward pyramid and the PVQ passes to a
+    strip of superblock rows (the kernels read their lapping halo from the pixels: no halo
+    recomputation); three uneven strips computed one after the other reproduce the full
+    frame bit for bit - planes, gains, candidates, pulses.  od_hip_gather_strips (RCCL,
+    device to device) is exercised with a one-rank communicator."""
+    prm = golden('encoder_params.npz')
+    pic_w, pic_h, fw, fh = 300, 200, 320, 224                    # 7 superblock rows
+    planes = [synth_plane(fw, fh, 21), synth_plane(fw//2, fh//2, 21, 1), synth_plane(fw//2, fh//2, 22, 1)]
+
+    def run(strips):
+        ctx = hip.DaalaHip(pic_w, pic_h, fw, fh, nplanes=3, xdec=(0, 1, 1), nslots=1)
+        ctx.upload_planes(0, planes)
+        for r0, r1 in strips:
+            ctx.set_strip(r0, r1)
+            ctx.forward_pyramid()
+            for pli in (0, 1):
+                for level in range(ctx.nlevels(pli)):
+                    n = (32 >> (pli > 0)) >> level
+                    bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+                    off, q, beta, qm = level_params(prm, 'q20_m1', pli, bs, int(pli > 0))
+                    ctx.pvq_noref_search(pli, level, qm, q, beta)
+        ctx.set_strip(0, fh//32)
+        return ctx
+
+    full = run([(0, 7)])
+    part = run([(0, 3), (3, 4), (4, 7)])
+    comm = hip.Comm(0, 1, 0, hip.comm_unique_id())
+    part.gather_strips(comm, 0, [0, 7])
+    comm.close()
+    for pli in range(3):
+        for level in range(full.nlevels(pli)):
+            assert np.array_equal(full.download_level(0, pli, level), part.download_level(0, pli, level))
+    for pli in (0, 1):
+        for level in range(full.nlevels(pli)):
+            (bf, yf), (bp, yp) = full.pvq_download(0, pli, level), part.pvq_download(0, pli, level)
+            assert np.array_equal(yf, yp)
+            for f in ('cg', 'g', 'cos_dist', 'dist', 'qg', 'k', 'ncand'):
+                assert np.array_equal(bf[f], bp[f]), (pli, level, f)
+    full.close()
+    part.close()
