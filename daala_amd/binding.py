@@ -402,6 +402,7 @@ class DaalaHip(object):
 
     def set_strip(self, sb_row0, sb_row1):
         """Restrict the forward pyramid and the PVQ passes to superblock rows [r0, r1)."""
+        self.lib.od_hip_set_strip.argtypes = [ctypes.c_void_p, c_int, c_int]
         _chk(self.lib.od_hip_set_strip(self.ctx, sb_row0, sb_row1))
 
     def gather_strips(self, comm, slot, sb_rows, with_pvq=True):
