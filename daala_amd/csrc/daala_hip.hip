@@ -1014,17 +1014,32 @@ int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, in
                              const int32_t *q, const double *beta) {
   PvqCall c;
   if (int rc = pvq_prepare(ctx, slot0, nslots, pli, level, nullptr, q, beta, c)) return rc;
-  const size_t cnt = (size_t)nslots*c.nrec;
-  std::vector<double> g(cnt), cg(cnt);
-  HIPCHK(hipMemcpyAsync(g.data(), c.a.out.g, cnt*8, hipMemcpyDeviceToHost, ctx->stream));
+  // only the strip's records travel: [band][blk_first, blk_end) of every slot
+  const long first = c.a.blk_first, count = c.a.blk_end - c.a.blk_first;
+  if (count <= 0) return 0;
+  const size_t per = (size_t)count, tot = (size_t)nslots*c.a.nbands*per;
+  std::vector<double> g(tot), cg(tot);
+  for (int s = 0; s < nslots; s++) {
+    for (int b = 0; b < c.a.nbands; b++) {
+      HIPCHK(hipMemcpyAsync(g.data() + ((size_t)s*c.a.nbands + b)*per,
+                            c.a.out.g + (size_t)s*c.nrec + (size_t)b*c.nblk + first, per*8,
+                            hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
-      const size_t o = (size_t)s*c.nrec + (size_t)b*c.nblk;
-      for (long i = c.a.blk_first; i < c.a.blk_end; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
+      const size_t o = ((size_t)s*c.a.nbands + b)*per;
+      for (size_t i = 0; i < per; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
     }
   }
-  HIPCHK(hipMemcpyAsync(c.a.out.cg, cg.data(), cnt*8, hipMemcpyHostToDevice, ctx->stream));
+  for (int s = 0; s < nslots; s++) {
+    for (int b = 0; b < c.a.nbands; b++) {
+      HIPCHK(hipMemcpyAsync(c.a.out.cg + (size_t)s*c.nrec + (size_t)b*c.nblk + first,
+                            cg.data() + ((size_t)s*c.a.nbands + b)*per, per*8,
+                            hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
