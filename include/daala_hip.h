@@ -12,6 +12,15 @@
  * 0 = success, negative = failure; od_hip_last_error() gives the text.
  * There is NO CPU fallback: without a usable HIP device every compute entry
  * point fails with OD_HIP_ENODEV.
+ *
+ * Threads: the entry points that take HOST pointers for their data (sections 1 and 2, the
+ * od_hip_bin_* drop-ins od_hip_vtbl_fill installs, the *_vectors / *_blocks calls) share
+ * one set of device scratch buffers and the null stream of the calling thread's current
+ * device: they are single-threaded, one call at a time per process.  Context objects
+ * (od_hip_ctx, od_hip_enc_feed, od_hip_dering, od_hip_comm) carry their own device id and
+ * streams; one thread at a time per object, different objects concurrently.  The
+ * exceptions, safe from several threads on one object: od_hip_upload_planes (different
+ * slots), od_hip_enc_feed_compand (different slots), od_hip_enc_feed_view.
  */
 #ifndef DAALA_HIP_H
 #define DAALA_HIP_H

@@ -233,3 +233,23 @@ def test_inter_stream_motion_compensation_on_the_device():
     assert frames == 4 and bad == 0          # frames 1, 2, 3 and 5 are P frames
     assert np.array_equal(got, want)
     assert np.array_equal(got[-1], rec)
+
+
+def test_stream_ordering_regression_many_workers_repeated():
+    """Regression for the round-1 stream-ordering race (a null-stream hipMemset could zero
+    dering flags AFTER the non-blocking context stream had uploaded them: rare +-1 pixels in
+    multi-worker decodes).  Six workers, each with its own context and
+    stream, decode 18 odd-sized frames three times over; every picture of every pass must
+    equal the reference decode - a late memset or copy anywhere shows up as a difference."""
+    w, h, nf = 200, 136, 18
+    buf = H.pack_frames(frames_of(w, h, list(range(40, 40 + nf))), w, h)
+    prm = H.Params(w, h, 12, 7, 1, 6, 0, 0)
+    n, pk, st = H.encode(prm, buf, nf)
+    assert n > 0
+    hdr = H.headers(prm)
+    n0, want, _, _ = H.decode(prm, hdr, pk, use_device=0)
+    assert n0 == nf
+    for rep in range(3):
+        n1, got, _, ds = H.decode(prm, hdr, pk, use_device=1)
+        assert n1 == nf and ds > 0
+        assert np.array_equal(got, want), rep

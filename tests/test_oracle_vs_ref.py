@@ -411,7 +411,8 @@ def test_full_pvq_theta_decision_with_reference(is_keyframe, pli):
         nn = n if itheta == -1 else n - 1
         assert np.array_equal(y[:nn], y_r[:nn]), trial
         assert np.array_equal(out, out_r), trial
-        assert abs(sd.value - (t.skip_dist - 0)) >= 0   # skip_diff accumulates skip_dist - best_dist
+        # skip_diff accumulates skip_dist - best_dist (src/pvq_encoder.c:505), bit for bit
+        assert sd.value == 0. + (t.skip_dist - decide_pvq_theta.best_dist), trial
     assert nsearched > 200
 
 

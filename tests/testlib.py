@@ -234,4 +234,5 @@ def decide_pvq_theta(o, rate_fn, t, y_ref, y_noref, x0, r0, n, q0, beta, is_keyf
         ret = qg if noref else neg_interleave(qg, t.icgr)
     else:
         ret = qg - 1 if noref else neg_interleave(qg + 1, t.icgr + 1)
+    decide_pvq_theta.best_dist = best_dist          # for the skip_diff identity
     return ret, itheta, max_theta, best_k, y, out
