@@ -15,6 +15,8 @@ struct od_hip_enc_feed {
   std::vector<hipEvent_t> gready;         // one per slot: gains landed on the host
   std::vector<hipEvent_t> cgup;           // one per slot: companded gains uploaded
   std::vector<char> companded;            // slot went through od_hip_enc_feed_compand since its gains
+  od_coeff *haar[3] = {nullptr, nullptr, nullptr};   // lossless frames: pinned [slot][h][w] Haar planes (lazy)
+  std::vector<char> lossless;             // slot holds Haar planes, not the PVQ feed
   std::vector<char> pending;              // slot has a copy in flight / landed
   struct Lev {
     int n, bs, nb, nblk, nbx, off[11];
@@ -46,6 +48,7 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
     if (l.cos_dist) (void)hipHostFree(l.cos_dist);
     if (l.plane) (void)hipHostFree(l.plane);
   }
+  for (auto &h : f->haar) if (h) (void)hipHostFree(h);
   for (auto e : f->ready) if (e) (void)hipEventDestroy(e);
   for (auto e : f->gready) if (e) (void)hipEventDestroy(e);
   for (auto e : f->cgup) if (e) (void)hipEventDestroy(e);
@@ -70,6 +73,7 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
   f->gready.assign(ns, nullptr);
   f->cgup.assign(ns, nullptr);
   f->companded.assign(ns, 0);
+  f->lossless.assign(ns, 0);
   for (size_t s = 0; ok && s < ns; s++) {
     ok = hipEventCreateWithFlags(&f->gready[s], hipEventDisableTiming) == hipSuccess
       && hipEventCreateWithFlags(&f->cgup[s], hipEventDisableTiming) == hipSuccess;
@@ -129,6 +133,7 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
     if (f->pending[s]) HIPCHK(hipEventSynchronize(f->ready[s]));
     f->pending[s] = 0;
     f->companded[s] = 0;
+    f->lossless[s] = 0;
   }
   if (int rc = od_hip_forward_pyramid(ctx, slot0, nslots)) return rc;
   // the level planes are final here: their copies overlap everything that follows
@@ -214,6 +219,51 @@ int od_hip_enc_feed_search(od_hip_enc_feed *f, int slot0, int nslots) {
   return 0;
 }
 
+// Lossless frames (quantizer 0): no lapping, no DCT, no PVQ - the encoder
+// transforms every whole superblock with od_haar (src/encode.c:1305, :1129).  One pass
+// (od_hip_forward_haar) produces the three coefficient planes of every slot; they travel to
+// pinned host memory, one completion event per slot.
+int od_hip_enc_feed_run_lossless(od_hip_enc_feed *f, int slot0, int nslots) {
+  if (!f) return fail(OD_HIP_EFAULT, "null feed");
+  od_hip_ctx *ctx = f->ctx;
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  if (ctx->geo.nplanes != 3) return fail(OD_HIP_EINVAL, "lossless feed needs 3 planes");
+  const size_t ns = ctx->geo.nslots;
+  for (int p = 0; p < 3; p++) {
+    if (!f->haar[p]) HIPCHK(hipHostMalloc((void **)&f->haar[p], ns*ctx->psz[p]*sizeof(od_coeff)));
+  }
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    if (f->pending[s]) HIPCHK(hipEventSynchronize(f->ready[s]));
+    f->pending[s] = 0;
+  }
+  if (int rc = od_hip_forward_haar(ctx, slot0, nslots)) return rc;
+  HIPCHK(hipEventRecord(f->computed, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    for (int p = 0; p < 3; p++) {
+      HIPCHK(hipMemcpyAsync(f->haar[p] + (size_t)s*ctx->psz[p], ctx->d[p] + (size_t)s*ctx->psz[p],
+                            ctx->psz[p]*sizeof(od_coeff), hipMemcpyDeviceToHost, f->copy));
+    }
+    HIPCHK(hipEventRecord(f->ready[s], f->copy));
+    f->pending[s] = 1;
+    f->lossless[s] = 1;
+  }
+  return 0;
+}
+
+int od_hip_enc_feed_haar_view(od_hip_enc_feed *f, int slot, const od_coeff *planes[3], int strides[3]) {
+  if (!f || !planes || !strides) return fail(OD_HIP_EFAULT, "null pointer");
+  if (slot < 0 || slot >= f->ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
+  if (!f->pending[slot] || !f->lossless[slot]) return fail(OD_HIP_EINVAL, "no lossless run covers this slot");
+  HIPCHK(hipSetDevice(f->ctx->device));
+  HIPCHK(hipEventSynchronize(f->ready[slot]));
+  for (int p = 0; p < 3; p++) {
+    planes[p] = f->haar[p] + (size_t)slot*f->ctx->psz[p];
+    strides[p] = f->ctx->pw[p];
+  }
+  return 0;
+}
+
 // The three phases back to back on the calling thread.
 int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
   if (int rc = od_hip_enc_feed_gains(f, slot0, nslots)) return rc;
@@ -226,7 +276,7 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
 int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4]) {
   if (!f || !lev) return fail(OD_HIP_EFAULT, "null pointer");
   if (slot < 0 || slot >= f->ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
-  if (!f->pending[slot]) return fail(OD_HIP_EINVAL, "no feed run covers this slot");
+  if (!f->pending[slot] || f->lossless[slot]) return fail(OD_HIP_EINVAL, "no feed run covers this slot");
   HIPCHK(hipSetDevice(f->ctx->device));       // callers are host worker threads
   HIPCHK(hipEventSynchronize(f->ready[slot]));
   for (int l = 0; l < 4; l++) {

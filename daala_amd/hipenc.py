@@ -53,7 +53,8 @@ class Stats(ctypes.Structure):
                 ('lost_sync', ctypes.c_int64), ('check_fail', ctypes.c_int64),
                 ('resampled', ctypes.c_int64), ('pvq_check_fail', ctypes.c_int64),
                 ('search_cpu_s', ctypes.c_double), ('search_class_s', ctypes.c_double*4),
-                ('fdct_hits', ctypes.c_int64), ('fdct_check_fail', ctypes.c_int64),
+                ('fdct_hits', ctypes.c_int64), ('haar_hits', ctypes.c_int64),
+                ('fdct_check_fail', ctypes.c_int64),
                 ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),

@@ -67,6 +67,7 @@ typedef struct dec_tls {
   int pinned[6];            /* rec[0..2], stage[0..2] page-locked */
   od_coeff *stage[3];       /* page-locked staging copies of the coefficient planes */
   long idct_skipped;
+  long haar_skipped;
   int failed;
   int check;
   double t_device;
@@ -90,6 +91,24 @@ void od_hipdec_mc_stats(long out[2]) {
 static int on_device(void) {
   return D.ctx != NULL && D.dec != NULL && D.dec->state.frame_type == OD_I_FRAME
    && D.dec->state.quantizer[0] > 0;
+}
+
+/* Lossless keyframes (quantizer 0: Haar wavelet of every whole superblock instead of
+   lapping + DCT, src/decode.c:785, :1036): od_haar_inv per superblock (:621) and the shift-0
+   od_coeff_to_ref_plane are one od_hip_inverse_haar pass per frame. */
+static int on_device_lossless(void) {
+  return D.ctx != NULL && D.dec != NULL && D.dec->state.frame_type == OD_I_FRAME
+   && D.dec->state.quantizer[0] == 0 && D.dec->state.quantizer[1] == 0
+   && D.dec->state.quantizer[2] == 0 && D.dec->state.info.nplanes == 3;
+}
+
+void od_haar_inv_cpu(od_coeff *x, int xstride, const od_coeff *y, int ystride, int ln);
+void od_haar_inv(od_coeff *x, int xstride, const od_coeff *y, int ystride, int ln) {
+  if (on_device_lossless()) {
+    D.haar_skipped++;
+    return;
+  }
+  od_haar_inv_cpu(x, xstride, y, ystride, ln);
 }
 
 #define IDCT_HOOK(name, bs) \
@@ -173,12 +192,51 @@ static int device_frame(od_state *state) {
   return 0;
 }
 
+static int device_frame_lossless(od_state *state) {
+  int pli;
+  double t0;
+  t0 = now_s();
+  for (pli = 0; pli < 3; pli++) {
+    const od_coeff *src;
+    src = state->dtmp[pli];
+    if (D.stage[pli] != NULL) {
+      memcpy(D.stage[pli], src, sizeof(od_coeff)*(size_t)(state->frame_width >> (pli > 0))
+       *(state->frame_height >> (pli > 0)));
+      src = D.stage[pli];
+    }
+    if (od_hip_upload_coeffs(D.ctx, 0, pli, src) != 0) return -2;
+  }
+  if (od_hip_inverse_haar(D.ctx, 0, 1) != 0) return -4;
+  for (pli = 0; pli < 3; pli++) {
+    if (od_hip_download_recon(D.ctx, 0, pli, D.rec[pli]) != 0) return -5;
+  }
+  D.t_device += now_s() - t0;
+  return 0;
+}
+
 void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
  int lossless_p) {
   od_img_plane *ip;
   int w;
   int h;
   int y;
+  if (lossless_p && on_device_lossless()) {
+    if (pli == 0) {
+      if (D.haar_skipped == 0 || device_frame_lossless(state) != 0) {
+        fprintf(stderr, "hip_dec_glue: device lossless decode failed: %s\n", od_hip_last_error());
+        D.failed = 1;
+        abort();
+      }
+      D.haar_skipped = 0;
+    }
+    ip = dst->planes + pli;
+    w = state->frame_width >> ip->xdec;
+    h = state->frame_height >> ip->ydec;
+    for (y = 0; y < h; y++) {
+      memcpy(ip->data + (size_t)y*ip->ystride, D.rec[pli] + (size_t)y*w, w);
+    }
+    return;
+  }
   if (!on_device() || lossless_p) {
     od_coeff_to_ref_plane_cpu(state, dst, pli, src, lossless_p);
     return;

@@ -240,6 +240,62 @@ void od_encode_rollback(daala_enc_ctx *enc, const od_rollback_buffer *rbuf) {
   else OD_COPY(&enc->state.adapt, &rbuf->adapt, 1);
 }
 
+/* od_haar (src/dct.c:1960) as the encoder calls it for lossless frames (quantizer 0): every
+   whole superblock of ctmp[pli] into dtmp[pli] (od_compute_dcts, src/encode.c:1305; the
+   block-size RDO pass and inter frames also come here, :1129).  With a device the three
+   Haar planes of the frame are already on the host (od_hip_enc_feed_run_lossless): a call
+   that transforms a whole superblock of the current frame into its dtmp position is a
+   block copy.  The build renames the reference's definition to od_haar_cpu. */
+void od_haar_cpu(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln);
+
+void od_haar(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln) {
+  if (T.haar[0] != NULL && T.enc != NULL && T.enc->state.frame_type == OD_I_FRAME) {
+    const od_state *st;
+    int pli;
+    st = &T.enc->state;
+    for (pli = 0; pli < 3; pli++) {
+      const od_coeff *d0;
+      int w;
+      int h;
+      int dec;
+      dec = pli > 0;
+      d0 = st->dtmp[pli];
+      w = st->frame_width >> dec;
+      h = st->frame_height >> dec;
+      if (ystride == w && y >= d0 && y < d0 + (size_t)w*h && ln == 5 - dec
+       && T.haar_stride[pli] == w) {
+        size_t off;
+        int n;
+        int yy;
+        int xx;
+        int i;
+        off = (size_t)(y - d0);
+        yy = (int)(off/w);
+        xx = (int)(off%w);
+        n = 1 << ln;
+        if ((yy & (n - 1)) == 0 && (xx & (n - 1)) == 0) {
+          const od_coeff *src;
+          src = T.haar[pli] + (size_t)yy*w + xx;
+          if (T.check) {
+            od_coeff tmp[32*32];
+            od_haar_cpu(tmp, n, x, xstride, ln);
+            for (i = 0; i < n; i++) {
+              if (memcmp(tmp + i*n, src + (size_t)i*w, sizeof(od_coeff)*n) != 0) {
+                T.st.fdct_check_fail++;
+                break;
+              }
+            }
+          }
+          for (i = 0; i < n; i++) memcpy(y + (size_t)i*ystride, src + (size_t)i*w, sizeof(od_coeff)*n);
+          T.st.haar_hits++;
+          return;
+        }
+      }
+    }
+  }
+  od_haar_cpu(y, ystride, x, xstride, ln);
+}
+
 /* od_pvq_encode as od_block_encode calls it (src/encode.c:1187): keyframes go through
    hip_pvq_host.c (the feed consumer), inter frames through the reference's definition. */
 int od_pvq_encode(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out,
@@ -423,6 +479,7 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->resampled += b->resampled;
   a->search_cpu_s += b->search_cpu_s;
   a->fdct_hits += b->fdct_hits;
+  a->haar_hits += b->haar_hits;
   a->fdct_check_fail += b->fdct_check_fail;
   a->dering_dev_sbs += b->dering_dev_sbs;
   a->dering_check_fail += b->dering_check_fail;
@@ -452,7 +509,11 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   int left;
   od_hip_feed_level lev[4];
   T.lev = NULL;
+  T.haar[0] = T.haar[1] = T.haar[2] = NULL;
   if (J->views != NULL) T.lev = J->views + 4*(size_t)f;
+  else if (S->feed != NULL && S->p.quant == 0) {
+    if (od_hip_enc_feed_haar_view(S->feed, f % J->nslots, T.haar, T.haar_stride) != 0) return -1;
+  }
   else if (S->feed != NULL) {
     if (od_hip_enc_feed_view(S->feed, f % J->nslots, lev) != 0) return -1;
     T.lev = lev;
@@ -486,6 +547,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
     J->pkt_len[f] += 4 + dp.bytes;
   }
   T.lev = NULL;
+  T.haar[0] = T.haar[1] = T.haar[2] = NULL;
   T.enc = NULL;
   return 0;
 }
@@ -804,6 +866,20 @@ long od_hipenc_encode(od_hipenc *S, int nframes, long frame0, const unsigned cha
       /* ~40 launches and event waits: workers coding the previous batch must be able to
          take the lock meanwhile (frames [b0, b0 + batch_n) are not claimable before
          launched_upto moves) */
+      if (S->p.quant == 0) {
+        /* lossless stream: Haar planes instead of the PVQ feed, nothing to compand */
+        pthread_mutex_unlock(&S->mu);
+        rc = od_hip_enc_feed_run_lossless(S->feed, b0 % J.nslots, J.batch_n);
+        pthread_mutex_lock(&S->mu);
+        if (rc != 0) {
+          J.failed = 1;
+          break;
+        }
+        J.st.t_launch_s += now_s() - tb;
+        J.launched_upto = b0 + J.batch_n;
+        pthread_cond_broadcast(&S->cv);
+        continue;
+      }
       pthread_mutex_unlock(&S->mu);
       rc = od_hip_enc_feed_gains(S->feed, b0 % J.nslots, J.batch_n);
       pthread_mutex_lock(&S->mu);

@@ -36,6 +36,7 @@ typedef struct od_hipenc_stats {
   double search_cpu_s;     /* seconds inside the C pvq_search_rdo_double, all workers */
   double search_class_s[4];/* ... split: luma no-ref, luma with-ref, chroma no-ref, chroma with-ref */
   int64_t fdct_hits;       /* luma fdct_2d calls answered from the device pyramid */
+  int64_t haar_hits;       /* lossless frames: od_haar calls (whole superblocks) answered from the device's Haar planes */
   int64_t fdct_check_fail; /* check mode: device block != C transform (must be 0) */
   int64_t dering_dev_sbs;  /* od_dering calls (superblock, plane) answered from the device pass */
   int64_t dering_check_fail; /* check mode: device block != C od_dering (must be 0) */

@@ -9,6 +9,8 @@
 /* Per-thread state: which frame's feed this worker consumes. */
 typedef struct glue_tls {
   const od_hip_feed_level *lev;   /* 4 views, or NULL: plain reference */
+  const od_coeff *haar[3];        /* lossless frames: the device's Haar planes of this frame, or NULL */
+  int haar_stride[3];
   int check;
   int time_cpu;
   int pli;                        /* plane of the block being coded */

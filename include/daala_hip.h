@@ -312,6 +312,14 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_compand(od_hip_enc_feed *feed, int slot);
 int od_hip_enc_feed_search(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_view(od_hip_enc_feed *feed, int slot, od_hip_feed_level lev[4]);
+/* Lossless frames (quantizer 0): the encoder codes the Haar wavelet of every whole
+ * superblock (od_haar, src/encode.c:1305; no lapping, DCT or PVQ).  _run_lossless =
+ * od_hip_forward_haar of the slots + the three coefficient planes to pinned host memory;
+ * _haar_view blocks until the slot has landed: planes[pli] is what od_haar writes into
+ * dtmp[pli] superblock by superblock (row-major, strides[pli] elements per row). */
+int od_hip_enc_feed_run_lossless(od_hip_enc_feed *feed, int slot0, int nslots);
+int od_hip_enc_feed_haar_view(od_hip_enc_feed *feed, int slot, const od_coeff *planes[3],
+ int strides[3]);
 
 /* ---------------------------------------------------------------------------
  * 4c. Encoder-side deringing: od_dering() (src/filter.c:1835) of EVERY 32x32 superblock of

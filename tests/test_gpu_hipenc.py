@@ -253,3 +253,33 @@ def test_stream_ordering_regression_many_workers_repeated():
         n1, got, _, ds = H.decode(prm, hdr, pk, use_device=1)
         assert n1 == nf and ds > 0
         assert np.array_equal(got, want), rep
+
+
+def test_lossless_frames_through_both_seams():
+    """BASELINE configs[4]: lossless mode (quantizer 0: Haar wavelet of whole superblocks).
+    Encoder seam: od_haar calls answered from the device's Haar planes (check mode compares
+    each with the reference's od_haar), packets identical to the pure reference encoder.
+    Decoder seam: od_haar_inv + od_coeff_to_ref_plane = one od_hip_inverse_haar per frame;
+    pictures identical to the reference decoder AND to the input (lossless round trip)."""
+    w, h, nf = 352, 288, 3
+    fr = frames_of(w, h, [61, 62, 63])
+    buf = H.pack_frames(fr, w, h)
+    lib = ref('enc_probe')
+    lib.probe_encode_frames.restype = ctypes.c_long
+    out = np.zeros(1 << 23, np.uint8)
+    fnv, sec = ctypes.c_uint(), ctypes.c_double()
+    n = lib.probe_encode_frames(w, h, nf, 0, 7, 1, 1, pu8(buf), ctypes.byref(fnv), ctypes.byref(sec),
+                                pu8(out), out.size)
+    assert n > 0
+    want_pk = H.split_packets(out, nf)
+    prm = H.Params(w, h, 0, 7, 1, 2, 1, 0)
+    n1, pk, st = H.encode(prm, buf, nf, use_device=1)
+    assert n1 > 0 and pk == want_pk
+    fw, fh = (w + 63)//64*64, (h + 63)//64*64
+    assert st.haar_hits >= nf*((fw//32)*(fh//32) + 2*(fw//32)*(fh//32)) and st.fdct_check_fail == 0
+    hdr = H.headers(prm)
+    n0, want, _, _ = H.decode(prm, hdr, pk, use_device=0)
+    n2, got, _, ds = H.decode(prm, hdr, pk, use_device=1)
+    assert n0 == nf and n2 == nf and ds > 0
+    assert np.array_equal(got, want)
+    assert np.array_equal(got.ravel(), buf)                # lossless: the input itself
