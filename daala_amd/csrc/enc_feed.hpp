@@ -318,6 +318,9 @@ struct od_hip_dering {
   uint8_t *d_bskip[3] = {nullptr, nullptr, nullptr};
   int16_t *h_in[3] = {nullptr, nullptr, nullptr};      // pinned
   int16_t *h_out[3] = {nullptr, nullptr, nullptr};     // pinned
+  // distortions of the on/off decision (od_hip_dering_run_dist): lazily allocated
+  uint8_t *d_orig = nullptr, *h_orig = nullptr;        // padded 8-bit luma input
+  double *d_mag2 = nullptr, *d_dist = nullptr, *h_dist = nullptr;   // [3][nsb*16]: arg, unfiltered, filtered
 };
 
 extern "C" {
@@ -333,6 +336,11 @@ void od_hip_dering_destroy(od_hip_dering *d) {
     if (d->h_in[p]) (void)hipHostFree(d->h_in[p]);
     if (d->h_out[p]) (void)hipHostFree(d->h_out[p]);
   }
+  if (d->d_orig) (void)hipFree(d->d_orig);
+  if (d->h_orig) (void)hipHostFree(d->h_orig);
+  if (d->d_mag2) (void)hipFree(d->d_mag2);
+  if (d->d_dist) (void)hipFree(d->d_dist);
+  if (d->h_dist) (void)hipHostFree(d->h_dist);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
 }
@@ -370,12 +378,29 @@ od_hip_dering *od_hip_dering_create(int device, int frame_width, int frame_heigh
   return d;
 }
 
-int od_hip_dering_run(od_hip_dering *d, const int16_t *const in[], const unsigned char *const bskip[],
-                      int skip_stride, const int32_t *threshold, const int32_t *quantizer,
-                      int16_t *const out[]) {
+static int dering_run_impl(od_hip_dering *d, const int16_t *const in[], const unsigned char *const bskip[],
+                           int skip_stride, const int32_t *threshold, const int32_t *quantizer,
+                           int16_t *const out[], const unsigned char *orig, int orig_stride,
+                           const double *mag2, int masking, double *dist_arg, double *dist_unf,
+                           double *dist_filt) {
   if (!d || !in || !bskip || !threshold || !quantizer || !out) return fail(OD_HIP_EFAULT, "null pointer");
   HIPCHK(hipSetDevice(d->device));
   const int fw4 = d->fw/4, fh4 = d->fh/4;
+  const bool dist = orig != nullptr;
+  const size_t nsub = (size_t)(d->fw/32)*(d->fh/32)*16;
+  if (dist) {
+    if (!mag2 || !dist_arg || !dist_unf || !dist_filt || orig_stride < d->fw) return fail(OD_HIP_EFAULT, "bad distortion arguments");
+    if (!d->d_orig) {
+      HIPCHK(hipMalloc((void **)&d->d_orig, d->psz[0]));
+      HIPCHK(hipHostMalloc((void **)&d->h_orig, d->psz[0]));
+      HIPCHK(hipMalloc((void **)&d->d_mag2, 64*8));
+      HIPCHK(hipMalloc((void **)&d->d_dist, 3*nsub*8));
+      HIPCHK(hipHostMalloc((void **)&d->h_dist, 3*nsub*8));
+    }
+    for (int y = 0; y < d->fh; y++) memcpy(d->h_orig + (size_t)y*d->fw, orig + (size_t)y*orig_stride, d->fw);
+    HIPCHK(hipMemcpyAsync(d->d_orig, d->h_orig, d->psz[0], hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->d_mag2, mag2, 64*8, hipMemcpyHostToDevice, d->stream));
+  }
   TailArgs t;
   memset(&t, 0, sizeof(t));
   for (int p = 0; p < d->nplanes; p++) {
@@ -400,11 +425,42 @@ int od_hip_dering_run(od_hip_dering *d, const int16_t *const in[], const unsigne
   t.is_keyframe = 1;
   hipLaunchKernelGGL(k_decode_tail, dim3(t.nhsb, t.nvsb, 1), dim3(256), 0, d->stream, t);
   HIPCHK(hipGetLastError());
+  if (dist) {
+    const long total = (long)t.nhsb*t.nvsb*32;
+    hipLaunchKernelGGL(k_dering_dist, dim3((unsigned)((total + 63)/64)), dim3(64), 0, d->stream, t.nhsb, t.nvsb,
+                       d->fw, (const uint8_t *)d->d_orig, d->fw, (const int16_t *)d->d_in[0],
+                       (const int16_t *)d->d_out[0], (const double *)d->d_mag2, masking, d->d_dist,
+                       d->d_dist + nsub, d->d_dist + 2*nsub);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d->h_dist, d->d_dist, 3*nsub*8, hipMemcpyDeviceToHost, d->stream));
+  }
   for (int p = 0; p < d->nplanes; p++)
     HIPCHK(hipMemcpyAsync(d->h_out[p], d->d_out[p], d->psz[p]*2, hipMemcpyDeviceToHost, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   for (int p = 0; p < d->nplanes; p++) memcpy(out[p], d->h_out[p], d->psz[p]*2);
+  if (dist) {
+    memcpy(dist_arg, d->h_dist, nsub*8);
+    memcpy(dist_unf, d->h_dist + nsub, nsub*8);
+    memcpy(dist_filt, d->h_dist + 2*nsub, nsub*8);
+  }
   return 0;
+}
+
+int od_hip_dering_run(od_hip_dering *d, const int16_t *const in[], const unsigned char *const bskip[],
+                      int skip_stride, const int32_t *threshold, const int32_t *quantizer,
+                      int16_t *const out[]) {
+  return dering_run_impl(d, in, bskip, skip_stride, threshold, quantizer, out, nullptr, 0, nullptr, 0,
+                         nullptr, nullptr, nullptr);
+}
+
+int od_hip_dering_run_dist(od_hip_dering *d, const int16_t *const in[], const unsigned char *const bskip[],
+                           int skip_stride, const int32_t *threshold, const int32_t *quantizer,
+                           int16_t *const out[], const unsigned char *orig_luma, int orig_stride,
+                           const double *mag2, int activity_masking, double *dist_arg,
+                           double *dist_unfiltered, double *dist_filtered) {
+  if (!orig_luma) return fail(OD_HIP_EFAULT, "null pointer");
+  return dering_run_impl(d, in, bskip, skip_stride, threshold, quantizer, out, orig_luma, orig_stride,
+                         mag2, activity_masking, dist_arg, dist_unfiltered, dist_filtered);
 }
 
 }  // extern "C"

@@ -254,22 +254,25 @@ __device__ inline int dist_var_4x4(const int32_t *x, int stride) {
   return s2 - (sum*sum >> 4);
 }
 
-__global__ void k_compute_dist_blocks(int n, int nblk, const int32_t *__restrict__ xa,
-                                      const int32_t *__restrict__ ya,
-                                      const double *__restrict__ mag2, int masking,
-                                      double *__restrict__ arg, double *__restrict__ energy) {
-  const int per = (n/8)*(n/8);
-  const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= (long)nblk*per) return;
-  const long b = t/per;
-  const int sb = (int)(t%per), bi = (sb/(n/8))*8, bj = (sb%(n/8))*8;
-  const int32_t *xs = xa + b*n*n + bi*n + bj, *ys = ya + b*n*n + bi*n + bj;
+// od_compute_dist_8x8 (src/encode.c:962-1030) up to the activity power: the argument of
+// pow() and the weighted error energy of one 8x8 sub-block.  x(i, j), y(i, j): the two
+// blocks' samples.
+template <typename FX, typename FY>
+__device__ __forceinline__ void dist8x8_core(FX x, FY y, const double *__restrict__ mag2, int masking,
+                                             double *arg, double *energy) {
   double mean_var = 0, vardist = 0;
   int min_var = 2147483647;
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) {
-      const int varx = dist_var_4x4(xs + 2*i*n + 2*j, n);
-      const int vary = dist_var_4x4(ys + 2*i*n + 2*j, n);
+      int sx = 0, s2x = 0, sy = 0, s2y = 0;
+      for (int u = 0; u < 4; u++) {
+        for (int v = 0; v < 4; v++) {
+          const int tx = x(2*i + u, 2*j + v) >> 2, ty = y(2*i + u, 2*j + v) >> 2;
+          sx += tx; s2x += tx*tx;
+          sy += ty; s2y += ty*ty;
+        }
+      }
+      const int varx = s2x - (sx*sx >> 4), vary = s2y - (sy*sy >> 4);
       min_var = varx < min_var ? varx : min_var;
       mean_var += 1./(1 + varx);
       const double diff = sqrt((double)varx) - sqrt((double)vary);
@@ -282,7 +285,7 @@ __global__ void k_compute_dist_blocks(int n, int nblk, const int32_t *__restrict
   for (int c = 0; c < 8; c++) {
     int32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = xs[k*n + c] - ys[k*n + c];
+    for (int k = 0; k < 8; k++) v[k] = x(k, c) - y(k, c);
     LiftDct<8, false>::fwd(v);
 #pragma unroll
     for (int k = 0; k < 8; k++) z[c*8 + k] = v[k];
@@ -297,6 +300,48 @@ __global__ void k_compute_dist_blocks(int n, int nblk, const int32_t *__restrict
   }
   double sum = 0;
   for (int i = 0; i < 64; i++) sum += et[i]*(double)et[i]*mag2[i];
-  arg[t] = .25 + var_stat/(1 << 2*4);
-  energy[t] = sum + vardist;
+  *arg = .25 + var_stat/(1 << 2*4);
+  *energy = sum + vardist;
+}
+
+__global__ void k_compute_dist_blocks(int n, int nblk, const int32_t *__restrict__ xa,
+                                      const int32_t *__restrict__ ya,
+                                      const double *__restrict__ mag2, int masking,
+                                      double *__restrict__ arg, double *__restrict__ energy) {
+  const int per = (n/8)*(n/8);
+  const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= (long)nblk*per) return;
+  const long b = t/per;
+  const int sb = (int)(t%per), bi = (sb/(n/8))*8, bj = (sb%(n/8))*8;
+  const int32_t *xs = xa + b*n*n + bi*n + bj, *ys = ya + b*n*n + bi*n + bj;
+  dist8x8_core([&](int i, int j) { return xs[i*n + j]; }, [&](int i, int j) { return ys[i*n + j]; },
+               mag2, masking, &arg[t], &energy[t]);
+}
+
+// The encoder's deringing on/off decision (src/encode.c:2606-2636) compares, for every 32x32
+// luma superblock, od_compute_dist(original, unfiltered reconstruction) with
+// od_compute_dist(original, deringed reconstruction): both for EVERY superblock of the frame
+// in one launch, right after the deringing pass that produced the second operand.  One
+// thread per (superblock, 8x8 sub-block, operand).  orig: the padded 8-bit input plane
+// ((p - 128) << 4 on the fly, od_ref_buf_to_coeff :2608).
+__global__ void k_dering_dist(int nhsb, int nvsb, int w, const uint8_t *__restrict__ orig, int ostride,
+                              const int16_t *__restrict__ unf, const int16_t *__restrict__ filt,
+                              const double *__restrict__ mag2, int masking,
+                              double *__restrict__ arg, double *__restrict__ e_unf,
+                              double *__restrict__ e_filt) {
+  const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+  const long total = (long)nhsb*nvsb*32;
+  if (t >= total) return;
+  const int which = (int)(t & 1), sub = (int)((t >> 1) & 15);
+  const long sb = t >> 5;
+  const int sbx = (int)(sb%nhsb), sby = (int)(sb/nhsb);
+  const int y0 = sby*32 + (sub >> 2)*8, x0 = sbx*32 + (sub & 3)*8;
+  const uint8_t *o = orig + (size_t)y0*ostride + x0;
+  const int16_t *r = (which ? filt : unf) + (size_t)y0*w + x0;
+  double a, e;
+  dist8x8_core([&](int i, int j) { return ((int)o[i*ostride + j] - 128) << 4; },
+               [&](int i, int j) { return (int)r[i*w + j]; }, mag2, masking, &a, &e);
+  const long idx = sb*16 + sub;
+  if (which) e_filt[idx] = e;
+  else { e_unf[idx] = e; arg[idx] = a; }
 }

@@ -56,6 +56,7 @@ class Stats(ctypes.Structure):
                 ('fdct_hits', ctypes.c_int64), ('haar_hits', ctypes.c_int64),
                 ('fdct_check_fail', ctypes.c_int64),
                 ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
+                ('dist_dev', ctypes.c_int64), ('dist_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_compand_s', ctypes.c_double),

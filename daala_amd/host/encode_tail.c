@@ -8,3 +8,15 @@ void od_hipenc_copy_pad(daala_enc_ctx *enc, od_img *img) {
   od_img_copy_pad(enc, img);
   enc->in_buff_ptr = keep;
 }
+
+/* od_compute_dist as the encoder calls it: the two calls of the deringing on/off decision
+ * (src/encode.c:2634-2635) are answered from the device pass that deringed the frame
+ * (od_hipenc_dist_hook, hip_enc_glue.c); every other call is the reference's own function. */
+int od_hipenc_dist_hook(daala_enc_ctx *enc, const od_coeff *x, const od_coeff *y, int n, int bs,
+ double *dist, double (*cpu)(daala_enc_ctx *, od_coeff *, od_coeff *, int, int));
+
+static double od_compute_dist(daala_enc_ctx *enc, od_coeff *x, od_coeff *y, int n, int bs) {
+  double d;
+  if (od_hipenc_dist_hook(enc, x, y, n, bs, &d, od_compute_dist_cpu)) return d;
+  return od_compute_dist_cpu(enc, x, y, n, bs);
+}

@@ -111,7 +111,49 @@ int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
       quant[p] = state->quantizer[p];
       thr[p] = (int32_t)(1.0*pow(state->quantizer[p], 0.84182));     /* src/filter.c:1876 */
     }
-    if (od_hip_dering_run(T.dr, in, sk, state->skip_stride, thr, quant, T.dr_out) != 0) {
+    /* The two od_compute_dist calls per luma superblock of the same loop (:2634-2635) can
+       come from the same device pass when their operands are what the device sees: the HVS
+       matrix (the other branch is a plain SSD), and an unfiltered reconstruction that fits
+       the int16 planes od_dering works on (the distortion reads the int32 ctmp plane). */
+    T.dist_valid = 0;
+    T.dist_sb = -1;
+    if (T.dist[0] != NULL && T.enc->qm == OD_HVS_QM) {
+      const od_coeff *c0;
+      size_t np;
+      size_t i;
+      int fits;
+      c0 = state->ctmp[0];
+      np = (size_t)state->frame_width*state->frame_height;
+      fits = 1;
+      for (i = 0; i < np; i++) fits &= c0[i] == (int16_t)c0[i];
+      if (fits) {
+        double mag2[64];
+        const od_img_plane *ip;
+        int a;
+        int b;
+        /* src/encode.c:1018-1025, bs = 3 */
+        for (a = 0; a < 8; a++) {
+          for (b = 0; b < 8; b++) {
+            double mag;
+            mag = 16./OD_QM8_Q4_HVS[a*8 + b];
+            mag *= OD_BASIS_MAG[0][3][a << 2]*OD_BASIS_MAG[0][3][b << 2];
+            mag *= mag;
+            mag2[a*8 + b] = mag;
+          }
+        }
+        ip = &T.enc->input_img[T.enc->curr_frame].planes[0];
+        if (ip->xstride == 1 && od_hip_dering_run_dist(T.dr, in, sk, state->skip_stride, thr, quant,
+         T.dr_out, ip->data, ip->ystride, mag2, T.enc->use_activity_masking, T.dist[0], T.dist[1],
+         T.dist[2]) == 0) {
+          T.dist_valid = 1;
+        }
+        else {
+          T.dr_error = 1;
+          return 0;
+        }
+      }
+    }
+    if (!T.dist_valid && od_hip_dering_run(T.dr, in, sk, state->skip_stride, thr, quant, T.dr_out) != 0) {
       T.dr_error = 1;      /* reported as a failed frame by encode_frame: no silent C path */
       return 0;
     }
@@ -133,6 +175,42 @@ int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
   }
   for (i = 0; i < n; i++) memcpy(y + (size_t)i*ystride, src + (size_t)i*w, sizeof(int16_t)*n);
   T.st.dering_dev_sbs++;
+  if (pli == 0 && T.dist_valid) {
+    /* the loop computes the two distortions of this superblock next (:2634-2635) */
+    T.dist_sb = sby*nhsb + sbx;
+    T.dist_calls = 0;
+  }
+  return 1;
+}
+
+/* od_compute_dist (src/encode.c:1032) for the two calls that follow a luma od_dering call of
+   the on/off loop: operand 0 = the unfiltered superblock, operand 1 = the deringed one.  The
+   device delivered, per 8x8 sub-block, the pow argument and the weighted energy; the
+   activity power is this process's libm, the sum runs in the reference's raster order. */
+int od_hipenc_dist_hook(daala_enc_ctx *enc, const od_coeff *x, const od_coeff *y, int n, int bs,
+ double *dist, double (*cpu)(daala_enc_ctx *, od_coeff *, od_coeff *, int, int)) {
+  const double *arg;
+  const double *en;
+  double calibration;
+  double sum;
+  int k;
+  if (T.dist_sb < 0 || enc != T.enc || n != 32 || bs != 3) return 0;
+  arg = T.dist[0] + (size_t)T.dist_sb*16;
+  en = T.dist[1 + T.dist_calls] + (size_t)T.dist_sb*16;
+  calibration = enc->use_activity_masking ? 1.95 : 1.62;      /* :997-1004 */
+  sum = 0;
+  for (k = 0; k < 16; k++) {
+    double activity;
+    activity = calibration*pow(arg[k], -1./6);                 /* :1007 */
+    sum += activity*activity*en[k];                            /* :1029, :1048 */
+  }
+  sum *= 1.7;                                                   /* :1055 */
+  if (T.check) {
+    if (cpu(enc, (od_coeff *)x, (od_coeff *)y, n, bs) != sum) T.st.dist_check_fail++;
+  }
+  T.st.dist_dev++;
+  if (++T.dist_calls == 2) T.dist_sb = -1;
+  *dist = sum;
   return 1;
 }
 
@@ -483,6 +561,8 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->fdct_check_fail += b->fdct_check_fail;
   a->dering_dev_sbs += b->dering_dev_sbs;
   a->dering_check_fail += b->dering_check_fail;
+  a->dist_dev += b->dist_dev;
+  a->dist_check_fail += b->dist_check_fail;
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
@@ -530,6 +610,8 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   fill_img(&img, J->frames + S->frame_bytes*f, S->p.pic_width, S->p.pic_height);
   T.enc = enc;
   T.dr_valid = 0;
+  T.dist_valid = 0;
+  T.dist_sb = -1;
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
   if (T.dr_error) return -4;
   J->pkt_len[f] = 0;
@@ -608,6 +690,16 @@ static void *worker(void *arg) {
     int xdec[3] = {0, 1, 1};
     int pli;
     T.dr = od_hip_dering_create(S->device, enc->state.frame_width, enc->state.frame_height, 3, xdec);
+    {
+      size_t nsub;
+      int k;
+      nsub = (size_t)(enc->state.frame_width/32)*(enc->state.frame_height/32)*16;
+      for (k = 0; k < 3; k++) T.dist[k] = (double *)malloc(sizeof(double)*nsub);
+      if (T.dist[0] == NULL || T.dist[1] == NULL || T.dist[2] == NULL) {
+        free(T.dist[0]);
+        T.dist[0] = NULL;        /* no distortions from the device: the reference's code runs */
+      }
+    }
     for (pli = 0; pli < 3; pli++) {
       T.dr_out[pli] = (int16_t *)malloc(sizeof(int16_t)*(size_t)(enc->state.frame_width >> (pli > 0))
        *(enc->state.frame_height >> (pli > 0)));
@@ -681,6 +773,9 @@ static void *worker(void *arg) {
   free(T.dr_out[0]);
   free(T.dr_out[1]);
   free(T.dr_out[2]);
+  free(T.dist[0]);
+  free(T.dist[1]);
+  free(T.dist[2]);
   if (enc != NULL) daala_encode_free(enc);
   return NULL;
 }

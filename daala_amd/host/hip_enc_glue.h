@@ -40,6 +40,8 @@ typedef struct od_hipenc_stats {
   int64_t fdct_check_fail; /* check mode: device block != C transform (must be 0) */
   int64_t dering_dev_sbs;  /* od_dering calls (superblock, plane) answered from the device pass */
   int64_t dering_check_fail; /* check mode: device block != C od_dering (must be 0) */
+  int64_t dist_dev;        /* od_compute_dist calls of the deringing on/off loop answered from the device pass */
+  int64_t dist_check_fail; /* check mode: device distortion != the reference's od_compute_dist (must be 0) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* upload done -> device batch enqueued (includes t_compand_s), wall */

@@ -22,6 +22,11 @@ typedef struct glue_tls {
   od_hip_dering *dr;              /* this worker's device deringing object, or NULL */
   int16_t *dr_out[3];             /* deringed planes of the frame being coded */
   int dr_valid;                   /* dr_out holds the current frame */
+  double *dist[3];                /* per 8x8 sub-block of every luma superblock: pow argument, energy vs the
+                                     unfiltered and vs the deringed reconstruction (od_hip_dering_run_dist) */
+  int dist_valid;                 /* dist[] holds the current frame */
+  int dist_sb;                    /* superblock whose two od_compute_dist calls come next, or -1 */
+  int dist_calls;
   int dr_error;
   od_hipenc_stats st;
 } glue_tls;

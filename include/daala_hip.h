@@ -336,6 +336,20 @@ void od_hip_dering_destroy(od_hip_dering *d);
 int od_hip_dering_run(od_hip_dering *d, const int16_t *const in[],
  const unsigned char *const bskip[], int skip_stride, const int32_t *threshold,
  const int32_t *quantizer, int16_t *const out[]);
+/* The same plus the two distortions the encoder's on/off decision compares for every 32x32
+ * luma superblock (src/encode.c:2606-2636): od_compute_dist(original, unfiltered) and
+ * od_compute_dist(original, deringed) (A22, src/encode.c:1032), up to the activity power:
+ * per superblock (raster order) and 8x8 sub-block (raster order, 16 per superblock)
+ *   dist_arg[sb*16 + k]         the argument .25 + var_stat/256 of pow(., -1/6) (:1007),
+ *   dist_unfiltered / _filtered the weighted error energy sum + vardist (:1029),
+ * so that od_compute_dist = 1.7 * sum_k (calibration*pow(arg_k, -1./6))^2 * energy_k with
+ * the HOST's pow.  orig_luma: the padded 8-bit input plane (frame_width x frame_height
+ * used, orig_stride bytes per row); mag2[64]: as od_hip_compute_dist_blocks, bs = 3. */
+int od_hip_dering_run_dist(od_hip_dering *d, const int16_t *const in[],
+ const unsigned char *const bskip[], int skip_stride, const int32_t *threshold,
+ const int32_t *quantizer, int16_t *const out[], const unsigned char *orig_luma,
+ int orig_stride, const double *mag2, int activity_masking, double *dist_arg,
+ double *dist_unfiltered, double *dist_filtered);
 
 /* Stand-alone batched pieces for parity tests (host memory):
  * nvec band vectors of length n. */
