@@ -109,10 +109,10 @@ KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel nam
     'k_forward_pyramid_chroma': 'k_forward_rt<16, 3, false>',
     'k_forward_known_luma': 'k_forward_rt<32, 4, true>',
     'k_forward_known_chroma': 'k_forward_rt<16, 3, true>',
-    'k_inverse_sb_luma': 'k_inverse_rt<32, 4>',
-    'k_inverse_sb_chroma': 'k_inverse_rt<16, 3>',
-    'k_postfilter_clamp_luma': 'k_postfilter_clamp<32>',
-    'k_postfilter_clamp_chroma': 'k_postfilter_clamp<16>',
+    'k_inverse_sb_luma': 'k_inverse_rt_fused<32, 4>',
+    'k_inverse_sb_chroma': 'k_inverse_rt_fused<16, 3>',
+    'k_inverse_strips_luma': 'k_inverse_strips<32>',
+    'k_inverse_strips_chroma': 'k_inverse_strips<16>',
 }
 
 
@@ -216,8 +216,8 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
         'k_forward_known_chroma': FRAMES*s_c*5,
         'k_inverse_sb_luma': FRAMES*s_y*5,          # inverse+postfilter+clamp is 5 B/sample
         'k_inverse_sb_chroma': FRAMES*s_c*5,        #   in total; split over two kernels here
-        'k_postfilter_clamp_luma': FRAMES*s_y*5,
-        'k_postfilter_clamp_chroma': FRAMES*s_c*5,
+        'k_inverse_strips_luma': FRAMES*s_y*5,
+        'k_inverse_strips_chroma': FRAMES*s_c*5,
     }
     kernels = {}
     pvq_names = ['k_pvq_noref<15>', 'k_pvq_noref<8>', 'k_pvq_noref<32>', 'k_pvq_noref<128>']

@@ -140,6 +140,8 @@ struct od_hip_ctx {
   uint8_t *rec[OD_HIP_NPLANES_MAX];          // [slot][h][w]
   uint8_t *bsize;                            // [slot][nvsb*4][nhsb*4]
   int32_t *p32[OD_HIP_NPLANES_MAX];          // [slot][h][w] post-filtered planes (decoder tail)
+  int32_t *rs[OD_HIP_NPLANES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // fused inverse: row strips (lazy)
+  int32_t *cs[OD_HIP_NPLANES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // fused inverse: column strips
   uint8_t *dflags;                           // [slot][nvsb*nhsb] dering flags
   uint8_t *bskip[OD_HIP_NPLANES_MAX];        // [slot][(fh/4)*(fw/4)]
   size_t bsize_sz;
@@ -591,6 +593,8 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
     if (ctx->c[p]) (void)hipFree(ctx->c[p]);
     if (ctx->rec[p]) (void)hipFree(ctx->rec[p]);
     if (ctx->p32[p]) (void)hipFree(ctx->p32[p]);
+    if (ctx->rs[p]) (void)hipFree(ctx->rs[p]);
+    if (ctx->cs[p]) (void)hipFree(ctx->cs[p]);
     if (ctx->bskip[p]) (void)hipFree(ctx->bskip[p]);
     for (int l = 0; l < 4; l++) {
       PvqSoA &o = ctx->pvq[p][l];
@@ -748,6 +752,9 @@ int od_hip_forward_known(od_hip_ctx *ctx, int slot0, int nslots, int keyframe) {
 
 int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  // OD_HIP_INVERSE_IMPL=1: the two-kernel form through the int32 work plane (what the
+  // decoder tail uses, where deringing needs that plane anyway); default: fused (no work plane)
+  static const int impl = getenv("OD_HIP_INVERSE_IMPL") ? atoi(getenv("OD_HIP_INVERSE_IMPL")) : 2;
   for (int p = 0; p < ctx->geo.nplanes; p++) {
     InvArgs a;
     a.d = ctx->d[p] + (size_t)slot0*ctx->psz[p];
@@ -759,6 +766,39 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
     a.w = ctx->pw[p]; a.h = ctx->ph[p]; a.nhsb = ctx->nhsb; a.nvsb = ctx->nvsb;
     a.pic_w = ctx->geo.pic_width; a.pic_h = ctx->geo.pic_height;
     a.dec = ctx->geo.xdec[p];
+    if (impl != 1) {
+      const int sb = 32 >> a.dec;
+      const int ntx = (a.w + 63)/64;
+      const size_t rsz = (size_t)ctx->nvsb*4*a.w, csz = (size_t)ntx*a.h*4;
+      if (!ctx->rs[p]) {
+        HIPCHK(hipMalloc((void **)&ctx->rs[p], (size_t)ctx->geo.nslots*rsz*sizeof(int32_t)));
+        HIPCHK(hipMalloc((void **)&ctx->cs[p], (size_t)ctx->geo.nslots*csz*sizeof(int32_t)));
+      }
+      a.rec = ctx->rec[p] + (size_t)slot0*ctx->psz[p];
+      a.rs = ctx->rs[p] + (size_t)slot0*rsz;
+      a.cs = ctx->cs[p] + (size_t)slot0*csz;
+      a.rs_fstride = rsz;
+      a.cs_fstride = csz;
+      a.ntx = ntx;
+      (void)sb;
+      const dim3 grid(ntx, ctx->nvsb, nslots);
+      if (a.dec == 0) {
+        { Timed tm(ctx, "k_inverse_sb_luma");
+          hipLaunchKernelGGL((k_inverse_rt_fused<32, 4>), grid, dim3(64), 0, ctx->stream, a); }
+        HIPCHK(hipGetLastError());
+        { Timed tm(ctx, "k_inverse_strips_luma");
+          hipLaunchKernelGGL((k_inverse_strips<32>), grid, dim3(64), 0, ctx->stream, a); }
+      }
+      else {
+        { Timed tm(ctx, "k_inverse_sb_chroma");
+          hipLaunchKernelGGL((k_inverse_rt_fused<16, 3>), grid, dim3(64), 0, ctx->stream, a); }
+        HIPCHK(hipGetLastError());
+        { Timed tm(ctx, "k_inverse_strips_chroma");
+          hipLaunchKernelGGL((k_inverse_strips<16>), grid, dim3(64), 0, ctx->stream, a); }
+      }
+      HIPCHK(hipGetLastError());
+      continue;
+    }
     PostArgs q;
     q.c = a.c; q.c_fstride = ctx->psz[p];
     q.rec = ctx->rec[p] + (size_t)slot0*ctx->psz[p]; q.rec_fstride = ctx->psz[p];

@@ -404,3 +404,194 @@ __global__ __launch_bounds__(64) void k_inverse_rt(InvArgs a) {
   }
   rt_store_tile<SB>(a.c + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0, Z);
 }
+
+
+// ---------------------------------------------------------------------------------
+// Inverse + frame post-filter + clamp WITHOUT the int32 work plane (A7 + A5 + A4 + A2).
+// k_inverse_rt above writes the whole lapped-domain tile as int32 and k_postfilter_clamp
+// reads it back: 13 B/sample of traffic for 5 B/sample of work.  Here the tile finishes
+// everything that does not involve another tile:
+//   * the frame post-filter's first pass (od_apply_postfilter_frame_sbs, src/filter.c:1627-
+//     1633: 4-tap across every vertical superblock boundary, all rows) on the boundaries
+//     INSIDE the 64-wide tile;
+//   * rows 2 .. SB-3 x columns 2 .. tw-3 are then final (the second pass touches only rows
+//     within 2 of a horizontal boundary, the first pass of a neighbouring tile only columns
+//     within 2 of the tile edge): clamped to 8 bit and written once;
+//   * the 2-sample edge strips (tile rows 0, 1, SB-2, SB-1; tile columns 0, 1, tw-2, tw-1)
+//     go to two small int32 strip buffers.
+// k_inverse_strips then finishes the strips of tile (tx, sby): the first pass across its
+// left tile boundary for its interior rows, and the second pass (vertical 4-tap across the
+// horizontal superblock boundary above it) for all its columns - after redoing the first
+// pass locally for the four rows x two tile boundaries involved, so that no workgroup
+// depends on another's output.  Frame edges have no boundary: those strips are only
+// clamped.  Order of the two passes and every tap are the reference's.
+__device__ __forceinline__ uint32_t clamp8(int32_t v) {
+  v = ((v + 8) >> 4) + 128;
+  return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+template <int SB, int NLEV>
+__global__ __launch_bounds__(64) void k_inverse_rt_fused(InvArgs a) {
+  using T = RowTile<SB>;
+  __shared__ int32_t Z[SB*T::LDZ];
+  __shared__ uint8_t bsz[16*T::NSB];
+  const int lane = threadIdx.x;
+  int tx, sby, f;
+  rt_tile_coords(tx, sby, f);
+  const int x0 = tx*T::W, y0 = sby*SB;
+  const int sbx0 = tx*T::NSB;
+  const int nsb = min(T::NSB, a.nhsb - sbx0);
+  const int tw = min(T::W, a.w - x0);
+  for (int e = lane; e < 16*T::NSB; e += 64) {
+    const int s = e >> 4, c = e & 15;
+    bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
+                               (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
+                     : 3;
+  }
+  rt_load_tile<SB>(Z, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0);
+  rt_sync();
+  int mx = 0;
+  for (int e = lane; e < SB*T::W; e += 64) {
+    const int v = Z[(e >> 6)*T::LDZ + (e & 63)];
+    mx = max(mx, v < 0 ? -(v + 1) : v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+  if (mx <= (1 << 18)) rt_inverse_body<SB, NLEV, true>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
+  else rt_inverse_body<SB, NLEV, false>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
+  // first pass on the tile-internal vertical superblock boundaries
+  if (lane < (T::NSB - 1)*SB) {
+    const int k = lane/SB + 1, r = lane%SB;
+    if (k < nsb) {
+      int32_t *p = Z + r*T::LDZ + k*SB - 2;
+      lap4_post(p[0], p[1], p[2], p[3]);
+    }
+  }
+  rt_sync();
+  // interior: final, 8 bit
+  {
+    uint8_t *rec = a.rec + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
+    const int r0 = lane & 3, c4 = (lane >> 2)*4;
+#pragma unroll
+    for (int it = 0; it < SB/4; it++) {
+      const int r = it*4 + r0;
+      if (r >= 2 && r < SB - 2 && c4 < tw) {
+        const int32_t *p = Z + r*T::LDZ + c4;
+        uint8_t *q = rec + (size_t)r*a.w + c4;
+        if (c4 == 0) *reinterpret_cast<uint16_t *>(q + 2) = (uint16_t)(clamp8(p[2]) | clamp8(p[3]) << 8);
+        else if (c4 == tw - 4) *reinterpret_cast<uint16_t *>(q) = (uint16_t)(clamp8(p[0]) | clamp8(p[1]) << 8);
+        else *reinterpret_cast<uint32_t *>(q) = clamp8(p[0]) | clamp8(p[1]) << 8 | clamp8(p[2]) << 16 | clamp8(p[3]) << 24;
+      }
+    }
+  }
+  // row strips: tile rows 0, 1, SB-2, SB-1
+  {
+    const int k = lane >> 4, c4 = (lane & 15)*4;
+    const int r = k < 2 ? k : SB - 4 + k;
+    if (c4 < tw) {
+      const int32_t *p = Z + r*T::LDZ + c4;
+      int32_t *q = a.rs + (size_t)f*a.rs_fstride + ((size_t)sby*4 + k)*a.w + x0 + c4;
+      *reinterpret_cast<int4 *>(q) = make_int4(p[0], p[1], p[2], p[3]);
+    }
+  }
+  // column strips: tile columns 0, 1, tw-2, tw-1 of every row
+  if (lane < SB) {
+    const int32_t *p = Z + lane*T::LDZ;
+    int32_t *q = a.cs + (size_t)f*a.cs_fstride + ((size_t)tx*a.h + y0 + lane)*4;
+    *reinterpret_cast<int4 *>(q) = make_int4(p[0], p[1], p[tw - 2], p[tw - 1]);
+  }
+}
+
+template <int SB>
+__global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
+  using T = RowTile<SB>;
+  __shared__ int32_t E[6][4];          // edge columns {0, 1, tw-2, tw-1} of rows y0-2 .. y0+1, then the frame's last two rows
+  const int lane = threadIdx.x;
+  int tx, sby, f;
+  rt_tile_coords(tx, sby, f);
+  const int x0 = tx*T::W, y0 = sby*SB;
+  const int tw = min(T::W, a.w - x0);
+  const int32_t *cs = a.cs + (size_t)f*a.cs_fstride;
+  const int32_t *rs = a.rs + (size_t)f*a.rs_fstride;
+  uint8_t *rec = a.rec + (size_t)f*a.fstride;
+  const bool left = tx > 0, right = tx < a.ntx - 1, top = sby > 0, last = sby == a.nvsb - 1;
+  auto csrow = [&](int t, int y) -> int4 {
+    return *reinterpret_cast<const int4 *>(cs + ((size_t)t*a.h + y)*4);
+  };
+  // first pass across the left tile boundary, this tile's interior rows
+  if (lane < SB) {
+    const int r = lane;
+    const int4 cur = csrow(tx, y0 + r);
+    int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
+    if (left) {
+      const int4 prv = csrow(tx - 1, y0 + r);
+      v0 = prv.z; v1 = prv.w;
+      lap4_post(v0, v1, v2, v3);
+    }
+    if (r >= 2 && r < SB - 2) {
+      uint8_t *q = rec + (size_t)(y0 + r)*a.w + x0;
+      if (left) *reinterpret_cast<uint16_t *>(q - 2) = (uint16_t)(clamp8(v0) | clamp8(v1) << 8);
+      *reinterpret_cast<uint16_t *>(q) = (uint16_t)(clamp8(v2) | clamp8(v3) << 8);
+      if (!right) *reinterpret_cast<uint16_t *>(q + tw - 2) = (uint16_t)(clamp8(cur.z) | clamp8(cur.w) << 8);
+    }
+  }
+  // the first pass redone for the rows of the horizontal boundary above this tile
+  // (y0-2 .. y0+1) and, on the last tile row, for the frame's last two rows
+  if (lane < 12) {
+    const int k = lane >> 1, side = lane & 1;          // row slot, 0 = left boundary / 1 = right boundary
+    const int y = k < 4 ? y0 - 2 + k : y0 + SB - 6 + k;  // k = 4, 5 -> y0 + SB - 2, y0 + SB - 1
+    const bool need = k < 4 ? (y >= 0) : last;
+    if (need) {
+      const int4 cur = csrow(tx, y);
+      if (side == 0) {
+        int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
+        if (left) {
+          const int4 prv = csrow(tx - 1, y);
+          v0 = prv.z; v1 = prv.w;
+          lap4_post(v0, v1, v2, v3);
+        }
+        E[k][0] = v2; E[k][1] = v3;
+      }
+      else {
+        int32_t v0 = cur.z, v1 = cur.w, v2 = 0, v3 = 0;
+        if (right) {
+          const int4 nxt = csrow(tx + 1, y);
+          v2 = nxt.x; v3 = nxt.y;
+          lap4_post(v0, v1, v2, v3);
+        }
+        E[k][2] = v0; E[k][3] = v1;
+      }
+    }
+  }
+  __syncthreads();
+  // second pass across the horizontal boundary above this tile, one column per lane
+  if (lane < tw) {
+    const int c = lane;
+    const int ei = c < 2 ? c : c >= tw - 2 ? c - (tw - 4) : -1;
+    const size_t col = (size_t)x0 + c;
+    int32_t v[4];
+    if (top) {
+      v[0] = rs[((size_t)(sby - 1)*4 + 2)*a.w + col];
+      v[1] = rs[((size_t)(sby - 1)*4 + 3)*a.w + col];
+    }
+    v[2] = rs[((size_t)sby*4 + 0)*a.w + col];
+    v[3] = rs[((size_t)sby*4 + 1)*a.w + col];
+    if (ei >= 0) {
+      if (top) { v[0] = E[0][ei]; v[1] = E[1][ei]; }
+      v[2] = E[2][ei]; v[3] = E[3][ei];
+    }
+    if (top) {
+      lap4_post(v[0], v[1], v[2], v[3]);
+      rec[(size_t)(y0 - 2)*a.w + col] = (uint8_t)clamp8(v[0]);
+      rec[(size_t)(y0 - 1)*a.w + col] = (uint8_t)clamp8(v[1]);
+    }
+    rec[(size_t)y0*a.w + col] = (uint8_t)clamp8(v[2]);
+    rec[(size_t)(y0 + 1)*a.w + col] = (uint8_t)clamp8(v[3]);
+    if (last) {
+      int32_t b0 = rs[((size_t)sby*4 + 2)*a.w + col], b1 = rs[((size_t)sby*4 + 3)*a.w + col];
+      if (ei >= 0) { b0 = E[4][ei]; b1 = E[5][ei]; }
+      rec[(size_t)(y0 + SB - 2)*a.w + col] = (uint8_t)clamp8(b0);
+      rec[(size_t)(y0 + SB - 1)*a.w + col] = (uint8_t)clamp8(b1);
+    }
+  }
+}
