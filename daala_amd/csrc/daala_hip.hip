@@ -140,8 +140,8 @@ struct od_hip_ctx {
   uint8_t *rec[OD_HIP_NPLANES_MAX];          // [slot][h][w]
   uint8_t *bsize;                            // [slot][nvsb*4][nhsb*4]
   int32_t *p32[OD_HIP_NPLANES_MAX];          // [slot][h][w] post-filtered planes (decoder tail)
-  int32_t *rs[OD_HIP_NPLANES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // fused inverse: row strips (lazy)
-  int32_t *cs[OD_HIP_NPLANES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // fused inverse: column strips
+  int16_t *rs[OD_HIP_NPLANES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // fused inverse: row strips (lazy)
+  int16_t *cs[OD_HIP_NPLANES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // fused inverse: column strips
   uint8_t *dflags;                           // [slot][nvsb*nhsb] dering flags
   uint8_t *bskip[OD_HIP_NPLANES_MAX];        // [slot][(fh/4)*(fw/4)]
   size_t bsize_sz;
@@ -771,8 +771,8 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
       const int ntx = (a.w + 63)/64;
       const size_t rsz = (size_t)ctx->nvsb*4*a.w, csz = (size_t)ntx*a.h*4;
       if (!ctx->rs[p]) {
-        HIPCHK(hipMalloc((void **)&ctx->rs[p], (size_t)ctx->geo.nslots*rsz*sizeof(int32_t)));
-        HIPCHK(hipMalloc((void **)&ctx->cs[p], (size_t)ctx->geo.nslots*csz*sizeof(int32_t)));
+        HIPCHK(hipMalloc((void **)&ctx->rs[p], (size_t)ctx->geo.nslots*rsz*sizeof(int16_t)));
+        HIPCHK(hipMalloc((void **)&ctx->cs[p], (size_t)ctx->geo.nslots*csz*sizeof(int16_t)));
       }
       a.rec = ctx->rec[p] + (size_t)slot0*ctx->psz[p];
       a.rs = ctx->rs[p] + (size_t)slot0*rsz;

@@ -212,8 +212,8 @@ struct InvArgs {
   int dec;
   // fused inverse (k_inverse_rt_fused / k_inverse_strips): 8-bit output and the edge strips
   uint8_t *rec;            // [frame][h][w]
-  int32_t *rs;             // row strips  [frame][nvsb][4][w]: tile rows 0, 1, SB-2, SB-1
-  int32_t *cs;             // column strips [frame][ntx][h][4]: tile columns 0, 1, tw-2, tw-1
+  int16_t *rs;             // row strips  [frame][nvsb][4][w]: tile rows 0, 1, SB-2, SB-1 (int16, escape in c)
+  int16_t *cs;             // column strips [frame][ntx][h][4]: tile columns 0, 1, tw-2, tw-1
   size_t rs_fstride, cs_fstride;
   int ntx;
 };

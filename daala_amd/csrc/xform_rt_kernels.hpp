@@ -418,13 +418,26 @@ __global__ __launch_bounds__(64) void k_inverse_rt(InvArgs a) {
 //     within 2 of a horizontal boundary, the first pass of a neighbouring tile only columns
 //     within 2 of the tile edge): clamped to 8 bit and written once;
 //   * the 2-sample edge strips (tile rows 0, 1, SB-2, SB-1; tile columns 0, 1, tw-2, tw-1)
-//     go to two small int32 strip buffers.
+//     go to two small int16 strip buffers; a value that does not fit int16 (possible only
+//     for out-of-range streams) is stored as the marker -32768 and its int32 value goes to
+//     the work plane c at its own position, where the strip kernel picks it up: exact for
+//     every input, 2 bytes per strip sample in the normal case.
 // k_inverse_strips then finishes the strips of tile (tx, sby): the first pass across its
 // left tile boundary for its interior rows, and the second pass (vertical 4-tap across the
 // horizontal superblock boundary above it) for all its columns - after redoing the first
 // pass locally for the four rows x two tile boundaries involved, so that no workgroup
 // depends on another's output.  Frame edges have no boundary: those strips are only
 // clamped.  Order of the two passes and every tap are the reference's.
+#define STRIP_ESC (-32768)
+__device__ __forceinline__ int16_t strip_put(int32_t v, int32_t *esc) {
+  if (v > STRIP_ESC && v <= 32767) return (int16_t)v;
+  *esc = v;
+  return (int16_t)STRIP_ESC;
+}
+__device__ __forceinline__ int32_t strip_get(int16_t s, const int32_t *esc) {
+  return s == STRIP_ESC ? *esc : (int32_t)s;
+}
+
 __device__ __forceinline__ uint32_t clamp8(int32_t v) {
   v = ((v + 8) >> 4) + 128;
   return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
@@ -485,20 +498,27 @@ __global__ __launch_bounds__(64) void k_inverse_rt_fused(InvArgs a) {
     }
   }
   // row strips: tile rows 0, 1, SB-2, SB-1
+  int32_t *escp = a.c + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
   {
     const int k = lane >> 4, c4 = (lane & 15)*4;
     const int r = k < 2 ? k : SB - 4 + k;
     if (c4 < tw) {
       const int32_t *p = Z + r*T::LDZ + c4;
-      int32_t *q = a.rs + (size_t)f*a.rs_fstride + ((size_t)sby*4 + k)*a.w + x0 + c4;
-      *reinterpret_cast<int4 *>(q) = make_int4(p[0], p[1], p[2], p[3]);
+      int32_t *e = escp + (size_t)r*a.w + c4;
+      int16_t *q = a.rs + (size_t)f*a.rs_fstride + ((size_t)sby*4 + k)*a.w + x0 + c4;
+      const uint32_t lo = (uint16_t)strip_put(p[0], e) | (uint32_t)(uint16_t)strip_put(p[1], e + 1) << 16;
+      const uint32_t hi = (uint16_t)strip_put(p[2], e + 2) | (uint32_t)(uint16_t)strip_put(p[3], e + 3) << 16;
+      *reinterpret_cast<uint2 *>(q) = make_uint2(lo, hi);
     }
   }
   // column strips: tile columns 0, 1, tw-2, tw-1 of every row
   if (lane < SB) {
     const int32_t *p = Z + lane*T::LDZ;
-    int32_t *q = a.cs + (size_t)f*a.cs_fstride + ((size_t)tx*a.h + y0 + lane)*4;
-    *reinterpret_cast<int4 *>(q) = make_int4(p[0], p[1], p[tw - 2], p[tw - 1]);
+    int32_t *e = escp + (size_t)lane*a.w;
+    int16_t *q = a.cs + (size_t)f*a.cs_fstride + ((size_t)tx*a.h + y0 + lane)*4;
+    const uint32_t lo = (uint16_t)strip_put(p[0], e) | (uint32_t)(uint16_t)strip_put(p[1], e + 1) << 16;
+    const uint32_t hi = (uint16_t)strip_put(p[tw - 2], e + tw - 2) | (uint32_t)(uint16_t)strip_put(p[tw - 1], e + tw - 1) << 16;
+    *reinterpret_cast<uint2 *>(q) = make_uint2(lo, hi);
   }
 }
 
@@ -511,12 +531,21 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
   rt_tile_coords(tx, sby, f);
   const int x0 = tx*T::W, y0 = sby*SB;
   const int tw = min(T::W, a.w - x0);
-  const int32_t *cs = a.cs + (size_t)f*a.cs_fstride;
-  const int32_t *rs = a.rs + (size_t)f*a.rs_fstride;
+  const int16_t *cs = a.cs + (size_t)f*a.cs_fstride;
+  const int16_t *rs = a.rs + (size_t)f*a.rs_fstride;
+  const int32_t *esc = a.c + (size_t)f*a.fstride;
   uint8_t *rec = a.rec + (size_t)f*a.fstride;
   const bool left = tx > 0, right = tx < a.ntx - 1, top = sby > 0, last = sby == a.nvsb - 1;
+  // the four strip columns of row y of tile t: its columns 0, 1, tw_t-2, tw_t-1
   auto csrow = [&](int t, int y) -> int4 {
-    return *reinterpret_cast<const int4 *>(cs + ((size_t)t*a.h + y)*4);
+    const uint2 u = *reinterpret_cast<const uint2 *>(cs + ((size_t)t*a.h + y)*4);
+    const int xt = t*T::W, twt = min(T::W, a.w - xt);
+    const int32_t *e = esc + (size_t)y*a.w + xt;
+    return make_int4(strip_get((int16_t)(u.x & 0xffff), e), strip_get((int16_t)(u.x >> 16), e + 1),
+                     strip_get((int16_t)(u.y & 0xffff), e + twt - 2), strip_get((int16_t)(u.y >> 16), e + twt - 1));
+  };
+  auto rsat = [&](int row4, size_t col, int y) -> int32_t {
+    return strip_get(rs[(size_t)row4*a.w + col], esc + (size_t)y*a.w + col);
   };
   // first pass across the left tile boundary, this tile's interior rows
   if (lane < SB) {
@@ -571,11 +600,11 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
     const size_t col = (size_t)x0 + c;
     int32_t v[4];
     if (top) {
-      v[0] = rs[((size_t)(sby - 1)*4 + 2)*a.w + col];
-      v[1] = rs[((size_t)(sby - 1)*4 + 3)*a.w + col];
+      v[0] = rsat((sby - 1)*4 + 2, col, y0 - 2);
+      v[1] = rsat((sby - 1)*4 + 3, col, y0 - 1);
     }
-    v[2] = rs[((size_t)sby*4 + 0)*a.w + col];
-    v[3] = rs[((size_t)sby*4 + 1)*a.w + col];
+    v[2] = rsat(sby*4 + 0, col, y0);
+    v[3] = rsat(sby*4 + 1, col, y0 + 1);
     if (ei >= 0) {
       if (top) { v[0] = E[0][ei]; v[1] = E[1][ei]; }
       v[2] = E[2][ei]; v[3] = E[3][ei];
@@ -588,7 +617,7 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
     rec[(size_t)y0*a.w + col] = (uint8_t)clamp8(v[2]);
     rec[(size_t)(y0 + 1)*a.w + col] = (uint8_t)clamp8(v[3]);
     if (last) {
-      int32_t b0 = rs[((size_t)sby*4 + 2)*a.w + col], b1 = rs[((size_t)sby*4 + 3)*a.w + col];
+      int32_t b0 = rsat(sby*4 + 2, col, y0 + SB - 2), b1 = rsat(sby*4 + 3, col, y0 + SB - 1);
       if (ei >= 0) { b0 = E[4][ei]; b1 = E[5][ei]; }
       rec[(size_t)(y0 + SB - 2)*a.w + col] = (uint8_t)clamp8(b0);
       rec[(size_t)(y0 + SB - 1)*a.w + col] = (uint8_t)clamp8(b1);

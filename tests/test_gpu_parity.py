@@ -215,6 +215,37 @@ def test_inverse_of_quantised_coefficients_matches_oracle(hip):
     ctx.close()
 
 
+@pytest.mark.parametrize('fw,fh,amp', [(320, 224, 4000), (192, 128, 400000), (448, 96, 60000)])
+def test_inverse_out_of_range_coefficients_and_odd_tilings(hip, fw, fh, amp):
+    """The fused inverse (interior written as 8 bit, 2-sample edge strips as int16 with an
+    int32 escape) on coefficients far outside what an encoder produces - reconstruction
+    values that do not fit int16, and beyond the 24-bit multiplier's range - and on plane
+    widths that end in a partial 64-wide tile (chroma 160, 96, 224): identical to the oracle."""
+    o = oracle()
+    nhsb, nvsb = fw//32, fh//32
+    ctx = hip.DaalaHip(fw - 7, fh - 5, fw, fh, nplanes=2, xdec=(0, 1), nslots=1)
+    bmap = random_bsize_map(nhsb, nvsb, 77)
+    ctx.set_bsize(0, bmap)
+    rng = np.random.default_rng(amp)
+    ds = []
+    for pli in (0, 1):
+        h, w = ctx.plane_shape(pli)
+        d = (rng.laplace(0, 1, size=(h, w))*amp).astype(np.int32)
+        d[rng.random((h, w)) < .7] = 0
+        ctx.upload_coeffs(0, pli, d)
+        ds.append(d)
+    ctx.inverse()
+    for pli in (0, 1):
+        h, w = ctx.plane_shape(pli)
+        out = np.zeros((h, w), np.uint8); c = np.zeros((h, w), np.int32)
+        o.orc_inverse_plane(pu8(out), w, p32(c), p32(ds[pli]), nhsb, nvsb, pli, pu8(bmap), nhsb*4,
+                            fw - 7, fh - 5)
+        assert np.array_equal(ctx.download_recon(0, pli), out), (pli, int(np.abs(c).max()))
+        if amp >= 60000:
+            assert np.abs(c).max() > 40000          # the escape path was exercised
+    ctx.close()
+
+
 def test_full_size_1080p_roundtrip_and_sampled_oracle(hip):
     """BASELINE config 2 geometry (1920x1080 4:2:0, padded to 1920x1088): the
     size-independent property forward(known) -> inverse == identity on the whole
