@@ -262,6 +262,42 @@ inline double host_gain_compand(double g, int q0, double beta) {
   if (beta == 1) return g/q0;
   return PVQ_COMPAND_SCALE*pow(g*(1./PVQ_COMPAND_SCALE), 1./beta)/q0;
 }
+
+inline bool pvq_sort_enabled() {
+  static const int on = getenv("OD_HIP_PVQ_SORT") ? atoi(getenv("OD_HIP_PVQ_SORT")) : 1;
+  return on != 0;
+}
+
+// Work-balancing order of the blocks of one band (performance only, any permutation is
+// correct): descending K of the larger gain candidate (counting sort), so that the lane slots
+// of a wave - which runs until its slowest band is done - hold similar K and the long
+// searches start first.  K as pvq_k_noref (src/pvq.c:508-514).
+inline void pvq_block_order(const double *cg, long first, long count, int n, double beta, bool sort,
+                            int32_t *perm) {
+  if (!sort) {
+    for (long i = 0; i < count; i++) perm[i] = (int32_t)(first + i);
+    return;
+  }
+  std::vector<uint8_t> key(count);
+  long hist[257];
+  for (int i = 0; i < 257; i++) hist[i] = 0;
+  const double sq = sqrt((double)((n + 3)/2));
+  for (long i = 0; i < count; i++) {
+    int k = 0;
+    if (cg[i] > 0) {
+      const double q = ceil(cg[i]) < 1 ? 1 : ceil(cg[i]);
+      if (n == 15 && q == 1 && beta > 1.25) k = 1;
+      else {
+        const double v = floor(.5 + (q - .2)*sq/beta);
+        k = v < 1 ? 1 : v > 255 ? 255 : (int)v;
+      }
+    }
+    key[i] = (uint8_t)(255 - k);
+    hist[key[i] + 1]++;
+  }
+  for (int i = 0; i < 256; i++) hist[i + 1] += hist[i];
+  for (long i = 0; i < count; i++) perm[hist[key[i]]++] = (int32_t)(first + i);
+}
 }  // namespace
 
 extern "C" {
@@ -598,7 +634,7 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
     if (ctx->bskip[p]) (void)hipFree(ctx->bskip[p]);
     for (int l = 0; l < 4; l++) {
       PvqSoA &o = ctx->pvq[p][l];
-      void *ptrs[] = {o.cg, o.g, o.cos_dist, o.dist, o.qg, o.k, o.ncand, o.y};
+      void *ptrs[] = {o.cg, o.g, o.cos_dist, o.dist, o.qg, o.k, o.ncand, o.y, o.perm_rw};
       for (void *q : ptrs) if (q) (void)hipFree(q);
     }
   }
@@ -955,6 +991,7 @@ int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, cons
     HIPCHK(hipMalloc((void **)&o.k, ns*2*nrec*4));
     HIPCHK(hipMalloc((void **)&o.ncand, ns*nrec*4));
     HIPCHK(hipMalloc((void **)&o.y, ns*ny*4));
+    HIPCHK(hipMalloc((void **)&o.perm_rw, ns*nrec*4));
     ctx->pvq_alloc[pli][level] = true;
   }
   // one QM copy per (plane, level): kernels of earlier calls may still be running on the
@@ -980,6 +1017,7 @@ int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, cons
   a.out.qg = o.qg + slot0*2*nrec;
   a.out.k = o.k + slot0*2*nrec;
   a.out.y = o.y + slot0*ny;
+  a.out.perm = o.perm_rw + slot0*nrec;          // written by the companding stage (od_hip_pvq_compand_level / feed)
   // the strip's blocks of this level: block rows are superblock rows times 32/n (luma units)
   {
     const int per_sb = (32 >> ctx->geo.xdec[pli])/n;
@@ -1067,16 +1105,22 @@ int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, in
     }
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> perm(tot);
+  const bool whole = ctx->strip0 == 0 && ctx->strip1 == ctx->nvsb && pvq_sort_enabled();
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
       const size_t o = ((size_t)s*c.a.nbands + b)*per;
       for (size_t i = 0; i < per; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
+      pvq_block_order(cg.data() + o, first, count, c.a.off[b + 1] - c.a.off[b], beta[b], whole, perm.data() + o);
     }
   }
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
       HIPCHK(hipMemcpyAsync(c.a.out.cg + (size_t)s*c.nrec + (size_t)b*c.nblk + first,
                             cg.data() + ((size_t)s*c.a.nbands + b)*per, per*8,
+                            hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(c.o->perm_rw + (size_t)(slot0 + s)*c.nrec + (size_t)b*c.nblk + first,
+                            perm.data() + ((size_t)s*c.a.nbands + b)*per, per*4,
                             hipMemcpyHostToDevice, ctx->stream));
     }
   }

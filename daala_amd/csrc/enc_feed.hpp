@@ -27,6 +27,7 @@ struct od_hip_enc_feed {
     double beta[11];
     // pinned host mirrors, all slots: [slot][...]
     int32_t *ncand = nullptr, *k = nullptr, *qg = nullptr, *y = nullptr;
+    int32_t *perm = nullptr;              // pinned: block order of every band (host -> device)
     double *cos_dist = nullptr, *cg = nullptr, *g = nullptr;
     od_coeff *plane = nullptr;            // [slot][h][w] the pyramid level itself
   } lev[4];
@@ -40,6 +41,7 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
   if (f->copy) (void)hipStreamSynchronize(f->copy);
   for (auto &l : f->lev) {
     if (l.ncand) (void)hipHostFree(l.ncand);
+    if (l.perm) (void)hipHostFree(l.perm);
     if (l.k) (void)hipHostFree(l.k);
     if (l.qg) (void)hipHostFree(l.qg);
     if (l.cg) (void)hipHostFree(l.cg);
@@ -94,6 +96,7 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
     L.nrec = (size_t)L.nb*L.nblk;
     L.ny = (size_t)2*L.nblk*(ncoded - 1);
     ok = ok && hipHostMalloc((void **)&L.ncand, ns*L.nrec*4) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&L.perm, ns*L.nrec*4) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.k, ns*2*L.nrec*4) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.qg, ns*2*L.nrec*4) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&L.cg, ns*L.nrec*8) == hipSuccess;
@@ -179,8 +182,12 @@ int od_hip_enc_feed_compand(od_hip_enc_feed *f, int slot) {
       const double beta = L.beta[b];
       const size_t o = (size_t)b*L.nblk;
       for (int i = 0; i < L.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
+      pvq_block_order(cg + o, 0, L.nblk, L.off[b + 1] - L.off[b], beta, pvq_sort_enabled(),
+                      L.perm + slot*L.nrec + o);
     }
     HIPCHK(hipMemcpyAsync(ctx->pvq[0][l].cg + slot*L.nrec, cg, L.nrec*8, hipMemcpyHostToDevice, f->up));
+    HIPCHK(hipMemcpyAsync(ctx->pvq[0][l].perm_rw + slot*L.nrec, L.perm + slot*L.nrec, L.nrec*4,
+                          hipMemcpyHostToDevice, f->up));
   }
   HIPCHK(hipEventRecord(f->cgup[slot], f->up));
   f->companded[slot] = 1;

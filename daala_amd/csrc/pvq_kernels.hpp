@@ -154,6 +154,11 @@ struct PvqSoA {
   int32_t *ncand;           // [nbands*nblk]
   // pulses: band b occupies y + 2*nblk*(off[b]-1), laid out [cand][block][n_b]
   int32_t *y;
+  // work-balancing order (performance only): perm[band*nblk + i] = the block the i-th lane
+  // slot of that band processes; written by the host with the companded gains, which fix
+  // every K.  nullptr: blocks in raster order.
+  const int32_t *perm;
+  int32_t *perm_rw;         // host side: the allocation perm points into (all slots)
 };
 
 struct PvqLevelArgs {
@@ -481,11 +486,21 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
   __shared__ int32_t Org[64];
   const int lane = threadIdx.x;
   const int g = lane%G, inst = lane/G;
-  const long blk0 = a.blk_first + (long)blockIdx.x*BPW;
-  const long blk = blk0 + inst;
+  __shared__ int32_t Pb[64];                        // the blocks of this wave's lane slots
+  const long idx0 = a.blk_first + (long)blockIdx.x*BPW;
   const int band = a.band_list[blockIdx.y], f = blockIdx.z;
   const long nblk = (long)a.nbx*a.nby;
-  const bool live = blk < a.blk_end;
+  // Waves run until their slowest band is done (trip count = max K of the wave), so the
+  // host orders the blocks of every band by K: neighbouring lane slots get similar K.
+  const int32_t *perm = (!GAIN_ONLY && a.out.perm) ? a.out.perm + (size_t)f*a.rec_fstride + (size_t)band*nblk : nullptr;
+  if (lane < BPW) {
+    const long i = idx0 + lane;
+    Pb[lane] = i < a.blk_end ? (perm ? perm[i] : (int32_t)i) : -1;
+  }
+  __syncthreads();
+  const bool live = idx0 + inst < a.blk_end;
+  const long blk = live ? Pb[inst] : 0;
+  const long blk0 = idx0;
   const int o0 = a.off[band];
   const int q0 = a.q[band];
   const double beta = a.beta[band];
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     const int32_t *plane = a.lev + (size_t)f*a.lev_fstride;
     const int nb_here = (int)(a.blk_end - blk0 < BPW ? a.blk_end - blk0 : BPW);
     if (lane < nb_here) {                          // block origins: one division per block
-      const long bb = blk0 + lane;
+      const long bb = Pb[lane];
       const int bx = bb%a.nbx, by = bb/a.nbx;
       Org[lane] = (by*a.n)*a.w + bx*a.n;
     }
@@ -590,10 +605,14 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     }
     __syncthreads();
     {
-      int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) +
-                    ((size_t)c*nblk + blk0)*N;
+      // [cand][block][N]: every block's N pulses are one contiguous run (whole runs of
+      // neighbouring blocks when the order is the raster order)
+      int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) + (size_t)c*nblk*N;
       const long lim = (a.blk_end - blk0 < BPW ? a.blk_end - blk0 : BPW)*N;
-      for (int e = lane; e < lim; e += 64) yo[e] = Yst[e];
+      for (int e = lane; e < lim; e += 64) {
+        const int b = e/N;
+        yo[(size_t)Pb[b]*N + (e - b*N)] = Yst[e];
+      }
     }
     __syncthreads();
   }
