@@ -44,7 +44,7 @@ c_int32 = ctypes.c_int32
 class Params(ctypes.Structure):
     _fields_ = [('pic_width', c_int32), ('pic_height', c_int32), ('quant', c_int32),
                 ('complexity', c_int32), ('masking', c_int32), ('nworkers', c_int32),
-                ('check', c_int32), ('batch', c_int32)]
+                ('check', c_int32), ('batch', c_int32), ('keyframe_rate', c_int32)]
 
 
 class Stats(ctypes.Structure):

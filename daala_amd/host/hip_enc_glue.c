@@ -405,7 +405,7 @@ static daala_enc_ctx *make_encoder(const od_hipenc_params *p, int w, int h) {
   di.frame_duration = 1;
   di.pixel_aspect_numerator = di.pixel_aspect_denominator = 1;
   di.bitdepth_mode = OD_BITDEPTH_MODE_8;
-  di.keyframe_rate = 1;
+  di.keyframe_rate = p->keyframe_rate > 1 ? p->keyframe_rate : 1;
   enc = daala_encode_create(&di);
   if (enc == NULL) return NULL;
   v = p->quant;
@@ -602,10 +602,12 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
      only history a keyframe packet carries is the golden-frame flag
      (ip_frame_count % OD_GOLDEN_FRAME_INTERVAL, forced on while no golden
      reference exists; src/encode.c:2958-2963, :3023). */
-  enc->ip_frame_count = (int)(J->frame0 + f);
-  if (J->frame0 + f > 0 && enc->state.ref_imgi[OD_FRAME_GOLD] < 0) {
-    enc->state.ref_imgi[OD_FRAME_GOLD] = 0;
-    enc->state.ref_imgi[OD_FRAME_PREV] = 0;
+  if (S->p.keyframe_rate <= 1) {
+    enc->ip_frame_count = (int)(J->frame0 + f);
+    if (J->frame0 + f > 0 && enc->state.ref_imgi[OD_FRAME_GOLD] < 0) {
+      enc->state.ref_imgi[OD_FRAME_GOLD] = 0;
+      enc->state.ref_imgi[OD_FRAME_PREV] = 0;
+    }
   }
   fill_img(&img, J->frames + S->frame_bytes*f, S->p.pic_width, S->p.pic_height);
   T.enc = enc;
@@ -829,6 +831,7 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
   S->use_device = use_device;
   S->device = device;
   nw = p->nworkers < 1 ? 1 : p->nworkers;
+  if (p->keyframe_rate > 1) nw = 1;       /* inter frames depend on their predecessors */
   S->nw = nw;
   cw = (p->pic_width + 1) >> 1;
   ch = (p->pic_height + 1) >> 1;
@@ -1064,6 +1067,33 @@ long od_hipenc_encode_frames(const od_hipenc_params *p, int nframes,
   n = od_hipenc_encode(S, nframes, 0, frames, views, pkt_out, pkt_cap, stats);
   od_hipenc_close(S);
   return n;
+}
+
+/* Test hook: an adaptation context for the rate-coder parity test.  seed 0: the state
+   od_adapt_ctx_reset leaves for a keyframe; otherwise that state with the PVQ codeword
+   adaptation (pvq_adapt, pvq_k1_cdf) driven away from it the way coding does. */
+const od_adapt_ctx *od_hipenc_test_adapt(unsigned seed) {
+  static __thread od_state st;
+  int i;
+  int j;
+  memset(&st.adapt, 0, sizeof(st.adapt));
+  st.info.nplanes = 3;
+  od_adapt_ctx_reset(&st.adapt, 1);
+  if (seed != 0) {
+    od_pvq_codeword_ctx *cw;
+    cw = &st.adapt.pvq.pvq_codeword_ctx;
+    for (i = 0; i < 2*OD_NBSIZES*OD_NSB_ADAPT_CTXS; i++) {
+      seed = seed*1664525u + 1013904223u;
+      cw->pvq_adapt[i] = 1 + (int)((seed >> 8)%(i & 1 ? 200000u : 60000u));
+    }
+    for (i = 0; i < 4; i++) {
+      for (j = 0; j < 16; j++) {
+        seed = seed*1664525u + 1013904223u;
+        cw->pvq_k1_cdf[i][j] = (uint16_t)((j ? cw->pvq_k1_cdf[i][j - 1] : 0) + 1 + (seed >> 20)%900u);
+      }
+    }
+  }
+  return &st.adapt;
 }
 
 /* The padded input planes daala_encode_img_in() codes for one frame (the

@@ -22,6 +22,9 @@ typedef struct od_hipenc_params {
   int32_t nworkers;                /* host threads, one reference encoder context each */
   int32_t check;                   /* OD_CHECKGPU: run the C search as well and compare */
   int32_t batch;                   /* frame slots resident on the device (0: default) */
+  int32_t keyframe_rate;           /* 0 or 1: every frame a keyframe (frames independent: N workers);
+                                      > 1: inter frames between keyframes - ONE worker codes the
+                                      stream in order (nworkers is forced to 1) */
 } od_hipenc_params;
 
 typedef struct od_hipenc_stats {

@@ -285,3 +285,23 @@ def test_lossless_frames_through_both_seams():
     assert n0 == nf and n2 == nf and ds > 0
     assert np.array_equal(got, want)
     assert np.array_equal(got.ravel(), buf)                # lossless: the input itself
+
+
+def test_inter_stream_encoded_through_the_seam():
+    """configs[3] on the ENCODER side: a session with keyframe_rate 4 (one worker, frames in
+    order).  Keyframes take the device feed, deringing and distortions as usual; every P frame's
+    od_state_mc_predict calls (od_mv_est evaluates predictions through it, src/mcenc.c, and
+    od_predict_frame forms the final one, src/encode.c:2219) run on the device in check mode.
+    The packets must equal the pure reference encoder's inter stream."""
+    from test_hipenc_cpu import inter_stream
+    w, h, nf = 176, 144, 5
+    want, rec = inter_stream(w, h, nf, keyrate=4)
+    base = [synth_plane(w + 64, h + 64, 31), synth_plane(w//2 + 32, h//2 + 32, 32, 1),
+            synth_plane(w//2 + 32, h//2 + 32, 33, 1)]
+    frames = [[base[0][2*f:2*f + h, 3*f:3*f + w], base[1][f:f + h//2, (3*f)//2:(3*f)//2 + w//2],
+               base[2][f:f + h//2, (3*f)//2:(3*f)//2 + w//2]] for f in range(nf)]
+    buf = H.pack_frames(frames, w, h)
+    prm = H.Params(w, h, 20, 7, 1, 3, 1, 0, 4)
+    n, pk, st = H.encode(prm, buf, nf, use_device=1)
+    assert n > 0 and pk == want
+    assert st.pvq_check_fail == 0 and st.check_fail == 0

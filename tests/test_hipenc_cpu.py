@@ -277,3 +277,40 @@ def test_inter_stream_through_the_decoder_driver_host_path():
     nd, out, sec, dsec = H.decode(prm, H.headers(prm), pk)
     assert nd == nf
     assert np.array_equal(out[-1], rec)
+
+
+def test_rate_only_coder_equals_reference_od_pvq_rate():
+    """od_hip_pvq_rate (hip_pvq_host.c: the (rng, bit count) recurrence alone) against the
+    reference's od_pvq_rate (trial coding into a real range encoder) on random pulse vectors,
+    sizes, K and adaptation states - including states far from the initial one."""
+    lib = H.hipenc()
+    I32P = ctypes.POINTER(ctypes.c_int32)
+    for f in (lib.od_hip_pvq_rate, lib.od_ref_pvq_rate):
+        f.restype = ctypes.c_double
+        f.argtypes = [ctypes.c_int]*4 + [ctypes.c_void_p, I32P] + [ctypes.c_int]*5
+    lib.od_hipenc_test_adapt.restype = ctypes.c_void_p
+    lib.od_hipenc_test_adapt.argtypes = [ctypes.c_uint]
+    rng = np.random.default_rng(11)
+    checked = 0
+    for trial in range(6000):
+        adapt = lib.od_hipenc_test_adapt(int(rng.integers(0, 1 << 31)) if trial % 3 else 0)
+        bs = int(rng.integers(0, 4))
+        noref = int(rng.integers(0, 2))
+        n = int(rng.choice([8, 15, 32, 128]))
+        k = int(rng.choice([1, 1, 2, 3, 5, 9, 20, 60, 200]))
+        nn = n - (0 if noref else 1)
+        y = np.zeros(n, np.int32)
+        pos = rng.integers(0, nn, size=k) if trial % 5 else rng.integers(0, max(1, nn//4), size=k)
+        for p in pos:
+            y[p] += 1
+        y *= rng.choice([-1, 1], size=n).astype(np.int32)
+        theta = -1 if noref else int(rng.integers(0, 6))
+        qg = int(rng.integers(0, 4))
+        icgr = int(rng.integers(0, 4))
+        ts = int(rng.integers(1, 12))
+        pli = int(rng.integers(0, 3))
+        a = lib.od_hip_pvq_rate(qg, icgr, theta, ts, adapt, y.ctypes.data_as(I32P), k, n, 1, pli, bs)
+        b = lib.od_ref_pvq_rate(qg, icgr, theta, ts, adapt, y.ctypes.data_as(I32P), k, n, 1, pli, bs)
+        assert a == b, (trial, n, k, noref, bs)
+        checked += 1
+    assert checked == 6000
