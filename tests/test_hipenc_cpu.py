@@ -314,3 +314,18 @@ def test_rate_only_coder_equals_reference_od_pvq_rate():
         assert a == b, (trial, n, k, noref, bs)
         checked += 1
     assert checked == 6000
+
+
+def test_inter_stream_encoded_by_the_driver_host_path():
+    """keyframe_rate > 1: one worker codes the stream in order; without a device the packets
+    of the integration library equal the pure reference encoder's inter stream."""
+    w, h, nf = 176, 144, 5
+    want, rec = inter_stream(w, h, nf, keyrate=4)
+    base = [synth_plane(w + 64, h + 64, 31), synth_plane(w//2 + 32, h//2 + 32, 32, 1),
+            synth_plane(w//2 + 32, h//2 + 32, 33, 1)]
+    frames = [[base[0][2*f:2*f + h, 3*f:3*f + w], base[1][f:f + h//2, (3*f)//2:(3*f)//2 + w//2],
+               base[2][f:f + h//2, (3*f)//2:(3*f)//2 + w//2]] for f in range(nf)]
+    buf = H.pack_frames(frames, w, h)
+    prm = H.Params(w, h, 20, 7, 1, 3, 0, 0, 4)          # 3 workers asked for, 1 used
+    n, pk, st = H.encode(prm, buf, nf)
+    assert n > 0 and pk == want
