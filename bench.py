@@ -116,6 +116,18 @@ KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel nam
 }
 
 
+def kernel_sources_sha():
+    """sha256 over the device sources: committed profiles carry the value of the build they
+    measured, so a profile older than the kernels is flagged instead of quoted silently."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'daala_amd', 'csrc', '*'))):
+        if os.path.isfile(f) and not f.endswith('.so'):
+            h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def measured_pmc(names):
     """SQ counter figures of the PVQ search kernels from the newest committed PMC profile
     (profiles/*_pmc.json, tools/pmc_round.sh + tools/summarize_pmc.py): VALU instructions per
@@ -125,8 +137,10 @@ def measured_pmc(names):
     if not files:
         return None
     with open(files[-1]) as f:
-        t = json.load(f)['kernels']
-    out = {'source': os.path.basename(files[-1])}
+        doc = json.load(f)
+    t = doc['kernels']
+    out = {'source': os.path.basename(files[-1]),
+           'stale': doc.get('kernel_sources_sha') != kernel_sources_sha()}
     for label, sym in names.items():
         for k, v in t.items():
             if sym in k:
@@ -150,7 +164,8 @@ def measured_traffic(label):
     for name, v in t['kernels'].items():
         if KERNEL_SYMBOL.get(label, '\0') in name:
             return {'hbm_bytes_per_launch': int(v['hbm_bytes']), 'fetch_bytes': int(v['fetch_bytes']),
-                    'write_bytes': int(v['write_bytes']), 'source': os.path.basename(files[-1])}
+                    'write_bytes': int(v['write_bytes']), 'source': os.path.basename(files[-1]),
+                    'stale': t.get('kernel_sources_sha') != kernel_sources_sha()}
     return None
 
 
@@ -277,6 +292,24 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
                                                    'k_pvq_noref<32>': 'k_pvq_noref_v3<32, false>',
                                                    'k_pvq_noref<15>': 'k_pvq_noref_v3<15, false>',
                                                    'k_pvq_noref<8>': 'k_pvq_noref_v3<8, false>'})}
+    if 'pvq' in out:
+        # Algorithmic FP64 work of the searches (device counters, one extra untimed step):
+        # element steps of the greedy scans (add, add, add, mul, 2 mul + compare per element:
+        # 6 flops, src/pvq_encoder.c:173-183) and of the RDO scans (7 flops, :204-215); the
+        # per-candidate set-up (norms, projection) is not counted.  Peak: FP64 vector rate of
+        # the chip = half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md.
+        ctx.pvq_stats(1)
+        for pli, level, q, beta, qm in lvl:
+            ctx.pvq_search(pli, level, qm, q, beta, 0, FRAMES)
+        ctx.sync()
+        gs, rs, nc = ctx.pvq_stats(0)
+        flops = 6*gs + 7*rs
+        t_s = out['pvq']['ms_per_step']*1e-3
+        out['pvq']['roofline'] = {'bound': 'valu_fp64', 'achieved': round(flops/t_s/1e12, 3), 'peak': 78.65,
+                                  'unit': 'TFLOP/s', 'frac': round(flops/t_s/1e12/78.65, 5),
+                                  'algorithmic_flops_per_step': int(flops),
+                                  'greedy_element_steps': int(gs), 'rdo_element_steps': int(rs),
+                                  'candidates_searched': int(nc)}
     if world == 1:
         # the decoder's pixel-domain tail on the same 30 frames (iDCT + post-filters +
         # deringing on every superblock + smoothing + clamp)

@@ -410,6 +410,14 @@ class DaalaHip(object):
         self.lib.od_hip_gather_strips.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_int, I32P, c_int]
         _chk(self.lib.od_hip_gather_strips(self.ctx, comm.h, slot, _p32(rows), int(with_pvq)))
 
+    def pvq_stats(self, enable):
+        """Device work counters of the searches (greedy element steps, RDO element steps,
+        candidates); enable=1 restarts them, 0 reads and stops."""
+        out = (ctypes.c_ulonglong*3)()
+        self.lib.od_hip_pvq_stats.argtypes = [ctypes.c_void_p, c_int, ctypes.POINTER(ctypes.c_ulonglong)]
+        _chk(self.lib.od_hip_pvq_stats(self.ctx, int(enable), out))
+        return [int(v) for v in out]
+
     def pvq_nblocks(self, pli, level):
         return _chk(self.lib.od_hip_pvq_nblocks(self.ctx, pli, level))
 

@@ -172,6 +172,7 @@ struct od_hip_ctx {
   // strip window (od_hip_set_strip): superblock rows [strip0, strip1) are computed by the
   // forward pyramid and the PVQ passes; the whole frame by default
   int strip0 = 0, strip1 = 0;
+  unsigned long long *pvq_stats = nullptr;   // od_hip_pvq_stats: device work counters (measurement)
 };
 
 namespace {
@@ -243,7 +244,7 @@ int check_slots(od_hip_ctx *ctx, int slot0, int nslots, bool join = true) {
 namespace {
 template <int N>
 void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk_unused, int nslots, hipStream_t s,
-                bool gain_only, const double *rsq) {
+                bool gain_only, const double *rsq, unsigned long long *stats) {
   constexpr int BPW = PvqGeom<N>::BPW;
   const long nblk = a.blk_end - a.blk_first;
   if (nblk <= 0) return;
@@ -251,6 +252,7 @@ void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk_unused, int nslots, 
   PvqLevelArgs3 aa;
   aa.a = a;
   aa.rsq = rsq;
+  aa.stats = stats;
   dim3 grid((unsigned)((nblk + BPW - 1)/BPW), nlist, nslots);
   if (gain_only) hipLaunchKernelGGL((k_pvq_noref_v3<N, true>), grid, dim3(64), 0, s, aa);
   else hipLaunchKernelGGL((k_pvq_noref_v3<N, false>), grid, dim3(64), 0, s, aa);
@@ -639,6 +641,7 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
     }
   }
   for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
+  if (ctx->pvq_stats) (void)hipFree(ctx->pvq_stats);
   if (ctx->bsize) (void)hipFree(ctx->bsize);
   if (ctx->dflags) (void)hipFree(ctx->dflags);
   for (int i = 0; i < od_hip_ctx::NAUX; i++) {
@@ -1062,16 +1065,40 @@ int pvq_launch(od_hip_ctx *ctx, PvqCall &c, int nslots, bool gain_only) {
                                   : sizes[si] == 32 ? "k_pvq_noref<32>" : "k_pvq_noref<128>");
     Timed tm(ctx, nm, ls);
     switch (sizes[si]) {
-      case 15: launch_pvq<15>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
-      case 8: launch_pvq<8>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
-      case 32: launch_pvq<32>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
-      default: launch_pvq<128>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq); break;
+      case 15: launch_pvq<15>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq, gain_only ? nullptr : ctx->pvq_stats); break;
+      case 8: launch_pvq<8>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq, gain_only ? nullptr : ctx->pvq_stats); break;
+      case 32: launch_pvq<32>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq, gain_only ? nullptr : ctx->pvq_stats); break;
+      default: launch_pvq<128>(a, nlist, c.nblk, nslots, ls, gain_only, ctx->rsq, gain_only ? nullptr : ctx->pvq_stats); break;
     }
     HIPCHK(hipGetLastError());
   }
   return 0;
 }
 }  // namespace
+
+// Measurement: enable = 1 allocates/zeroes three device counters that every following search
+// launch of this context adds to; the call returns their current values (element steps of the
+// greedy scans, of the RDO scans, candidates searched); enable = 0 stops counting.
+int od_hip_pvq_stats(od_hip_ctx *ctx, int enable, unsigned long long out[3]) {
+  if (int rc = check_slots(ctx, 0, 1)) return rc;
+  if (out) {
+    out[0] = out[1] = out[2] = 0;
+    if (ctx->pvq_stats) {
+      HIPCHK(hipMemcpyAsync(out, ctx->pvq_stats, 24, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  if (enable) {
+    if (!ctx->pvq_stats) HIPCHK(hipMalloc((void **)&ctx->pvq_stats, 24));
+    HIPCHK(hipMemsetAsync(ctx->pvq_stats, 0, 24, ctx->stream));
+  }
+  else if (ctx->pvq_stats) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->pvq_stats);
+    ctx->pvq_stats = nullptr;
+  }
+  return 0;
+}
 
 int od_hip_pvq_compand(int count, const double *g, int q0, double beta, double *cg) {
   if (!g || !cg) return fail(OD_HIP_EFAULT, "null pointer");

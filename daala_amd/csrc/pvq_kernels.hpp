@@ -282,7 +282,8 @@ __device__ __forceinline__ void pvq_vec_finish(PvqVec<N> &v, int g, int lane) {
 template <int N>
 __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int lane, int k,
                                                 double g2, const double *rsq,
-                                                int (&y)[PvqGeom<N>::NL]) {
+                                                int (&y)[PvqGeom<N>::NL], int &npulse_greedy,
+                                                int &npulse_rdo) {
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL;
   const int base = (lane/G)*G;                  // first lane of my band
   const int nvalid = (N - g*NL) < NL ? (N - g*NL) : NL;
@@ -404,6 +405,7 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
         for (int j = 0; j < NL; j++) y[j] += (j == wl);
       }
       i++;
+      npulse_greedy++;
     }
   }
   // ---- RDO phase -------------------------------------------------------------
@@ -458,6 +460,7 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
         for (int j = 0; j < NL; j++) y[j] += (j == wl);
       }
       i++;
+      npulse_rdo++;
     }
   }
   return xy/(1e-100 + sqrt(v.xx*yy));
@@ -466,6 +469,10 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
 struct PvqLevelArgs3 {
   PvqLevelArgs a;
   const double *rsq;
+  // optional work counters (measurement only): [0] pulses placed by greedy scans x N,
+  // [1] pulses placed by RDO scans x N, [2] candidates searched - the algorithmic element
+  // steps of pvq_search_rdo_double (src/pvq_encoder.c:166-220), summed over the launch
+  unsigned long long *stats;
 };
 
 // No-reference candidates (state-free part of pvq_theta, src/pvq_encoder.c:352-357,
@@ -588,7 +595,13 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     const double qcg = gi;
     const int k = has ? pvq_k_noref(qcg, N, beta) : 0;
     int y[NL];
-    const double cd = pvq_search_v3<N>(v, g, lane, k, qcg*cg, aa.rsq, y);
+    int npg = 0, npr = 0;
+    const double cd = pvq_search_v3<N>(v, g, lane, k, qcg*cg, aa.rsq, y, npg, npr);
+    if (aa.stats && has && g == 0) {
+      atomicAdd(&aa.stats[0], (unsigned long long)npg*N);
+      atomicAdd(&aa.stats[1], (unsigned long long)npr*N);
+      atomicAdd(&aa.stats[2], 1ull);
+    }
     if (live && g == 0) {
       a.out.qg[c*a.rec_fstride + rec2] = has ? gi : 0;
       a.out.k[c*a.rec_fstride + rec2] = k;

@@ -247,6 +247,12 @@ int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, in
 int od_hip_pvq_search(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level,
  const int16_t *qm, const int32_t *q, const double *beta);
 int od_hip_pvq_compand(int count, const double *g, int q0, double beta, double *cg);
+/* Measurement only: algorithmic work of the searches.  enable = 1 zeroes three device
+ * counters that every following search launch of the context adds to and returns their
+ * previous values in out: [0] element steps of the greedy scans (pulses placed x band size,
+ * src/pvq_encoder.c:166-188), [1] of the RDO scans (:193-220), [2] candidates searched;
+ * enable = 0 reads them and stops counting. */
+int od_hip_pvq_stats(od_hip_ctx *ctx, int enable, unsigned long long out[3]);
 
 /* Number of blocks of that level in one frame; the y array of one slot holds
  * nblocks * 2 * ncoded int32 (ncoded = min(n*n, 512)), block-major, then

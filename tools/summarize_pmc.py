@@ -48,8 +48,11 @@ for k, d in sorted(allc.items()):
         e['kernel_cycles'] = cyc
         e['valu_pipe_utilisation'] = d['SQ_ACTIVE_INST_VALU']*4/(NSIMD*cyc)
     out[k] = e
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha        # noqa: E402
 with open(os.path.join(ROOT, 'profiles', tag + '_pmc.json'), 'w') as f:
-    json.dump({'what': __doc__, 'kernels': out}, f, indent=1, sort_keys=True)
+    json.dump({'what': __doc__, 'kernel_sources_sha': kernel_sources_sha(), 'kernels': out}, f, indent=1,
+              sort_keys=True)
 for k, e in out.items():
     print('%-52s' % k[:52], ' '.join('%s=%.3g' % (n, e[n]) for n in
           ('valu_per_wave', 'valu_active_of_wave', 'parked_of_wave', 'valu_pipe_utilisation') if n in e))

@@ -49,6 +49,9 @@ for k in sorted(fetch):
     wb = write.get(k, [0])[-1]*1024*w_int4
     out['kernels'][k] = {'fetch_bytes': fb, 'write_bytes': wb, 'hbm_bytes': fb + wb,
                          'fetch_counter_kib': fetch[k][-1], 'write_counter_kib': write.get(k, [0])[-1]}
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha        # noqa: E402
+out['kernel_sources_sha'] = kernel_sources_sha()     # bench.py flags a profile older than the kernels
 with open(os.path.join(dst, tag + '_traffic.json'), 'w') as f:
     json.dump(out, f, indent=1, sort_keys=True)
 st = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
