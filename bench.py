@@ -473,10 +473,13 @@ def main():
                     'upload_phase_s': round(st.t_upload_s, 4), 'device_launch_phase_s': round(st.t_launch_s, 4),
                     'last_step_s': round(st.t_total_s, 4), 'session_setup_s': round(st.t_setup_s, 3)},
         }
-    if world == 1 and rank == 0:
+    if rank == 0:
+        # the kernel-level section (roofline of the dominant HBM-bound kernel, PVQ counters):
+        # rank 0's GPU, after the timed region; at N > 1 the other ranks are done by now
         ds, roofline = device_step(local_rank, frames, rank, args.device_steps, 2, args.skip_pvq, world)
         line['roofline'] = roofline
         line['device_step'] = ds
+    if world == 1 and rank == 0:
         if not args.no_cpu_baseline:
             nref = 10                # ~14 s of single-core work (the contract asks for 10-30 s)
             ref = reference_packets(frames, nref)
