@@ -20,6 +20,7 @@ def main():
     total = dict(dev_hits=0, g2=0, fdct=0)
     cases = [(1280, 720, q, m, s) for q in (3, 10, 20, 45, 100, 250) for m in (0, 1) for s in (0,)]
     cases += [(w, h, 20, 1, 7) for (w, h) in ((1920, 1080), (720, 576), (854, 480), (98, 50))]
+    cases += [(640, 360, 0, 1, 3)]                      # lossless
     for (w, h, q, m, seed) in cases:
         cw, ch = (w + 1)//2, (h + 1)//2
         nf = 4
@@ -32,7 +33,8 @@ def main():
         hdr = H.headers(prm)
         _, p0, _, _ = H.decode(prm, hdr, want)
         _, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
-        ok = (n == n0 and got == want and st.check_fail == 0 and st.lost_sync == 0
+        ok = (n == n0 and got == want and st.check_fail == 0 and st.lost_sync == 0 and st.pvq_check_fail == 0
+              and st.g2_mismatch == 0 and st.dist_check_fail == 0
               and st.fdct_check_fail == 0 and st.dering_check_fail == 0 and st.dering_dev_sbs > 0
               and np.array_equal(p0, p1))
         total['dev_hits'] += st.dev_hits
