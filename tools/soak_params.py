@@ -35,7 +35,8 @@ def main():
         _, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
         ok = (n == n0 and got == want and st.check_fail == 0 and st.lost_sync == 0 and st.pvq_check_fail == 0
               and st.g2_mismatch == 0 and st.dist_check_fail == 0
-              and st.fdct_check_fail == 0 and st.dering_check_fail == 0 and st.dering_dev_sbs > 0
+              and st.fdct_check_fail == 0 and st.dering_check_fail == 0
+              and (st.dering_dev_sbs > 0 if q > 0 else st.haar_hits > 0)
               and np.array_equal(p0, p1))
         total['dev_hits'] += st.dev_hits
         total['g2'] += st.g2_mismatch
