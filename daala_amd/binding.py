@@ -205,6 +205,27 @@ def od_mc_predict_blocks(refs, org_x, org_y, blocks, dst):
     return out
 
 
+class McPair(ctypes.Structure):
+    """od_hip_mc_pair (include/daala_hip.h)."""
+    _fields_ = [('sx', ctypes.c_int32), ('sy', ctypes.c_int32), ('rx', ctypes.c_int32),
+                ('ry', ctypes.c_int32), ('log_blk_sz', ctypes.c_int32), ('satd', ctypes.c_int32)]
+
+
+def od_mc_sad_pairs(src, ref, pairs):
+    """SAD / SATD of block pairs; pairs: iterable of (sx, sy, rx, ry, log_blk_sz, satd)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    arr = (McPair*len(pairs))(*[McPair(*[int(v) for v in p]) for p in pairs])
+    out = np.zeros(len(pairs), np.int32)
+    lib = load()
+    lib.od_hip_mc_sad_pairs.argtypes = [U8P, c_int, c_int, U8P, c_int, c_int, ctypes.POINTER(McPair),
+                                        c_int, I32P]
+    _chk(lib.od_hip_mc_sad_pairs(src.ctypes.data_as(U8P), src.shape[1], src.shape[0],
+                                 ref.ctypes.data_as(U8P), ref.shape[1], ref.shape[0], arr, len(pairs),
+                                 _p32(out)))
+    return out
+
+
 def od_coding_order_blocks(bs, blocks, to_raster=False, dst=None):
     """A11 gather (raster -> coding order) / scatter (coding order -> raster) of dense blocks."""
     x = _c32(blocks)

@@ -252,7 +252,7 @@ int od_hip_pvq_compand(int count, const double *g, int q0, double beta, double *
  * previous values in out: [0] element steps of the greedy scans (pulses placed x band size,
  * src/pvq_encoder.c:166-188), [1] of the RDO scans (:193-220), [2] candidates searched;
  * enable = 0 reads them and stops counting. */
-int od_hip_pvq_stats(od_hip_ctx *ctx, int enable, unsigned long long out[3]);
+int od_hip_pvq_stats(od_hip_ctx *ctx, int enable, uint64_t out[3]);
 
 /* Number of blocks of that level in one frame; the y array of one slot holds
  * nblocks * 2 * ncoded int32 (ncoded = min(n*n, 512)), block-major, then
@@ -434,6 +434,22 @@ typedef struct od_hip_mc_block {
 int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int ref_stride,
  int ref_h, int org_x, int org_y, const od_hip_mc_block *blocks, int nblocks,
  unsigned char *dst, int dst_stride, int dst_h);
+
+/* F3: the encoder's SAD / SATD table od_enc_opt_vtbl (src/encint.h:61-82; C entries
+ * od_mc_compute_sad8_NxN_c src/mcenc.c:1349-1372, od_mc_compute_satd8_NxN_c :1584-1660) for a
+ * list of block pairs: out[i] = SAD or SATD between the 2^log_blk_sz square block at (sx, sy)
+ * of the source plane and the one at (rx, ry) of the reference plane (a prediction or a
+ * reference frame), 8-bit samples.  Building block for a batched candidate evaluation; the
+ * reference's motion search itself (src/mcenc.c:6390) decides candidate by candidate and stays
+ * host code. */
+typedef struct od_hip_mc_pair {
+  int32_t sx, sy, rx, ry;
+  int32_t log_blk_sz;
+  int32_t satd;
+} od_hip_mc_pair;
+int od_hip_mc_sad_pairs(const unsigned char *src, int src_stride, int src_h,
+ const unsigned char *ref, int ref_stride, int ref_h, const od_hip_mc_pair *pairs, int npairs,
+ int32_t *out);
 
 /* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
  * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks

@@ -1455,3 +1455,64 @@ void orc_mc_predict(uint8_t *dst, int dystride, const uint8_t *const src[4], int
   if (s == 3) orc_mc_blend_full8(dst, dystride, p, log_xblk_sz, log_yblk_sz);
   else orc_mc_blend_full_split8(dst, dystride, p, oc, s, log_xblk_sz, log_yblk_sz);
 }
+
+/* ---------------------------------------------------------------------------------
+ * F3: SAD and SATD of a block pair (the C entries of od_enc_opt_vtbl, src/encint.h:61-82).
+ * orc_mc_sad8: sum |ref - src| over the block (od_mc_compute_sad8_c, src/mcenc.c:1333-1347).
+ * orc_mc_satd8: od_mc_compute_satd8 (src/mcenc.c:1464-1489): difference block, n-point
+ * Hadamard of rows then of columns (od_mc_hadamard_1d :1415-1461, sums in the low half and
+ * differences in the high half, recursing on both), sum of magnitudes, (sum + n/2) >> ln;
+ * 4x4 is one such transform and larger blocks are the sum over their 8x8 sub-blocks
+ * (od_mc_compute_sum_8x8_satd8 :1520-1539, entries :1562-1612). */
+int32_t orc_mc_sad8(const uint8_t *src, int systride, const uint8_t *ref, int rystride, int ln) {
+  int32_t sad = 0;
+  int n = 1 << ln;
+  int i, j;
+  for (i = 0; i < n; i++) {
+    for (j = 0; j < n; j++) sad += abs((int)ref[i*rystride + j] - (int)src[i*systride + j]);
+  }
+  return sad;
+}
+
+static void orc_hadamard_1d(int32_t *v, int step, int n) {
+  /* in place on v[0], v[step], ..., v[(n-1)*step] */
+  int32_t t[8];
+  int h = n >> 1;
+  int i;
+  if (n < 2) return;
+  for (i = 0; i < h; i++) {
+    t[i] = v[(2*i)*step] + v[(2*i + 1)*step];
+    t[h + i] = v[(2*i)*step] - v[(2*i + 1)*step];
+  }
+  for (i = 0; i < n; i++) v[i*step] = t[i];
+  orc_hadamard_1d(v, step, h);
+  orc_hadamard_1d(v + h*step, step, h);
+}
+
+static int32_t orc_satd_sub(const uint8_t *src, int systride, const uint8_t *ref, int rystride,
+                            int ln) {
+  int32_t w[64];
+  int n = 1 << ln;
+  int32_t sum = 0;
+  int i, j;
+  for (i = 0; i < n; i++) {
+    for (j = 0; j < n; j++) w[i*n + j] = (int32_t)src[i*systride + j] - (int32_t)ref[i*rystride + j];
+  }
+  for (i = 0; i < n; i++) orc_hadamard_1d(w + i*n, 1, n);
+  for (j = 0; j < n; j++) orc_hadamard_1d(w + j, n, n);
+  for (i = 0; i < n*n; i++) sum += abs(w[i]);
+  return (sum + (1 << ln >> 1)) >> ln;
+}
+
+int32_t orc_mc_satd8(const uint8_t *src, int systride, const uint8_t *ref, int rystride, int ln) {
+  int n = 1 << ln;
+  int32_t satd = 0;
+  int i, j;
+  if (ln == 2) return orc_satd_sub(src, systride, ref, rystride, 2);
+  for (i = 0; i < n; i += 8) {
+    for (j = 0; j < n; j += 8) {
+      satd += orc_satd_sub(src + i*systride + j, systride, ref + i*rystride + j, rystride, 3);
+    }
+  }
+  return satd;
+}

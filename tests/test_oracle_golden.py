@@ -225,3 +225,21 @@ def test_obmc_blocks_golden():
                          int(b[16]), int(b[17]), lx, ly)
         got[y:y + m, x:x + n] = out
     assert np.array_equal(got, dst)
+
+
+def test_sad_satd_pairs_golden():
+    """F3: the oracle's SAD / SATD (orc_mc_sad8, orc_mc_satd8) against the reference's C vtable
+    entries' outputs stored in tests/golden/mc_sad_pairs.npz (tools/gen_golden.py)."""
+    import ctypes
+    g = load('mc_sad_pairs.npz')
+    o = oracle()
+    src, rf = g['src'], g['ref']
+    W = src.shape[1]
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    o.orc_mc_sad8.restype = o.orc_mc_satd8.restype = ctypes.c_int32
+    got = []
+    for sx, sy, rx, ry, lg, satd in g['pairs']:
+        f = o.orc_mc_satd8 if satd else o.orc_mc_sad8
+        got.append(f(ctypes.cast(src.ctypes.data + int(sy)*W + int(sx), U8P), W,
+                     ctypes.cast(rf.ctypes.data + int(ry)*W + int(rx), U8P), W, int(lg)))
+    assert np.array_equal(np.array(got, np.int32), g['out'])

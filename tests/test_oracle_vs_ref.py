@@ -459,3 +459,33 @@ def test_obmc_block_prediction_matches_reference():
         o.orc_mc_predict(pu8(got), n, srcs, W, mvx.ctypes.data_as(I32P), mvy.ctypes.data_as(I32P),
                          oc, s, lx, ly)
         assert np.array_equal(got, want), (trial, lx, ly, oc, s)
+
+
+def test_sad_satd_match_reference():
+    """F3: orc_mc_sad8 / orc_mc_satd8 against the reference's od_mc_compute_sad8_NxN_c and
+    od_mc_compute_satd8_NxN_c (src/mcenc.c:1349-1372, :1562-1612), distinct strides, extreme and
+    near-identical content."""
+    o = oracle()
+    r = ref()
+    rng = np.random.default_rng(77)
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    o.orc_mc_sad8.restype = o.orc_mc_satd8.restype = ctypes.c_int32
+    for trial in range(600):
+        lg = int(rng.integers(2, 7))
+        n = 1 << lg
+        ss, rs = n + int(rng.integers(0, 9)), n + int(rng.integers(0, 9))
+        a = rng.integers(0, 256, size=(n, ss), dtype=np.uint8)
+        if trial % 3 == 0:
+            b = np.clip(a[:, :n].astype(np.int32) + rng.integers(-3, 4, size=(n, n)), 0, 255).astype(np.uint8)
+        elif trial % 3 == 1:
+            b = rng.integers(0, 256, size=(n, n), dtype=np.uint8)
+        else:
+            a[:] = 255*(rng.integers(0, 2, size=a.shape))
+            b = (255 - a[:, :n]).astype(np.uint8)
+        bb = np.zeros((n, rs), np.uint8)
+        bb[:, :n] = b
+        for kind, f in (('sad', o.orc_mc_sad8), ('satd', o.orc_mc_satd8)):
+            g = getattr(r, 'od_mc_compute_%s8_%dx%d_c' % (kind, n, n))
+            g.restype = ctypes.c_int32
+            want = g(a.ctypes.data_as(U8P), ss, bb.ctypes.data_as(U8P), rs)
+            assert f(a.ctypes.data_as(U8P), ss, bb.ctypes.data_as(U8P), rs, lg) == want, (trial, kind, n)

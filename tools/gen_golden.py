@@ -308,6 +308,33 @@ def mc_blocks():
     print('mc_blocks:', len(blocks), 'blocks')
 
 
+def mc_sad_pairs():
+    """F3: the reference's SAD / SATD C entries (od_mc_compute_sad8_NxN_c, od_mc_compute_satd8_NxN_c,
+    src/mcenc.c:1349-1372, :1562-1612) on a list of block pairs of two 160x128 planes."""
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    g = np.random.default_rng(5150)
+    W, H = 160, 128
+    src = synth_plane(W, H, 91)
+    rf = synth_plane(W, H, 92)
+    rf[40:90, 30:120] = np.clip(src[38:88, 33:123].astype(np.int32) + g.integers(-6, 7, size=(50, 90)), 0, 255)
+    rf[::7] = 255 - rf[::7]
+    pairs, want = [], []
+    for i in range(600):
+        lg = int(g.integers(2, 7))
+        n = 1 << lg
+        satd = int(g.integers(0, 2))
+        sx, sy = int(g.integers(0, W - n + 1)), int(g.integers(0, H - n + 1))
+        rx, ry = int(g.integers(0, W - n + 1)), int(g.integers(0, H - n + 1))
+        f = getattr(r, 'od_mc_compute_%s8_%dx%d_c' % ('satd' if satd else 'sad', n, n))
+        f.restype = ctypes.c_int32
+        want.append(f(ctypes.cast(src.ctypes.data + sy*W + sx, U8P), W,
+                      ctypes.cast(rf.ctypes.data + ry*W + rx, U8P), W))
+        pairs.append([sx, sy, rx, ry, lg, satd])
+    np.savez_compressed(os.path.join(G, 'mc_sad_pairs.npz'), src=src, ref=rf,
+                        pairs=np.array(pairs, np.int32), out=np.array(want, np.int32))
+    print('mc_sad_pairs:', len(pairs), 'pairs')
+
+
 def dcttest_md5():
     out = subprocess.run([os.path.join(ROOT, 'oracle', '_ref', 'dcttest')], capture_output=True)
     assert out.returncode == 0
@@ -330,6 +357,7 @@ if __name__ == '__main__':
     e2e_anchors()
     compute_dist_vectors()
     mc_blocks()
+    mc_sad_pairs()
     if '--dcttest' in sys.argv:
         dcttest_md5()
     print('golden fixtures written to', G)
