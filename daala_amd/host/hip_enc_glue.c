@@ -47,22 +47,24 @@ double od_hipenc_now(void) {
 #define now_s od_hipenc_now
 
 /* pvq_search_rdo_double as the reference's own pvq_theta calls it (inter frames, and the
-   reference's od_pvq_encode in check mode): the kept C search, timed. */
+   reference's od_pvq_encode in check mode).  Check mode keeps the reference's C search (it is
+   the checker there); otherwise vectors of 24 coefficients and more take the lane-wise search
+   of hip_pvq_search.c (bit-identical, tests/test_hipenc_cpu.py), shorter ones the C search. */
 double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypulse,
  double g2) {
   double t0;
   double r;
   T.st.cpu_other++;
+  t0 = T.time_cpu ? now_s() : 0;
+  if (n >= 24 && !T.check) r = od_hip_pvq_search_host(xcoeff, n, k, ypulse, g2);
+  else r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
   if (T.time_cpu) {
     double dt;
-    t0 = now_s();
-    r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
     dt = now_s() - t0;
     T.st.search_cpu_s += dt;
     T.st.search_class_s[(T.pli != 0)*2 + !(n == 15 || n == 8 || n == 32 || n == 128)] += dt;
-    return r;
   }
-  return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
+  return r;
 }
 
 /* for the bindings in hip_dec_glue.c that serve encoder threads too (od_dering,
@@ -687,6 +689,9 @@ static void *worker(void *arg) {
       T.fdct_cpu[i] = enc->state.opt_vtbl.fdct_2d[i];
       enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
     }
+    /* the motion search's per-block leaves (hip_mc_host.c) */
+    enc->state.opt_vtbl.mc_blend_full = od_hipenc_mc_blend_full8;
+    enc->state.opt_vtbl.mc_predict1fmv = od_hipenc_mc_predict1fmv8;
   }
   if (enc != NULL && S->ctx != NULL) {
     int xdec[3] = {0, 1, 1};

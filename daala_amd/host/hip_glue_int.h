@@ -51,9 +51,40 @@ void od_encode_rollback_cpu(daala_enc_ctx *enc, const od_rollback_buffer *rbuf);
 
 double od_hipenc_now(void);
 
-/* hip_pvq_search.c: pvq_search_rdo_double, four coefficients at a time, bit-identical */
+/* hip_pvq_search.c: pvq_search_rdo_double, bit-identical, for the many searches pvq_theta
+   makes of one vector (what does not depend on the candidate is computed once, the greedy
+   pulses once per distinct K) */
+#define OD_HIP_SEARCH_KCACHE (12)
+typedef struct od_hip_search {
+  double x[MAXN + 8] __attribute__((aligned(32)));   /* |x|, zero padded to a multiple of 4 */
+  const double *xcoeff;
+  double xx;
+  double norm_1;
+  double l1_inv;
+  int n;
+  int nv;
+  int have_l1;
+  int lanes;                   /* AVX2 lane scans (n >= 24) or the scalar scan */
+  int nk;
+  struct {
+    int k;
+    int placed;
+    double xy;
+    double yy;
+  } ka[OD_HIP_SEARCH_KCACHE];
+  int32_t ky[OD_HIP_SEARCH_KCACHE][MAXN + 8] __attribute__((aligned(32)));
+} od_hip_search;
+void od_hip_search_begin(od_hip_search *S, const double *xcoeff, int n);
+void od_hip_search_begin_ex(od_hip_search *S, const double *xcoeff, int n, int lanes);
+double od_hip_search_run(od_hip_search *S, int k, od_coeff *ypulse, double g2);
 double od_hip_pvq_search_host(const double *xcoeff, int n, int k, od_coeff *ypulse,
  double g2);
+
+/* hip_mc_host.c: od_state_opt_vtbl leaves of the motion search, host vector unit */
+void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned char *src[4],
+ int log_xblk_sz, int log_yblk_sz);
+void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsigned char *src,
+ int systride, int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz);
 
 /* hip_pvq_host.c */
 int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,

@@ -1,0 +1,256 @@
+/* hip_mc_host.c - the per-block leaves of the motion search that stay on the host.
+ *
+ * od_mv_est (src/mcenc.c:6390) decides candidate by candidate: every candidate vector of every
+ * grid point is judged by predicting the (at most four) blocks around it with OBMC and taking
+ * their SAD, and the next candidate depends on the outcome.  One such prediction is a few
+ * hundred pixels - far below what a kernel launch and a PCIe round trip cost - so inside the
+ * search the two leaves stay host code; whole-frame predictions (od_state_mc_predict, the
+ * frame the residual is taken from) go to the device (od_hip_mc_predict_blocks).
+ *
+ * A profile of two 1080p P frames on one worker puts 37 % of all host time in the blend and
+ * 20 % in the sub-pel predictor as the reference's scalar C compiles them, so both are bound
+ * through od_state_opt_vtbl (src/state.h:106-119) here with the host's vector unit, eight
+ * pixels at a time, same integer arithmetic:
+ *   od_hipenc_mc_blend_full8     replaces od_mc_blend_full8_c     (src/mc.c:352-377)
+ *   od_hipenc_mc_predict1fmv8    replaces od_mc_predict1fmv8_c    (src/mc.c:94-203)
+ */
+#include <immintrin.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "mc.h"
+
+#include "hip_glue_int.h"
+
+/* dst[i] = ((a << ly) + (b - a)*j + round) >> (lx + ly) with
+   a = (s0 << lx) + (s1 - s0)*i and b = (s3 << lx) + (s2 - s3)*i   (src/mc.c:364-376) */
+void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned char *src[4],
+ int log_xblk_sz, int log_yblk_sz) {
+  const unsigned char *s0;
+  const unsigned char *s1;
+  const unsigned char *s2;
+  const unsigned char *s3;
+  int xblk_sz;
+  int yblk_sz;
+  int log_blk_sz2;
+  int round;
+  int i;
+  int j;
+  xblk_sz = 1 << log_xblk_sz;
+  yblk_sz = 1 << log_yblk_sz;
+  log_blk_sz2 = log_xblk_sz + log_yblk_sz;
+  round = 1 << (log_blk_sz2 - 1);
+  s0 = src[0];
+  s1 = src[1];
+  s2 = src[2];
+  s3 = src[3];
+  if (xblk_sz >= 8) {
+    /* a and b fit 16 bits (<= 255 << 6); the second stage is one multiply-add of the pairs
+       (a, b - a) with (1 << ly, j) into 32 bits */
+    const __m128i vround = _mm_set1_epi32(round);
+    const __m128i cx = _mm_cvtsi32_si128(log_xblk_sz);
+    const __m128i c2 = _mm_cvtsi32_si128(log_blk_sz2);
+    for (j = 0; j < yblk_sz; j++) {
+      const __m128i wj = _mm_set1_epi32((1 << log_yblk_sz) | (j << 16));
+      __m128i vi;
+      vi = _mm_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7);
+      for (i = 0; i < xblk_sz; i += 8) {
+        __m128i a;
+        __m128i b;
+        __m128i p1;
+        __m128i p2;
+        __m128i lo;
+        __m128i hi;
+        a = _mm_cvtepu8_epi16(_mm_loadl_epi64((const __m128i *)(s0 + i)));
+        p1 = _mm_cvtepu8_epi16(_mm_loadl_epi64((const __m128i *)(s1 + i)));
+        p2 = _mm_cvtepu8_epi16(_mm_loadl_epi64((const __m128i *)(s2 + i)));
+        b = _mm_cvtepu8_epi16(_mm_loadl_epi64((const __m128i *)(s3 + i)));
+        a = _mm_add_epi16(_mm_sll_epi16(a, cx), _mm_mullo_epi16(_mm_sub_epi16(p1, a), vi));
+        b = _mm_add_epi16(_mm_sll_epi16(b, cx), _mm_mullo_epi16(_mm_sub_epi16(p2, b), vi));
+        b = _mm_sub_epi16(b, a);
+        lo = _mm_madd_epi16(_mm_unpacklo_epi16(a, b), wj);
+        hi = _mm_madd_epi16(_mm_unpackhi_epi16(a, b), wj);
+        lo = _mm_sra_epi32(_mm_add_epi32(lo, vround), c2);
+        hi = _mm_sra_epi32(_mm_add_epi32(hi, vround), c2);
+        /* the result is a convex combination of four bytes: no saturation happens */
+        lo = _mm_packs_epi32(lo, hi);
+        _mm_storel_epi64((__m128i *)(dst + i), _mm_packus_epi16(lo, lo));
+        vi = _mm_add_epi16(vi, _mm_set1_epi16(8));
+      }
+      s0 += xblk_sz;
+      s1 += xblk_sz;
+      s2 += xblk_sz;
+      s3 += xblk_sz;
+      dst += dystride;
+    }
+    return;
+  }
+  for (j = 0; j < yblk_sz; j++) {
+    for (i = 0; i < xblk_sz; i++) {
+      int32_t a;
+      int32_t b;
+      a = s0[i];
+      b = s3[i];
+      a = (a << log_xblk_sz) + (s1[i] - a)*i;
+      b = (b << log_xblk_sz) + (s2[i] - b)*i;
+      dst[i] = (unsigned char)(((a << log_yblk_sz) + (b - a)*j + round) >> log_blk_sz2);
+    }
+    s0 += xblk_sz;
+    s1 += xblk_sz;
+    s2 += xblk_sz;
+    s3 += xblk_sz;
+    dst += dystride;
+  }
+}
+
+/* od_mc_predict1fmv8_c (src/mc.c:94-203): the 1/8-pel predictor, separable 6-tap filters
+   (OD_SUBPEL_FILTER_SET, src/mc.c:69-80), horizontal pass into a 16-bit buffer with a two-row
+   top and three-row bottom apron, then the vertical pass, one rounding at the end.  Eight
+   columns at a time.  The horizontal sums are formed in 16-bit lanes: the value stored,
+   sum - (128 << 7), always fits (its range is [-19954, 19826] for 8-bit input and these taps)
+   and two's-complement additions are exact modulo 2^16, so a sum of pair sums that passes
+   32767 on the way does no harm.  Blocks narrower than eight columns go to the reference's function. */
+void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsigned char *src,
+ int systride, int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz) {
+  int16_t buff[(OD_MVBSIZE_MAX + OD_SUBPEL_BUFF_APRON_SZ)*OD_MVBSIZE_MAX] __attribute__((aligned(32)));
+  const unsigned char *src_p;
+  const int16_t *fx;
+  const int16_t *fy;
+  int16_t *buff_p;
+  int mvxf;
+  int mvyf;
+  int xblk_sz;
+  int yblk_sz;
+  int i;
+  int j;
+  mvxf = mvx & 0x07;
+  mvyf = mvy & 0x07;
+  if (log_xblk_sz < 3 || !(mvxf || mvyf)) {
+    od_mc_predict1fmv8_c(state, dst, src, systride, mvx, mvy, log_xblk_sz, log_yblk_sz);
+    return;
+  }
+  xblk_sz = 1 << log_xblk_sz;
+  yblk_sz = 1 << log_yblk_sz;
+  src_p = src + (mvx >> 3) + (mvy >> 3)*systride;
+  fx = OD_SUBPEL_FILTER_SET[mvxf];
+  fy = OD_SUBPEL_FILTER_SET[mvyf];
+  buff_p = buff;
+  src_p -= systride*OD_SUBPEL_TOP_APRON_SZ;
+  if (mvxf) {
+    /* taps paired (1, 2), (3, 4), (0, 5): in every phase each pair holds at most one large
+       positive tap (<= 122), so a pair sum of byte x tap products stays inside 16 bits
+       (<= 255*122, >= -255*20*2) and the saturating multiply-add never saturates */
+    const __m128i c12 = _mm_set1_epi16((short)((fx[1] & 255) | (fx[2] << 8)));
+    const __m128i c34 = _mm_set1_epi16((short)((fx[3] & 255) | (fx[4] << 8)));
+    const __m128i c05 = _mm_set1_epi16((short)((fx[0] & 255) | (fx[5] << 8)));
+    const __m128i norm = _mm_set1_epi16((short)OD_SUBPEL_COEFF_NORMALIZE);
+    for (j = -OD_SUBPEL_TOP_APRON_SZ; j < yblk_sz + OD_SUBPEL_BOTTOM_APRON_SZ; j++) {
+      for (i = 0; i < xblk_sz; i += 8) {
+        const unsigned char *p;
+        __m128i t0;
+        __m128i t1;
+        __m128i t2;
+        __m128i t3;
+        __m128i t4;
+        __m128i t5;
+        __m128i sum;
+        p = src_p + i - OD_SUBPEL_TOP_APRON_SZ;
+        t0 = _mm_loadl_epi64((const __m128i *)p);
+        t1 = _mm_loadl_epi64((const __m128i *)(p + 1));
+        t2 = _mm_loadl_epi64((const __m128i *)(p + 2));
+        t3 = _mm_loadl_epi64((const __m128i *)(p + 3));
+        t4 = _mm_loadl_epi64((const __m128i *)(p + 4));
+        t5 = _mm_loadl_epi64((const __m128i *)(p + 5));
+        sum = _mm_maddubs_epi16(_mm_unpacklo_epi8(t1, t2), c12);
+        sum = _mm_add_epi16(sum, _mm_maddubs_epi16(_mm_unpacklo_epi8(t3, t4), c34));
+        sum = _mm_add_epi16(sum, _mm_maddubs_epi16(_mm_unpacklo_epi8(t0, t5), c05));
+        _mm_store_si128((__m128i *)(buff_p + i), _mm_sub_epi16(sum, norm));
+      }
+      src_p += systride;
+      buff_p += xblk_sz;
+    }
+  }
+  else {
+    const __m128i norm = _mm_set1_epi16((short)OD_SUBPEL_COEFF_NORMALIZE);
+    for (j = -OD_SUBPEL_TOP_APRON_SZ; j < yblk_sz + OD_SUBPEL_BOTTOM_APRON_SZ; j++) {
+      for (i = 0; i < xblk_sz; i += 8) {
+        __m128i v;
+        v = _mm_cvtepu8_epi16(_mm_loadl_epi64((const __m128i *)(src_p + i)));
+        _mm_store_si128((__m128i *)(buff_p + i),
+         _mm_sub_epi16(_mm_slli_epi16(v, OD_SUBPEL_COEFF_SCALE), norm));
+      }
+      src_p += systride;
+      buff_p += xblk_sz;
+    }
+  }
+  buff_p = buff + xblk_sz*OD_SUBPEL_TOP_APRON_SZ;
+  if (mvyf) {
+    const __m128i c01 = _mm_set1_epi32((fy[0] & 0xffff) | (fy[1] << 16));
+    const __m128i c23 = _mm_set1_epi32((fy[2] & 0xffff) | (fy[3] << 16));
+    const __m128i c45 = _mm_set1_epi32((fy[4] & 0xffff) | (fy[5] << 16));
+    const __m128i rnd = _mm_set1_epi32(OD_SUBPEL_RND_OFFSET3);
+    for (j = 0; j < yblk_sz; j++) {
+      for (i = 0; i < xblk_sz; i += 8) {
+        const int16_t *p;
+        __m128i r0;
+        __m128i r1;
+        __m128i lo;
+        __m128i hi;
+        p = buff_p + i - OD_SUBPEL_TOP_APRON_SZ*xblk_sz;
+        r0 = _mm_load_si128((const __m128i *)p);
+        r1 = _mm_load_si128((const __m128i *)(p + xblk_sz));
+        lo = _mm_madd_epi16(_mm_unpacklo_epi16(r0, r1), c01);
+        hi = _mm_madd_epi16(_mm_unpackhi_epi16(r0, r1), c01);
+        r0 = _mm_load_si128((const __m128i *)(p + 2*xblk_sz));
+        r1 = _mm_load_si128((const __m128i *)(p + 3*xblk_sz));
+        lo = _mm_add_epi32(lo, _mm_madd_epi16(_mm_unpacklo_epi16(r0, r1), c23));
+        hi = _mm_add_epi32(hi, _mm_madd_epi16(_mm_unpackhi_epi16(r0, r1), c23));
+        r0 = _mm_load_si128((const __m128i *)(p + 4*xblk_sz));
+        r1 = _mm_load_si128((const __m128i *)(p + 5*xblk_sz));
+        lo = _mm_add_epi32(lo, _mm_madd_epi16(_mm_unpacklo_epi16(r0, r1), c45));
+        hi = _mm_add_epi32(hi, _mm_madd_epi16(_mm_unpackhi_epi16(r0, r1), c45));
+        lo = _mm_srai_epi32(_mm_add_epi32(lo, rnd), OD_SUBPEL_COEFF_SCALE2);
+        hi = _mm_srai_epi32(_mm_add_epi32(hi, rnd), OD_SUBPEL_COEFF_SCALE2);
+        /* OD_CLAMP255: saturating packs, 32 -> 16 (signed) -> 8 (unsigned) */
+        lo = _mm_packs_epi32(lo, hi);
+        _mm_storel_epi64((__m128i *)(dst + i), _mm_packus_epi16(lo, lo));
+      }
+      buff_p += xblk_sz;
+      dst += xblk_sz;
+    }
+  }
+  else {
+    for (j = 0; j < yblk_sz; j++) {
+      for (i = 0; i < xblk_sz; i += 8) {
+        __m128i v;
+        /* buff + RND_OFFSET4 <= 19826 + 16448 passes 32767: widen before adding */
+        __m256i w;
+        __m128i o;
+        v = _mm_load_si128((const __m128i *)(buff_p + i));
+        w = _mm256_add_epi32(_mm256_cvtepi16_epi32(v), _mm256_set1_epi32(OD_SUBPEL_RND_OFFSET4));
+        w = _mm256_srai_epi32(w, OD_SUBPEL_COEFF_SCALE);
+        o = _mm_packs_epi32(_mm256_castsi256_si128(w), _mm256_extracti128_si256(w, 1));
+        _mm_storel_epi64((__m128i *)(dst + i), _mm_packus_epi16(o, o));
+      }
+      buff_p += xblk_sz;
+      dst += xblk_sz;
+    }
+  }
+}
+
+/* test entries: the two leaves and the reference's, same arguments */
+void od_hipenc_mc_leaves_test(int which, unsigned char *dst, int dystride, const unsigned char *s0,
+ const unsigned char *s1, const unsigned char *s2, const unsigned char *s3, int systride,
+ int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz) {
+  const unsigned char *src[4];
+  src[0] = s0;
+  src[1] = s1;
+  src[2] = s2;
+  src[3] = s3;
+  switch (which) {
+    case 0: od_hipenc_mc_blend_full8(dst, dystride, src, log_xblk_sz, log_yblk_sz); break;
+    case 1: od_mc_blend_full8_c(dst, dystride, src, log_xblk_sz, log_yblk_sz); break;
+    case 2: od_hipenc_mc_predict1fmv8(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
+    default: od_mc_predict1fmv8_c(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
+  }
+}

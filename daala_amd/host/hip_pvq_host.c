@@ -250,43 +250,56 @@ static void rc_laplace_vector(hip_rc *c, const od_coeff *y, int n, int k,
   }
 }
 
+/* The codeword's share of od_pvq_rate (src/pvq_encoder.c:257-276): trial coding of y into
+   a fresh range coder.  It depends on (y, k, n, noref, bs) and the adaptation state only, so
+   within one band - where the state does not move - equal codewords have equal rates. */
+static double pvq_codeword_rate(const od_adapt_ctx *adapt, const od_coeff *y0, int k, int n,
+ int noref, int bs) {
+  const od_pvq_codeword_ctx *cd;
+  hip_rc c;
+  c.rng = 0x8000;
+  c.nbits = 1;
+  cd = &adapt->pvq.pvq_codeword_ctx;
+  /* od_encode_pvq_codeword (src/pvq_encoder.c:41-80) */
+  if (k == 1 && n < 16) {
+    int cdf_id;
+    int i;
+    int pos;
+    int nn;
+    cdf_id = 2*(n == 15) + !noref;
+    nn = n - !noref;
+    pos = 32;
+    for (i = 0; i < nn; i++) {
+      if (y0[i]) {
+        pos = i;
+        break;
+      }
+    }
+    rc_cdf_unscaled(&c, pos, cd->pvq_k1_cdf[cdf_id], 0, nn);
+    c.nbits += 1;
+  }
+  else {
+    rc_laplace_vector(&c, y0, n - !noref, k, cd->pvq_adapt + 4*(2*bs + noref));
+  }
+  /* (od_ec_enc_tell_frac(&ec) - tell)/8. with tell = od_ec_tell_frac(1, 0x8000) = 8 */
+  return (uint32_t)(od_ec_tell_frac(c.nbits, c.rng) - 8)/8.;
+}
+
+static double pvq_rate_with_codeword(double rate, int qg, int icgr, int theta, int ts,
+ int is_keyframe, int pli);
+
 /* od_pvq_rate (src/pvq_encoder.c:248-284) */
 double od_hip_pvq_rate(int qg, int icgr, int theta, int ts, const od_adapt_ctx *adapt,
  const od_coeff *y0, int k, int n, int is_keyframe, int pli, int bs) {
   double rate;
-  if (k > 0) {
-    const od_pvq_codeword_ctx *cd;
-    hip_rc c;
-    int noref;
-    c.rng = 0x8000;
-    c.nbits = 1;
-    cd = &adapt->pvq.pvq_codeword_ctx;
-    noref = theta == -1;
-    /* od_encode_pvq_codeword (src/pvq_encoder.c:41-80) */
-    if (k == 1 && n < 16) {
-      int cdf_id;
-      int i;
-      int pos;
-      int nn;
-      cdf_id = 2*(n == 15) + !noref;
-      nn = n - !noref;
-      pos = 32;
-      for (i = 0; i < nn; i++) {
-        if (y0[i]) {
-          pos = i;
-          break;
-        }
-      }
-      rc_cdf_unscaled(&c, pos, cd->pvq_k1_cdf[cdf_id], 0, nn);
-      c.nbits += 1;
-    }
-    else {
-      rc_laplace_vector(&c, y0, n - !noref, k, cd->pvq_adapt + 4*(2*bs + noref));
-    }
-    /* (od_ec_enc_tell_frac(&ec) - tell)/8. with tell = od_ec_tell_frac(1, 0x8000) = 8 */
-    rate = (uint32_t)(od_ec_tell_frac(c.nbits, c.rng) - 8)/8.;
-  }
+  if (k > 0) rate = pvq_codeword_rate(adapt, y0, k, n, theta == -1, bs);
   else rate = 0;
+  return pvq_rate_with_codeword(rate, qg, icgr, theta, ts, is_keyframe, pli);
+}
+
+/* the gain/theta terms (:277-283) added to a codeword rate */
+static double pvq_rate_with_codeword(double rate, int qg, int icgr, int theta, int ts,
+ int is_keyframe, int pli) {
   if (qg > 0 && theta >= 0) {
     /* .9*OD_LOG2(ts): ts is a small integer, the libm value is cached per thread (same
        call, same bits) */
@@ -419,10 +432,18 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
   if (n <= OD_MAX_PVQ_SIZE && !r_null && corr > 0) {
     /* :399-448, the reference's arithmetic: its input depends on the reconstruction of the
        neighbours (or of luma), so there is nothing the device could have prepared */
+    od_hip_search sc;
+    /* codewords already priced in this band: (k, y) -> codeword rate */
+    od_coeff seen_y[OD_HIP_SEARCH_KCACHE][128];
+    double seen_rate[OD_HIP_SEARCH_KCACHE];
+    int seen_k[OD_HIP_SEARCH_KCACHE];
+    int nseen;
+    nseen = 0;
     theta = acos(corr);
     m = od_compute_householder(r, n, gr, &s);
     od_apply_householder(x, r, n);
     for (i = m; i < n - 1; i++) x[i] = x[i + 1];
+    od_hip_search_begin(&sc, x, n - 1);
     for (i = OD_MAXI(1, (int)floor(cg - gain_offset) - 1);
      i <= (int)ceil(cg - gain_offset); i++) {
       int j;
@@ -440,8 +461,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         qtheta = od_pvq_compute_theta(j, ts);
         k = od_pvq_compute_k(qcg, j, qtheta, 0, n, beta, 1);
         t0 = T.time_cpu ? od_hipenc_now() : 0;
-        cos_dist = od_hip_pvq_search_host(x, n - 1, k, y_tmp,
-         qcg*cg*sin(theta)*sin(qtheta));
+        cos_dist = od_hip_search_run(&sc, k, y_tmp, qcg*cg*sin(theta)*sin(qtheta));
         if (T.time_cpu) {
           double dt;
           dt = od_hipenc_now() - t0;
@@ -458,7 +478,27 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
            beat the incumbent even so is not priced. */
         if (!(dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, NULL, 0, n, 1, pli, bs)
          < best_cost)) continue;
-        cost = dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, y_tmp, k, n, 1, pli, bs);
+        {
+          double cw;
+          int e;
+          cw = 0;
+          if (k > 0) {
+            for (e = 0; e < nseen; e++) {
+              if (seen_k[e] == k && memcmp(seen_y[e], y_tmp, sizeof(od_coeff)*(n - 1)) == 0) break;
+            }
+            if (e < nseen) cw = seen_rate[e];
+            else {
+              cw = pvq_codeword_rate(adapt, y_tmp, k, n, 0, bs);
+              if (nseen < OD_HIP_SEARCH_KCACHE && n - 1 <= 128) {
+                seen_k[nseen] = k;
+                seen_rate[nseen] = cw;
+                memcpy(seen_y[nseen], y_tmp, sizeof(od_coeff)*(n - 1));
+                nseen++;
+              }
+            }
+          }
+          cost = dist + lambda*pvq_rate_with_codeword(cw, i, icgr, j, ts, 1, pli);
+        }
         if (cost < best_cost) {
           best_cost = cost;
           best_dist = dist;
@@ -548,7 +588,9 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
     }
     else {
       double x1[MAXN];
+      od_hip_search sc;
       for (i = 0; i < n; i++) x1[i] = x0[i]*qm[i]*OD_QM_SCALE_1;
+      od_hip_search_begin(&sc, x1, n);
       for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++) {
         double cos_dist;
         double cost;
@@ -557,7 +599,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         qcg = i;
         k = od_pvq_compute_k(qcg, -1, -1, 1, n, beta, 1);
         t0 = T.time_cpu ? od_hipenc_now() : 0;
-        cos_dist = od_hip_pvq_search_host(x1, n, k, y_tmp, qcg*cg);
+        cos_dist = od_hip_search_run(&sc, k, y_tmp, qcg*cg);
         if (T.time_cpu) {
           double dt;
           dt = od_hipenc_now() - t0;

@@ -44,70 +44,99 @@ static inline double rsqrt_int(int i) {
 
 #define NPAD (MAXN + 8)
 
-double od_hip_pvq_search_lanes(const double *xcoeff, int n, int k, od_coeff *ypulse,
- double g2);
-
 /* Below this many coefficients the reference's scalar scan is faster than four lanes plus
    the verification pass (measured: 7 and 14 coefficients 103/292 ns scalar vs 142/370 ns
-   here; 31: 1.07 vs 0.99 us; 127: 9.8 vs 6.4 us). */
+   with lanes; 31: 1.07 vs 0.99 us; 127: 9.8 vs 6.4 us). */
 #define OD_HIP_SEARCH_MIN_N (24)
 
-double od_hip_pvq_search_host(const double *xcoeff, int n, int k, od_coeff *ypulse,
- double g2) {
-  if (n < OD_HIP_SEARCH_MIN_N) return od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
-  return od_hip_pvq_search_lanes(xcoeff, n, k, ypulse, g2);
+/* One vector, many searches.  pvq_theta (src/pvq_encoder.c:399-481) searches the SAME input
+   once per (gain, theta) candidate, changing only K and g2.  Of what pvq_search_rdo_double
+   computes, |x|, xx, norm_1 and the L1 norm do not depend on either; the projection and the
+   greedy pulses (:147-188) depend on K alone; only the last 1 + K/4 pulses (:193-220) see
+   g2.  The context keeps the first group per vector and the second per distinct K (two in
+   five of a frame's with-reference searches repeat a K of their band), so a candidate costs
+   its RDO pulses only - every value still comes out of the reference's operations in the
+   reference's order. */
+void od_hip_search_begin(od_hip_search *S, const double *xcoeff, int n) {
+  od_hip_search_begin_ex(S, xcoeff, n, n >= OD_HIP_SEARCH_MIN_N);
 }
 
-double od_hip_pvq_search_lanes(const double *xcoeff, int n, int k, od_coeff *ypulse,
- double g2) {
-  double x[NPAD] __attribute__((aligned(32)));
+void od_hip_search_begin_ex(od_hip_search *S, const double *xcoeff, int n, int lanes) {
+  double xx;
+  int j;
+  S->xcoeff = xcoeff;
+  S->n = n;
+  S->nv = (n + 3) & ~3;
+  xx = 0;
+  for (j = 0; j < n; j++) {
+    S->x[j] = fabs(xcoeff[j]);
+    xx += S->x[j]*S->x[j];
+  }
+  for (j = n; j < S->nv; j++) S->x[j] = 0;
+  S->xx = xx;
+  S->norm_1 = 1./sqrt(1e-30 + xx);
+  S->have_l1 = 0;
+  S->nk = 0;
+  S->lanes = lanes;
+}
+
+/* ---- greedy phase (:166-188): pulses i .. to-1 ---- */
+static void greedy_scalar(const od_hip_search *S, int32_t *yi, double *pxy, double *pyy,
+ int i, int to) {
+  const double *x;
+  double xy;
+  double yy;
+  int n;
+  int j;
+  x = S->x;
+  n = S->n;
+  xy = *pxy;
+  yy = *pyy;
+  for (; i < to; i++) {
+    int pos;
+    double best_xy;
+    double best_yy;
+    pos = 0;
+    best_xy = -10;
+    best_yy = 1;
+    for (j = 0; j < n; j++) {
+      double tmp_xy;
+      double tmp_yy;
+      tmp_xy = xy + x[j];
+      tmp_yy = yy + 2*yi[j] + 1;
+      tmp_xy *= tmp_xy;
+      if (j == 0 || tmp_xy*best_yy > best_xy*tmp_yy) {
+        best_xy = tmp_xy;
+        best_yy = tmp_yy;
+        pos = j;
+      }
+    }
+    xy = xy + x[pos];
+    yy = yy + 2*yi[pos] + 1;
+    yi[pos]++;
+  }
+  *pxy = xy;
+  *pyy = yy;
+}
+
+static void greedy_lanes(const od_hip_search *S, int32_t *yi, double *pxy, double *pyy,
+ int i, int to) {
   double yd[NPAD] __attribute__((aligned(32)));      /* pulses as doubles (exact integers) */
   double a[NPAD] __attribute__((aligned(32)));
   double b[NPAD] __attribute__((aligned(32)));
-  double lj[NPAD] __attribute__((aligned(32)));
-  int32_t yi[NPAD] __attribute__((aligned(32)));
-  double xx;
+  const double *x;
   double xy;
   double yy;
-  double lambda;
-  double norm_1;
-  double delta_rate;
-  int rdo_pulses;
-  int i;
-  int j;
+  int n;
   int nv;
-  xx = xy = yy = 0;
-  for (j = 0; j < n; j++) {
-    x[j] = fabs(xcoeff[j]);
-    xx += x[j]*x[j];
-  }
-  nv = (n + 3) & ~3;
-  for (j = n; j < nv; j++) x[j] = 0;
-  norm_1 = 1./sqrt(1e-30 + xx);
-  lambda = OD_PVQ_LAMBDA/(1e-30 + g2);
-  i = 0;
-  if (k > 2) {
-    double l1_norm;
-    double l1_inv;
-    l1_norm = 0;
-    for (j = 0; j < n; j++) l1_norm += x[j];
-    l1_inv = 1./OD_MAXF(l1_norm, 1e-100);
-    for (j = 0; j < n; j++) {
-      yi[j] = OD_MAXI(0, (int)floor(k*x[j]*l1_inv));
-      xy += x[j]*yi[j];
-      yy += yi[j]*yi[j];
-      i += yi[j];
-    }
-  }
-  else {
-    for (j = 0; j < n; j++) yi[j] = 0;
-  }
-  for (j = n; j < nv; j++) yi[j] = 0;
+  int j;
+  x = S->x;
+  n = S->n;
+  nv = S->nv;
+  xy = *pxy;
+  yy = *pyy;
   for (j = 0; j < nv; j++) yd[j] = yi[j];
-  rdo_pulses = 1 + k/4;
-  delta_rate = 3./n;
-  /* ---- greedy phase (:166-188) ---- */
-  for (; i < k - rdo_pulses; i++) {
+  for (; i < to; i++) {
     const __m256d vxy = _mm256_set1_pd(xy);
     const __m256d vyy = _mm256_set1_pd(yy);
     const __m256d one = _mm256_set1_pd(1.);
@@ -228,7 +257,71 @@ double od_hip_pvq_search_lanes(const double *xcoeff, int n, int k, od_coeff *ypu
     yi[pos]++;
     yd[pos] = yi[pos];
   }
-  /* ---- RDO phase (:193-220) ---- */
+  *pxy = xy;
+  *pyy = yy;
+}
+
+/* ---- RDO phase (:193-220): pulses i .. k-1 ---- */
+static void rdo_scalar(const od_hip_search *S, int32_t *yi, double *pxy, double *pyy,
+ int i, int k, double lambda) {
+  const double *x;
+  double xy;
+  double yy;
+  double norm_1;
+  double delta_rate;
+  int n;
+  int j;
+  x = S->x;
+  n = S->n;
+  xy = *pxy;
+  yy = *pyy;
+  norm_1 = S->norm_1;
+  delta_rate = 3./n;
+  for (; i < k; i++) {
+    double tb[4];
+    int pos;
+    double best_cost;
+    int l;
+    pos = 0;
+    best_cost = -1e5;
+    for (l = 0; l < 4; l++) tb[l] = rsqrt_int((int)(yy + 2*l + 1));
+    for (j = 0; j < n; j++) {
+      double tmp_xy;
+      double tmp_yy;
+      tmp_xy = xy + x[j];
+      tmp_yy = yi[j] < 4 ? tb[yi[j]] : rsqrt_int((int)(yy + 2*yi[j] + 1));
+      tmp_xy = 2*tmp_xy*norm_1*tmp_yy - lambda*j*delta_rate;
+      if (j == 0 || tmp_xy > best_cost) {
+        best_cost = tmp_xy;
+        pos = j;
+      }
+    }
+    xy = xy + x[pos];
+    yy = yy + 2*yi[pos] + 1;
+    yi[pos]++;
+  }
+  *pxy = xy;
+  *pyy = yy;
+}
+
+static void rdo_lanes(const od_hip_search *S, int32_t *yi, double *pxy, double *pyy,
+ int i, int k, double lambda) {
+  double lj[NPAD] __attribute__((aligned(32)));
+  const double *x;
+  double xy;
+  double yy;
+  double norm_1;
+  double delta_rate;
+  int n;
+  int nv;
+  int j;
+  x = S->x;
+  n = S->n;
+  nv = S->nv;
+  xy = *pxy;
+  yy = *pyy;
+  norm_1 = S->norm_1;
+  delta_rate = 3./n;
   if (i < k) {
     for (j = 0; j < nv; j++) lj[j] = lambda*j*delta_rate;
   }
@@ -285,6 +378,93 @@ double od_hip_pvq_search_lanes(const double *xcoeff, int n, int k, od_coeff *ypu
     yy = yy + 2*yi[pos] + 1;
     yi[pos]++;
   }
-  for (j = 0; j < n; j++) ypulse[j] = xcoeff[j] < 0 ? -yi[j] : yi[j];
-  return xy/(1e-100 + sqrt(xx*yy));
+  *pxy = xy;
+  *pyy = yy;
+}
+
+double od_hip_search_run(od_hip_search *S, int k, od_coeff *ypulse, double g2) {
+  int32_t yi[NPAD] __attribute__((aligned(32)));
+  const double *x;
+  double xy;
+  double yy;
+  double lambda;
+  int rdo_pulses;
+  int n;
+  int nv;
+  int i;
+  int j;
+  int e;
+  x = S->x;
+  n = S->n;
+  nv = S->nv;
+  lambda = OD_PVQ_LAMBDA/(1e-30 + g2);
+  rdo_pulses = 1 + k/4;
+  for (e = 0; e < S->nk && S->ka[e].k != k; e++);
+  if (e < S->nk) {
+    memcpy(yi, S->ky[e], sizeof(int32_t)*nv);
+    xy = S->ka[e].xy;
+    yy = S->ka[e].yy;
+    i = S->ka[e].placed;
+  }
+  else {
+    xy = yy = 0;
+    i = 0;
+    if (k > 2) {
+      double l1_inv;
+      if (!S->have_l1) {
+        double l1_norm;
+        l1_norm = 0;
+        for (j = 0; j < n; j++) l1_norm += x[j];
+        S->l1_inv = 1./OD_MAXF(l1_norm, 1e-100);
+        S->have_l1 = 1;
+      }
+      l1_inv = S->l1_inv;
+      for (j = 0; j < n; j++) {
+        yi[j] = OD_MAXI(0, (int)floor(k*x[j]*l1_inv));
+        xy += x[j]*yi[j];
+        yy += yi[j]*yi[j];
+        i += yi[j];
+      }
+    }
+    else {
+      for (j = 0; j < n; j++) yi[j] = 0;
+    }
+    for (j = n; j < nv; j++) yi[j] = 0;
+    if (i < k - rdo_pulses) {
+      if (!S->lanes) greedy_scalar(S, yi, &xy, &yy, i, k - rdo_pulses);
+      else greedy_lanes(S, yi, &xy, &yy, i, k - rdo_pulses);
+      i = k - rdo_pulses;
+    }
+    if (S->nk < OD_HIP_SEARCH_KCACHE) {
+      e = S->nk++;
+      S->ka[e].k = k;
+      S->ka[e].placed = i;
+      S->ka[e].xy = xy;
+      S->ka[e].yy = yy;
+      memcpy(S->ky[e], yi, sizeof(int32_t)*nv);
+    }
+  }
+  if (i < k) {
+    if (!S->lanes) rdo_scalar(S, yi, &xy, &yy, i, k, lambda);
+    else rdo_lanes(S, yi, &xy, &yy, i, k, lambda);
+  }
+  for (j = 0; j < n; j++) ypulse[j] = S->xcoeff[j] < 0 ? -yi[j] : yi[j];
+  return xy/(1e-100 + sqrt(S->xx*yy));
+}
+
+/* one search of one vector */
+double od_hip_pvq_search_host(const double *xcoeff, int n, int k, od_coeff *ypulse,
+ double g2) {
+  od_hip_search S;
+  od_hip_search_begin(&S, xcoeff, n);
+  return od_hip_search_run(&S, k, ypulse, g2);
+}
+
+/* test entry: ncand searches of one vector through one context, scalar or lane scans */
+void od_hip_pvq_search_multi(const double *xcoeff, int n, int lanes, int ncand, const int *k,
+ const double *g2, od_coeff *y, double *cos_dist) {
+  od_hip_search S;
+  int c;
+  od_hip_search_begin_ex(&S, xcoeff, n, lanes);
+  for (c = 0; c < ncand; c++) cos_dist[c] = od_hip_search_run(&S, k[c], y + (size_t)c*n, g2[c]);
 }

@@ -217,17 +217,21 @@ def test_truncated_or_mismatched_container_is_rejected():
 
 
 def test_host_codeword_search_equals_reference_search():
-    """od_hip_pvq_search_lanes (hip_pvq_search.c: lane-wise scans + verified winner) against
-    the reference's pvq_search_rdo_double on the sizes the host searches (with-reference
-    bands have n - 1 coefficients), including inputs full of exact ties."""
+    """hip_pvq_search.c against the reference's pvq_search_rdo_double: several (K, g2)
+    candidates of ONE vector through one search context (what is shared between candidates is
+    computed once, the greedy pulses once per distinct K - repeated K's are in the list),
+    scalar scans and lane-wise scans + verified winner, on the sizes the host searches
+    (with-reference bands have n - 1 coefficients), including inputs full of exact ties."""
     lib = H.hipenc()
     F64P, I32P = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
-    for f in (lib.od_hip_pvq_search_lanes, lib.od_ref_pvq_search_rdo_double_cpu):
-        f.restype = ctypes.c_double
-        f.argtypes = [F64P, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_double]
+    lib.od_ref_pvq_search_rdo_double_cpu.restype = ctypes.c_double
+    lib.od_ref_pvq_search_rdo_double_cpu.argtypes = [F64P, ctypes.c_int, ctypes.c_int, I32P, ctypes.c_double]
+    lib.od_hip_pvq_search_multi.restype = None
+    lib.od_hip_pvq_search_multi.argtypes = [F64P, ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, F64P,
+                                            I32P, F64P]
     rng = np.random.default_rng(7)
     for n in (7, 8, 14, 15, 31, 32, 127, 128):
-        for trial in range(400):
+        for trial in range(160):
             kind = trial % 4
             x = rng.laplace(0, 1, n)*rng.choice([.01, 1, 30, 900])
             if kind == 1:
@@ -237,14 +241,22 @@ def test_host_codeword_search_equals_reference_search():
             elif kind == 3:
                 x = np.full(n, x[0] if x[0] else 1.)  # everything tied
                 x[rng.integers(n)] *= -1
-            k = int(rng.choice([1, 2, 3, 5, 9, 17, 40, 120]))
-            g2 = float(rng.uniform(.01, 50))
             x = np.ascontiguousarray(x)
-            ya, yb = np.zeros(n, np.int32), np.zeros(n, np.int32)
-            ca = lib.od_hip_pvq_search_lanes(x.ctypes.data_as(F64P), n, k, ya.ctypes.data_as(I32P), g2)
-            cb = lib.od_ref_pvq_search_rdo_double_cpu(x.ctypes.data_as(F64P), n, k,
-                                                      yb.ctypes.data_as(I32P), g2)
-            assert np.array_equal(ya, yb) and ca == cb, (n, trial, k)
+            nc = 14                                   # more candidates than the context caches
+            ks = rng.choice([1, 2, 3, 5, 9, 17, 40, 120], size=nc).astype(np.int32)
+            ks[1::3] = ks[0]                          # repeated K, different g2
+            g2 = rng.uniform(.01, 50, size=nc)
+            g2[4] = g2[1]                             # and an exact repeat
+            want_y, want_c = np.zeros((nc, n), np.int32), np.zeros(nc)
+            for c in range(nc):
+                want_c[c] = lib.od_ref_pvq_search_rdo_double_cpu(
+                    x.ctypes.data_as(F64P), n, int(ks[c]), want_y[c].ctypes.data_as(I32P), float(g2[c]))
+            for lanes in (0, 1):
+                y, cd = np.zeros((nc, n), np.int32), np.zeros(nc)
+                lib.od_hip_pvq_search_multi(x.ctypes.data_as(F64P), n, lanes, nc, ks.ctypes.data_as(I32P),
+                                            g2.ctypes.data_as(F64P), y.ctypes.data_as(I32P),
+                                            cd.ctypes.data_as(F64P))
+                assert np.array_equal(y, want_y) and np.array_equal(cd, want_c), (n, trial, lanes)
 
 
 def inter_stream(w, h, nf, keyrate=4):
@@ -329,3 +341,51 @@ def test_inter_stream_encoded_by_the_driver_host_path():
     prm = H.Params(w, h, 20, 7, 1, 3, 0, 0, 4)          # 3 workers asked for, 1 used
     n, pk, st = H.encode(prm, buf, nf)
     assert n > 0 and pk == want
+
+
+def test_motion_search_leaves_equal_reference():
+    """hip_mc_host.c: the host-vector od_state_opt_vtbl leaves of the motion search
+    (od_hipenc_mc_blend_full8, od_hipenc_mc_predict1fmv8) against the reference's C entries
+    (src/mc.c:352-377, :94-203) - every block shape, every sub-pel phase pair, saturating
+    content, strides that are not the block width."""
+    lib = H.hipenc()
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    f = lib.od_hipenc_mc_leaves_test
+    f.restype = None
+    f.argtypes = [ctypes.c_int, U8P, ctypes.c_int, U8P, U8P, U8P, U8P, ctypes.c_int, ctypes.c_int32,
+                  ctypes.c_int32, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(12)
+    for trial in range(600):
+        lx, ly = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+        n, m = 1 << lx, 1 << ly
+        kind = trial % 3
+        srcs = [rng.integers(0, 256, size=n*m, dtype=np.uint8) for _ in range(4)]
+        if kind == 1:
+            srcs = [(255*rng.integers(0, 2, size=n*m)).astype(np.uint8) for _ in range(4)]
+        ds = n + int(rng.integers(0, 5))
+        got, want = np.zeros((m, ds), np.uint8), np.zeros((m, ds), np.uint8)
+        for which, o in ((0, got), (1, want)):
+            f(which, pu8(o), ds, pu8(srcs[0]), pu8(srcs[1]), pu8(srcs[2]), pu8(srcs[3]), 0, 0, 0, lx, ly)
+        assert np.array_equal(got, want), ('blend', trial, lx, ly)
+    W, Hh, pad = 160, 144, 24
+    for trial in range(900):
+        lx, ly = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+        n, m = 1 << lx, 1 << ly
+        plane = rng.integers(0, 256, size=(Hh, W), dtype=np.uint8)
+        if trial % 3 == 1:
+            plane = (255*rng.integers(0, 2, size=(Hh, W))).astype(np.uint8)
+        elif trial % 3 == 2:
+            plane[:, ::2] = 255; plane[:, 1::2] = 0      # worst case for the 6-tap sums
+        x0, y0 = int(rng.integers(pad, W - pad - n)), int(rng.integers(pad, Hh - pad - m))
+        mvx, mvy = int(rng.integers(-8*(pad - 8), 8*(pad - 8))), int(rng.integers(-8*(pad - 8), 8*(pad - 8)))
+        if trial % 5 == 0:
+            mvx &= ~7
+        elif trial % 5 == 1:
+            mvy &= ~7
+        if not (mvx & 7 or mvy & 7):
+            mvx |= 3                                 # the full-pel copy goes through state->opt_vtbl
+        src = ctypes.cast(plane.ctypes.data + y0*W + x0, U8P)
+        got, want = np.zeros((m, n), np.uint8), np.zeros((m, n), np.uint8)
+        for which, o in ((2, got), (3, want)):
+            f(which, pu8(o), n, src, src, src, src, W, mvx, mvy, lx, ly)
+        assert np.array_equal(got, want), ('predict', trial, lx, ly, mvx & 7, mvy & 7)
