@@ -152,14 +152,18 @@ __global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
       // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE
       const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
       const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
-      for (int e = t; e < TAIL_BSTRIDE*TAIL_BSTRIDE; e += 256) {
-        const int i = e/TAIL_BSTRIDE - 3, j = e%TAIL_BSTRIDE - 3;
+      // only the (n + 6)^2 corner of the 38 x 38 buffers is ever read: a chroma tile loads
+      // 22 x 22 cells, not 38 x 38
+      const int tw = n + 6;
+      for (int e = t; e < tw*tw; e += 256) {
+        const int r = xdec ? e/22 : e/38;
+        const int i = r - 3, j = e - r*tw - 3;
         int16_t v = TAIL_VERY_LARGE;
         if (i >= lo_i && i < hi_i && j >= lo_j && j < hi_j) {
           v = enc_mode ? P16[(ptrdiff_t)i*w + j] : (int16_t)P[(ptrdiff_t)i*w + j];
         }
-        in0[e] = v;
-        in1[e] = v;
+        in0[r*TAIL_BSTRIDE + j + 3] = v;
+        in1[r*TAIL_BSTRIDE + j + 3] = v;
       }
       __syncthreads();
       const int16_t *in = in0 + 3*TAIL_BSTRIDE + 3;

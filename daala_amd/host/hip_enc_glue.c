@@ -56,7 +56,20 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
   double r;
   T.st.cpu_other++;
   t0 = T.time_cpu ? now_s() : 0;
-  if (n >= 24 && !T.check) r = od_hip_pvq_search_host(xcoeff, n, k, ypulse, g2);
+  if (n >= 24 && !T.check) {
+    /* the reference's pvq_theta searches one vector once per (gain, theta) candidate: while
+       the input stays the same (compared by value) the search context is kept, so the
+       candidate-independent sums and the greedy pulses of a repeated K are not redone */
+    static __thread od_hip_search sc;
+    static __thread double sc_x[MAXN];
+    static __thread int sc_n;
+    if (sc_n != n || memcmp(sc_x, xcoeff, sizeof(double)*n) != 0) {
+      memcpy(sc_x, xcoeff, sizeof(double)*n);
+      sc_n = n;
+      od_hip_search_begin(&sc, sc_x, n);
+    }
+    r = od_hip_search_run(&sc, k, ypulse, g2);
+  }
   else r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
   if (T.time_cpu) {
     double dt;

@@ -44,6 +44,48 @@ void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned c
   s1 = src[1];
   s2 = src[2];
   s3 = src[3];
+  if (xblk_sz >= 16) {
+    /* sixteen pixels per step; the 32-bit halves come out of the unpacks per 128-bit lane and
+       the saturating packs put them back in order */
+    const __m256i vround = _mm256_set1_epi32(round);
+    const __m128i cx = _mm_cvtsi32_si128(log_xblk_sz);
+    const __m128i c2 = _mm_cvtsi32_si128(log_blk_sz2);
+    for (j = 0; j < yblk_sz; j++) {
+      const __m256i wj = _mm256_set1_epi32((1 << log_yblk_sz) | (j << 16));
+      __m256i vi;
+      vi = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      for (i = 0; i < xblk_sz; i += 16) {
+        __m256i a;
+        __m256i b;
+        __m256i p1;
+        __m256i p2;
+        __m256i lo;
+        __m256i hi;
+        a = _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i *)(s0 + i)));
+        p1 = _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i *)(s1 + i)));
+        p2 = _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i *)(s2 + i)));
+        b = _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i *)(s3 + i)));
+        a = _mm256_add_epi16(_mm256_sll_epi16(a, cx), _mm256_mullo_epi16(_mm256_sub_epi16(p1, a), vi));
+        b = _mm256_add_epi16(_mm256_sll_epi16(b, cx), _mm256_mullo_epi16(_mm256_sub_epi16(p2, b), vi));
+        b = _mm256_sub_epi16(b, a);
+        lo = _mm256_madd_epi16(_mm256_unpacklo_epi16(a, b), wj);
+        hi = _mm256_madd_epi16(_mm256_unpackhi_epi16(a, b), wj);
+        lo = _mm256_sra_epi32(_mm256_add_epi32(lo, vround), c2);
+        hi = _mm256_sra_epi32(_mm256_add_epi32(hi, vround), c2);
+        lo = _mm256_packs_epi32(lo, hi);
+        lo = _mm256_packus_epi16(lo, lo);
+        _mm_storel_epi64((__m128i *)(dst + i), _mm256_castsi256_si128(lo));
+        _mm_storel_epi64((__m128i *)(dst + i + 8), _mm256_extracti128_si256(lo, 1));
+        vi = _mm256_add_epi16(vi, _mm256_set1_epi16(16));
+      }
+      s0 += xblk_sz;
+      s1 += xblk_sz;
+      s2 += xblk_sz;
+      s3 += xblk_sz;
+      dst += dystride;
+    }
+    return;
+  }
   if (xblk_sz >= 8) {
     /* a and b fit 16 bits (<= 255 << 6); the second stage is one multiply-add of the pairs
        (a, b - a) with (1 << ly, j) into 32 bits */
