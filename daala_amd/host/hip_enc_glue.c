@@ -629,6 +629,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   T.dr_valid = 0;
   T.dist_valid = 0;
   T.dist_sb = -1;
+  od_hipenc_mc_cache_flush();          /* reference frames change between frames */
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
   if (T.dr_error) return -4;
   J->pkt_len[f] = 0;

@@ -16,6 +16,7 @@
  */
 #include <immintrin.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mc.h"
@@ -152,7 +153,7 @@ void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned c
    sum - (128 << 7), always fits (its range is [-19954, 19826] for 8-bit input and these taps)
    and two's-complement additions are exact modulo 2^16, so a sum of pair sums that passes
    32767 on the way does no harm.  Blocks narrower than eight columns go to the reference's function. */
-void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsigned char *src,
+static void mc_predict1fmv8_compute(od_state *state, unsigned char *dst, const unsigned char *src,
  int systride, int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz) {
   int16_t buff[(OD_MVBSIZE_MAX + OD_SUBPEL_BUFF_APRON_SZ)*OD_MVBSIZE_MAX] __attribute__((aligned(32)));
   const unsigned char *src_p;
@@ -280,6 +281,84 @@ void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsign
   }
 }
 
+/* The search asks for the same prediction again and again: a dynamic-programming step over
+   two neighbouring grid points tries every pair of their candidate vectors, and each of the
+   (up to four) blocks touched is rebuilt from its four corner vectors every time although
+   only one or two of them changed (od_mv_dp_*, src/mcenc.c).  One corner's prediction is a
+   pure function of (reference samples, vector, block shape), and reference frames are not
+   written while a frame is being searched, so recent predictions are kept per thread -
+   direct mapped, keyed by (source address, stride, vector, shape), emptied at every frame
+   start (od_hipenc_mc_cache_flush) - and a repeat costs a copy instead of two filter passes. */
+#define MC_CACHE_LOG (10)
+#define MC_CACHE_N (1 << MC_CACHE_LOG)
+#define MC_CACHE_BLK (OD_MVBSIZE_MAX*OD_MVBSIZE_MAX)
+typedef struct mc_key {
+  const unsigned char *src;
+  int32_t mvx;
+  int32_t mvy;
+  int32_t shape;              /* systride << 8 | log_xblk_sz << 4 | log_yblk_sz */
+  uint32_t gen;
+} mc_key;
+static __thread mc_key *mc_keys;
+static __thread unsigned char *mc_data;
+static __thread uint32_t mc_gen = 1;
+static __thread int64_t mc_hits;
+static __thread int64_t mc_misses;
+
+void od_hipenc_mc_cache_flush(void) {
+  mc_gen++;
+  if (mc_gen == 0) {
+    if (mc_keys != NULL) memset(mc_keys, 0, sizeof(mc_key)*MC_CACHE_N);
+    mc_gen = 1;
+  }
+}
+
+void od_hipenc_mc_cache_stats(int64_t *hits, int64_t *misses) {
+  *hits = mc_hits;
+  *misses = mc_misses;
+}
+
+void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsigned char *src,
+ int systride, int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz) {
+  mc_key *e;
+  unsigned char *d;
+  uint64_t h;
+  int32_t shape;
+  size_t bytes;
+  if (mc_keys == NULL) {
+    mc_keys = (mc_key *)calloc(MC_CACHE_N, sizeof(mc_key));
+    mc_data = (unsigned char *)malloc((size_t)MC_CACHE_N*MC_CACHE_BLK);
+    if (mc_keys == NULL || mc_data == NULL) {
+      free(mc_keys);
+      free(mc_data);
+      mc_keys = NULL;
+      mc_data = NULL;
+      mc_predict1fmv8_compute(state, dst, src, systride, mvx, mvy, log_xblk_sz, log_yblk_sz);
+      return;
+    }
+  }
+  shape = systride << 8 | log_xblk_sz << 4 | log_yblk_sz;
+  h = (uint64_t)(uintptr_t)src*0x9E3779B97F4A7C15ull;
+  h ^= ((uint64_t)(uint32_t)mvx*0x85EBCA6Bu) ^ ((uint64_t)(uint32_t)mvy*0xC2B2AE35u << 13) ^ (uint64_t)shape << 40;
+  h ^= h >> 29;
+  e = mc_keys + ((h*0x9E3779B97F4A7C15ull) >> (64 - MC_CACHE_LOG));
+  d = mc_data + (size_t)(e - mc_keys)*MC_CACHE_BLK;
+  bytes = (size_t)1 << (log_xblk_sz + log_yblk_sz);
+  if (e->gen == mc_gen && e->src == src && e->mvx == mvx && e->mvy == mvy && e->shape == shape) {
+    memcpy(dst, d, bytes);
+    mc_hits++;
+    return;
+  }
+  mc_predict1fmv8_compute(state, dst, src, systride, mvx, mvy, log_xblk_sz, log_yblk_sz);
+  memcpy(d, dst, bytes);
+  e->src = src;
+  e->mvx = mvx;
+  e->mvy = mvy;
+  e->shape = shape;
+  e->gen = mc_gen;
+  mc_misses++;
+}
+
 /* test entries: the two leaves and the reference's, same arguments */
 void od_hipenc_mc_leaves_test(int which, unsigned char *dst, int dystride, const unsigned char *s0,
  const unsigned char *s1, const unsigned char *s2, const unsigned char *s3, int systride,
@@ -292,7 +371,12 @@ void od_hipenc_mc_leaves_test(int which, unsigned char *dst, int dystride, const
   switch (which) {
     case 0: od_hipenc_mc_blend_full8(dst, dystride, src, log_xblk_sz, log_yblk_sz); break;
     case 1: od_mc_blend_full8_c(dst, dystride, src, log_xblk_sz, log_yblk_sz); break;
-    case 2: od_hipenc_mc_predict1fmv8(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
+    case 2:
+      /* a fresh plane may sit at the address of the last one: new frame, empty cache */
+      od_hipenc_mc_cache_flush();
+      od_hipenc_mc_predict1fmv8(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz);
+      break;
+    case 4: od_hipenc_mc_predict1fmv8(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
     default: od_mc_predict1fmv8_c(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
   }
 }

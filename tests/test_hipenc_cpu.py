@@ -386,6 +386,12 @@ def test_motion_search_leaves_equal_reference():
             mvx |= 3                                 # the full-pel copy goes through state->opt_vtbl
         src = ctypes.cast(plane.ctypes.data + y0*W + x0, U8P)
         got, want = np.zeros((m, n), np.uint8), np.zeros((m, n), np.uint8)
-        for which, o in ((2, got), (3, want)):
+        again = np.zeros((m, n), np.uint8)
+        for which, o in ((2, got), (3, want), (4, again)):     # 4: the repeat, from the cache
             f(which, pu8(o), n, src, src, src, src, W, mvx, mvy, lx, ly)
         assert np.array_equal(got, want), ('predict', trial, lx, ly, mvx & 7, mvy & 7)
+        assert np.array_equal(again, want), ('cached', trial)
+    lib.od_hipenc_mc_cache_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]*2
+    hits, misses = ctypes.c_int64(), ctypes.c_int64()
+    lib.od_hipenc_mc_cache_stats(ctypes.byref(hits), ctypes.byref(misses))
+    assert hits.value >= 900 and misses.value >= 900
