@@ -477,6 +477,9 @@ struct PvqLevelArgs3 {
 
 // No-reference candidates (state-free part of pvq_theta, src/pvq_encoder.c:352-357,
 // :452-481) of the bands of size N of one pyramid level, register-resident.
+#ifndef PVQ_STAGE_MIN_N
+#define PVQ_STAGE_MIN_N 32    /* bands longer than this are gathered through LDS (measured: pays for 128 only) */
+#endif
 #ifndef PVQ_V3_WAVES
 #define PVQ_V3_WAVES(N) 3     /* min waves/SIMD: 3 measured best for every N (4+ spills, 1-2 starves) */
 #endif
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
   constexpr int LDSN = (G*CH) | 1;                 // odd per-band stride
   int32_t cf[NL];
   int qi[NL];
-  constexpr bool STAGE = N > 32;   // measured: pays for the 128-coefficient bands only
+  constexpr bool STAGE = N > PVQ_STAGE_MIN_N;
   if (!STAGE) {
     const long bsafe = live ? blk : 0;
     const int bx = bsafe%a.nbx, by = bsafe/a.nbx;

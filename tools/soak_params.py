@@ -11,6 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 
 def main():
@@ -44,6 +45,25 @@ def main():
         print('%4dx%-4d q=%-3d masking=%d: %s  (hits %d, g2 %d, fdct %d, bytes %d)'
               % (w, h, q, m, 'ok' if ok else 'MISMATCH', st.dev_hits, st.g2_mismatch, st.fdct_hits, n),
               flush=True)
+        bad += not ok
+    # inter streams (configs[3]): one worker, frames in order, check mode (every device OBMC frame
+    # and every keyframe answer compared), packets against the PURE reference build
+    import configs_round as C
+    for (w, h, q, m, keyrate, nf) in ((640, 360, 20, 1, 3, 6), (352, 288, 10, 0, 4, 5), (98, 50, 60, 1, 2, 5),
+                                      (416, 240, 35, 1, 30, 4)):
+        buf = H.pack_frames(C.frames_of(w, h, nf, 50 + q, step=(2, 3)), w, h)
+        want, _ = C.reference(w, h, buf, nf, q, m, keyrate)
+        prm = H.Params(w, h, q, 7, m, 1, 1, 0, keyrate)
+        n, got, st = H.encode(prm, buf, nf, use_device=1)
+        hdr = H.headers(prm)
+        nd0, p0, _, _ = H.decode(prm, hdr, want)
+        nd1, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
+        fdev, fbad = H.mc_stats()
+        ok = (got == want and st.check_fail == 0 and st.pvq_check_fail == 0 and st.lost_sync == 0
+              and st.fdct_check_fail == 0 and st.dering_check_fail == 0 and st.dist_check_fail == 0
+              and nd0 == nf and nd1 == nf and np.array_equal(p0, p1) and fbad == 0)
+        print('%4dx%-4d q=%-3d masking=%d inter keyrate=%d: %s  (bytes %d, device OBMC frames in decode %d)'
+              % (w, h, q, m, keyrate, 'ok' if ok else 'MISMATCH', n, fdev), flush=True)
         bad += not ok
     print('total', total)
     sys.exit(1 if bad else 0)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc_<tag>/pass{1,2,3} (tools/pmc_round.sh) -> profiles/<tag>_pmc.json:
-per kernel (last dispatch of each), raw SQ/GRBM counters and derived figures:
+per kernel (counters SUMMED over all its dispatches of the run - a kernel launched once per
+pyramid level has dispatches of very different sizes, and the last one alone, the smallest,
+under-fills the chip), raw SQ/GRBM counters and derived figures:
   valu_per_wave          SQ_INSTS_VALU / SQ_WAVES
   valu_active_of_wave    SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   (quad-cycles both)
   parked_of_wave         SQ_WAIT_ANY / SQ_WAVE_CYCLES           (s_waitcnt / barrier)
@@ -22,9 +24,9 @@ NSIMD = 256*4
 
 def counters(sub):
     f = glob.glob(os.path.join(src, sub, '*', '*_counter_collection.csv'))[0]
-    agg = collections.defaultdict(dict)
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name']][r['Counter_Name']] = float(r['Counter_Value'])     # last dispatch wins
+        agg[r['Kernel_Name']][r['Counter_Name']] += float(r['Counter_Value'])
     return agg
 
 
