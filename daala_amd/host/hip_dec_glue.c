@@ -675,6 +675,12 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   }
   nw = p->nworkers < 1 ? 1 : p->nworkers;
   if (nw > nframes) nw = nframes;
+  /* workers take frames independently, which only keyframes allow: a stream with a packet
+     that is not one (daala_packet_iskeyframe, src/internal.c:654) is decoded in order by
+     one worker */
+  for (i = 0; i < nframes; i++) {
+    if (J.pkt_len[i] > 0 && !(J.pkt[i][0] & 0x40)) nw = 1;
+  }
   th = (pthread_t *)calloc(nw, sizeof(*th));
   if (th == NULL) {
     free(J.pkt);

@@ -289,6 +289,10 @@ def test_inter_stream_through_the_decoder_driver_host_path():
     nd, out, sec, dsec = H.decode(prm, H.headers(prm), pk)
     assert nd == nf
     assert np.array_equal(out[-1], rec)
+    # asking for several workers must not split a stream that has P frames
+    prm4 = H.Params(w, h, 20, 7, 1, 4, 0, 0)
+    nd4, out4, _, _ = H.decode(prm4, H.headers(prm4), pk)
+    assert nd4 == nf and np.array_equal(out4, out)
 
 
 def test_rate_only_coder_equals_reference_od_pvq_rate():

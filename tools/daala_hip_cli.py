@@ -1,16 +1,17 @@
-"""Command line front end of the MI355X Daala path (intra-only streams):
+"""Command line front end of the MI355X Daala path:
 
-  python tools/daala_hip_cli.py encode in.y4m out.dhip [-v 20] [--workers N] [--no-device]
+  python tools/daala_hip_cli.py encode in.y4m out.dhip [-v 20] [-k 1] [--workers N] [--no-device]
   python tools/daala_hip_cli.py decode out.dhip out.y4m [--workers N] [--no-device]
 
 (The drivers live in the reference-side integration library, which is built from the
 reference sources in the dev container - see INTEGRATION.md "Seam 2, live" - so this
 front end sits beside it in tools/, not in the product package.)
 
-encode: every frame is coded as a keyframe by the reference encoder's serial stage on
-N host workers with the device feed answering the state-free PVQ searches
-(daala_amd/host/hip_enc_glue.c); the packets are byte-identical to the reference
-encoder's.  decode: reference symbol parse on the host workers, pixel-domain stage on
+encode: with -k 1 (default) every frame is a keyframe coded by the reference encoder's serial
+stage on N host workers with the device feed answering the state-free PVQ searches
+(daala_amd/host/hip_enc_glue.c); -k K > 1 codes an inter stream (keyframe every K frames)
+in order on one worker; -v 0 codes lossless frames (Haar planes from the device).  The
+packets are byte-identical to the reference encoder's.  decode: reference symbol parse on the host workers, pixel-domain stage on
 the device.  The reference's examples write Ogg; libogg is not part of this path, so
 the container is minimal: b"DHIP1\\n", then little-endian u32 fields (width, height,
 quant, masking, fps_n, fps_d, nframes, header bytes), the header-packet blob and the
@@ -40,7 +41,8 @@ def cmd_encode(a):
     if not frames:
         raise SystemExit('no frames in %s' % a.input)
     buf = np.ascontiguousarray(np.concatenate(frames))
-    prm = H.Params(rd.width, rd.height, a.quant, 7, 0 if a.no_masking else 1, a.workers, 0, a.batch)
+    prm = H.Params(rd.width, rd.height, a.quant, 7, 0 if a.no_masking else 1, a.workers, 0, a.batch,
+                   a.keyframe_rate)
     t0 = time.perf_counter()
     n, pk, st = H.encode(prm, buf, len(frames), use_device=0 if a.no_device else 1, device=a.device)
     if n < 0:
@@ -87,7 +89,8 @@ def main(argv=None):
     e = sub.add_parser('encode')
     e.add_argument('input')
     e.add_argument('output')
-    e.add_argument('-v', '--quant', type=int, default=20, help='OD_SET_QUANT (0 = lossless is not on the device path)')
+    e.add_argument('-v', '--quant', type=int, default=20, help='OD_SET_QUANT (0 = lossless)')
+    e.add_argument('-k', '--keyframe-rate', type=int, default=1, help='OD_SET_KEYFRAME_RATE (1 = intra only)')
     e.add_argument('--no-masking', action='store_true')
     e.add_argument('--limit', type=int, default=None)
     e.add_argument('--batch', type=int, default=0, help='frames resident on the device at once (0: all)')
@@ -100,8 +103,8 @@ def main(argv=None):
         p.add_argument('--no-device', action='store_true')
     a = ap.parse_args(argv)
     if a.cmd == 'encode':
-        if a.quant < 1:
-            raise SystemExit('quant must be >= 1 here (lossless frames use the Haar path: od_hip_forward_haar)')
+        if a.quant < 0 or a.keyframe_rate < 1:
+            raise SystemExit('quant must be >= 0 and the keyframe rate >= 1')
         cmd_encode(a)
     else:
         cmd_decode(a)
