@@ -290,8 +290,8 @@ def test_lossless_frames_through_both_seams():
 def test_inter_stream_encoded_through_the_seam():
     """configs[3] on the ENCODER side: a session with keyframe_rate 4 (one worker, frames in
     order).  Keyframes take the device feed, deringing and distortions as usual; every P frame's
-    od_state_mc_predict calls (od_mv_est evaluates predictions through it, src/mcenc.c, and
-    od_predict_frame forms the final one, src/encode.c:2219) run on the device in check mode.
+    od_state_mc_predict call (od_predict_frame, src/encode.c:2219: the frame the residual is taken
+    from; the calls in src/mcenc.c exist only in OD_ANIMATE builds) runs on the device in check mode.
     The packets must equal the pure reference encoder's inter stream."""
     from test_hipenc_cpu import inter_stream
     w, h, nf = 176, 144, 5
