@@ -35,13 +35,13 @@ def frames_of(w, h, count, seed0, step=(3, 5)):
     return out
 
 
-def reference(w, h, buf, nframes, quant, masking, keyrate):
+def reference(w, h, buf, nframes, quant, masking, keyrate, complexity=7):
     import daala_amd.hipenc as H
     lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so'))
     lib.probe_encode_frames.restype = ctypes.c_long
     out = np.zeros(max(1 << 22, buf.size*2), np.uint8)
     fnv, sec = ctypes.c_uint(), ctypes.c_double()
-    n = lib.probe_encode_frames(w, h, nframes, quant, 7, masking, keyrate, buf.ctypes.data_as(U8P),
+    n = lib.probe_encode_frames(w, h, nframes, quant, complexity, masking, keyrate, buf.ctypes.data_as(U8P),
                                 ctypes.byref(fnv), ctypes.byref(sec), out.ctypes.data_as(U8P), out.size)
     assert n > 0
     return H.split_packets(out, nframes), sec.value
