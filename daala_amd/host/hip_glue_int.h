@@ -50,6 +50,8 @@ void od_encode_checkpoint_cpu(const daala_enc_ctx *enc, od_rollback_buffer *rbuf
 void od_encode_rollback_cpu(daala_enc_ctx *enc, const od_rollback_buffer *rbuf);
 
 double od_hipenc_now(void);
+/* src/pvq_encoder.c:589 (no prototype in the reference's headers) */
+int od_rdo_quant(od_coeff x, int q, double delta0);
 
 /* hip_pvq_search.c: pvq_search_rdo_double, bit-identical, for the many searches pvq_theta
    makes of one vector (what does not depend on the candidate is computed once, the greedy

@@ -328,12 +328,12 @@ static int neg_interleave(int x, int ref) {       /* src/pvq_encoder.c:236-240 *
   else return x - 1;
 }
 
-/* pvq_theta (src/pvq_encoder.c:311-511) for keyframes.  L/band/blk: the feed records of
-   this band (keyframe luma with a device feed), or L == NULL. */
+/* pvq_theta (src/pvq_encoder.c:311-511).  L/band/blk: the feed records of this band
+   (keyframe luma with a device feed), or L == NULL. */
 static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n,
  int q0, od_coeff *y, int *itheta, int *max_theta, int *vk, double beta,
- double *skip_diff, int robust, int pli, const od_adapt_ctx *adapt, int bs,
- const int16_t *qm, const int16_t *qm_inv, const od_hip_feed_level *L, int band,
+ double *skip_diff, int robust, int is_keyframe, int pli, const od_adapt_ctx *adapt,
+ int bs, const int16_t *qm, const int16_t *qm_inv, const od_hip_feed_level *L, int band,
  int blk) {
   double g;
   double gr;
@@ -408,7 +408,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
     gr = 0;
     cgr = 0;
   }
-  cfl_enabled = pli != 0 && !OD_DISABLE_CFL;
+  cfl_enabled = is_keyframe && pli != 0 && !OD_DISABLE_CFL;
   if (cfl_enabled) cgr = 1;
   icgr = (int)floor(.5 + cgr);
   gain_offset = cgr - icgr;
@@ -428,7 +428,22 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
   s = 1;
   corr = corr/(1e-100 + g*gr);
   corr = OD_MAXF(OD_MINF(corr, 1.), -1.);
-  skip_dist = gain_weight*cg*cg;
+  if (is_keyframe) skip_dist = gain_weight*cg*cg;
+  else skip_dist = gain_weight*(cg - cgr)*(cg - cgr) + cgr*cg*(2 - 2*corr);
+  if (!is_keyframe) {
+    /* noref with gain 0 is not allowed on inter frames, skip is (:385-398); the rate of
+       (qg = 0, theta = 0, no codeword) is 0 */
+    double scgr;
+    scgr = OD_MAXF(0, gain_offset);
+    if (icgr == 0) {
+      best_dist = gain_weight*(cg - scgr)*(cg - scgr) + scgr*cg*(2 - 2*corr);
+    }
+    best_cost = best_dist + lambda*0.;
+    best_qtheta = 0;
+    *itheta = 0;
+    *max_theta = 0;
+    noref = 0;
+  }
   if (n <= OD_MAX_PVQ_SIZE && !r_null && corr > 0) {
     /* :399-448, the reference's arithmetic: its input depends on the reconstruction of the
        neighbours (or of luma), so there is nothing the device could have prepared */
@@ -459,7 +474,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         double qtheta;
         double t0;
         qtheta = od_pvq_compute_theta(j, ts);
-        k = od_pvq_compute_k(qcg, j, qtheta, 0, n, beta, 1);
+        k = od_pvq_compute_k(qcg, j, qtheta, 0, n, beta, robust || is_keyframe);
         t0 = T.time_cpu ? od_hipenc_now() : 0;
         cos_dist = od_hip_search_run(&sc, k, y_tmp, qcg*cg*sin(theta)*sin(qtheta));
         if (T.time_cpu) {
@@ -476,7 +491,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
            cost is at least the cost with the codeword bits left out (k = 0 below: only the
            theta/gain terms of od_pvq_rate, which can be negative).  A candidate that cannot
            beat the incumbent even so is not priced. */
-        if (!(dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, NULL, 0, n, 1, pli, bs)
+        if (!(dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, NULL, 0, n, is_keyframe, pli, bs)
          < best_cost)) continue;
         {
           double cw;
@@ -497,7 +512,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
               }
             }
           }
-          cost = dist + lambda*pvq_rate_with_codeword(cw, i, icgr, j, ts, 1, pli);
+          cost = dist + lambda*pvq_rate_with_codeword(cw, i, icgr, j, ts, is_keyframe, pli);
         }
         if (cost < best_cost) {
           best_cost = cost;
@@ -513,7 +528,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
       }
     }
   }
-  if (n <= OD_MAX_PVQ_SIZE && (pli == 0 || corr < .5 || cg < 2.)) {
+  if (n <= OD_MAX_PVQ_SIZE && ((is_keyframe && pli == 0) || corr < .5 || cg < 2.)) {
     /* :452-481 */
     int c;
     int from_feed;
@@ -533,7 +548,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         int j;
         i = OD_MAXI(1, (int)floor(cg)) + c;
         if (L->qg[c*nrec + rec] != i
-         || L->k[c*nrec + rec] != od_pvq_compute_k(i, -1, -1, 1, n, beta, 1)) from_feed = 0;
+         || L->k[c*nrec + rec] != od_pvq_compute_k(i, -1, -1, 1, n, beta, robust || is_keyframe)) from_feed = 0;
         /* a codeword of the search has exactly K pulses and a cosine in [0, 1]: cheap
            integrity checks of the two fields that are taken on trust */
         yc = L->y + (size_t)2*L->nblk*(L->off[band] - 1) + ((size_t)c*L->nblk + blk)*n;
@@ -573,7 +588,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         T.st.dev_hits++;
         dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
         if (!(dist <= best_cost)) continue;         /* no-reference rate = codeword bits >= 0 */
-        cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, yc, k, n, 1, pli, bs);
+        cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, yc, k, n, is_keyframe, pli, bs);
         if (cost <= best_cost) {
           best_cost = cost;
           best_dist = dist;
@@ -597,7 +612,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         double qcg;
         double t0;
         qcg = i;
-        k = od_pvq_compute_k(qcg, -1, -1, 1, n, beta, 1);
+        k = od_pvq_compute_k(qcg, -1, -1, 1, n, beta, robust || is_keyframe);
         t0 = T.time_cpu ? od_hipenc_now() : 0;
         cos_dist = od_hip_search_run(&sc, k, y_tmp, qcg*cg);
         if (T.time_cpu) {
@@ -610,7 +625,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         else T.st.cpu_other++;
         dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
         if (!(dist <= best_cost)) continue;
-        cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, y_tmp, k, n, 1, pli, bs);
+        cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, y_tmp, k, n, is_keyframe, pli, bs);
         if (cost <= best_cost) {
           best_cost = cost;
           best_dist = dist;
@@ -632,7 +647,10 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
   if (noref) {
     if (qg == 0) skip = OD_PVQ_SKIP_ZERO;
   }
-  else if (qg == icgr && *itheta == 0 && !cfl_enabled) skip = OD_PVQ_SKIP_COPY;
+  else {
+    if (!is_keyframe && qg == 0) skip = (icgr ? OD_PVQ_SKIP_ZERO : OD_PVQ_SKIP_COPY);
+    if (qg == icgr && *itheta == 0 && !cfl_enabled) skip = OD_PVQ_SKIP_COPY;
+  }
   /* Synthesize like the decoder would (:493-503). */
   if (skip) {
     if (skip == OD_PVQ_SKIP_COPY) OD_COPY(out, r0, n);
@@ -645,8 +663,8 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
   }
   *vk = k;
   *skip_diff += skip_dist - best_dist;
-  (void)robust;
-  return noref ? qg : neg_interleave(qg, icgr);
+  if (is_keyframe) return noref ? qg : neg_interleave(qg, icgr);
+  return noref ? qg - 1 : neg_interleave(qg + 1, icgr + 1);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -693,8 +711,8 @@ static void pvq_restore(const pvq_ckpt *c, daala_enc_ctx *enc, int pli, int bs, 
 }
 
 /* od_pvq_encode (src/pvq_encoder.c:645-815) for keyframes */
-static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
- od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,
+static int pvq_encode_block(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
+ od_coeff *out, int q0, int pli, int bs, const double *beta, int robust, int is_keyframe,
  int q_scaling, int bx, int by, const int16_t *qm, const int16_t *qm_inv) {
   int theta[PVQ_MAX_PARTITIONS];
   int max_theta[PVQ_MAX_PARTITIONS];
@@ -718,6 +736,9 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
   int skip_rest;
   int skip_dir;
   int gt0;
+  int dc_quant;
+  int skip_theta_value;
+  double dc_rate;
   const unsigned char *pvq_qm;
   const od_hip_feed_level *L;
   int blk;
@@ -732,12 +753,13 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
   nb0 = nb_bands;
   off = &OD_BAND_OFFSETS[bs][1];
   gt0 = (pli != 0)*OD_NBSIZES*PVQ_MAX_PARTITIONS + bs*PVQ_MAX_PARTITIONS;
+  dc_quant = OD_MAXI(1, q0*pvq_qm[od_qm_get_index(bs, 0)] >> 4);
   for (i = 0; i < nb_bands; i++) size[i] = off[i + 1] - off[i];
   skip_diff = 0;
   flip = 0;
   /* chroma of a keyframe is predicted from luma: negate the reference when the first
      band points away from it (:697-709) */
-  if (pli != 0) {
+  if (pli != 0 && is_keyframe) {
     double xy;
     xy = 0;
     for (i = off[0]; i < off[1]; i++) {
@@ -751,7 +773,7 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
   /* the feed records of this block: keyframe luma, level 3 - bs, bx/by in 4x4 units */
   L = NULL;
   blk = 0;
-  if (T.lev != NULL && pli == 0) {
+  if (T.lev != NULL && pli == 0 && is_keyframe) {
     L = &T.lev[3 - bs];
     blk = (by >> bs)*L->nbx + (bx >> bs);
     if (L->g == NULL || blk < 0 || blk >= L->nblk || L->nbands != nb_bands) L = NULL;
@@ -779,14 +801,19 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     int q;
     q = OD_MAXI(1, q0*pvq_qm[od_qm_get_index(bs, i + 1)] >> 4);
     qg[i] = hip_pvq_theta(out + off[i], in + off[i], ref + off[i], size[i], q, y + off[i],
-     &theta[i], &max_theta[i], &k[i], beta[i], &skip_diff, robust, pli, adapt, bs,
-     qm + off[i], qm_inv + off[i], L, i, blk);
+     &theta[i], &max_theta[i], &k[i], beta[i], &skip_diff, robust, is_keyframe, pli, adapt,
+     bs, qm + off[i], qm_inv + off[i], L, i, blk);
   }
   pvq_save(&buf, enc, pli, bs, nb0, gt0);
-  out[0] = 0;
+  if (is_keyframe) out[0] = 0;
+  else {
+    dc_rate = -OD_LOG2((double)(skip_cdf[1] - skip_cdf[0])/(double)skip_cdf[0]);
+    out[0] = od_rdo_quant(in[0] - ref[0], dc_quant, dc_rate);
+  }
   tell = od_ec_enc_tell_frac(&enc->ec);
   /* Code as if we're not skipping. */
-  od_encode_cdf_adapt(&enc->ec, 0, skip_cdf, 4 + (pli == 0 && bs > 0), adapt->skip_increment);
+  od_encode_cdf_adapt(&enc->ec, out[0] != 0, skip_cdf, 4 + (pli == 0 && bs > 0),
+   adapt->skip_increment);
 #if OD_SIGNAL_Q_SCALING
   if (bs == OD_NBSIZES - 1 && pli == 0) {
     od_encode_quantizer_scaling(enc, q_scaling, bx >> (OD_NBSIZES - 1), by >> (OD_NBSIZES - 1), 0);
@@ -794,8 +821,9 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
 #endif
   cfl_encoded = 0;
   skip_rest = 1;
+  skip_theta_value = is_keyframe ? -1 : 0;
   for (i = 1; i < nb_bands; i++) {
-    if (theta[i] != -1 || qg[i]) skip_rest = 0;
+    if (theta[i] != skip_theta_value || qg[i]) skip_rest = 0;
   }
   skip_dir = 0;
   if (nb_bands > 1) {
@@ -804,24 +832,24 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
       int tmp;
       tmp = 1;
       for (j = i + 1; j < nb_bands; j += 3) {
-        if (theta[j] != -1 || qg[j]) tmp = 0;
+        if (theta[j] != skip_theta_value || qg[j]) tmp = 0;
       }
       skip_dir |= tmp << i;
     }
   }
-  if (theta[0] == -1 && qg[0] == 0 && skip_rest) nb_bands = 0;
+  if (theta[0] == skip_theta_value && qg[0] == 0 && skip_rest) nb_bands = 0;
   for (i = 0; i < nb_bands; i++) {
     if (i == 0 || (!skip_rest && !(skip_dir & (1 << ((i - 1)%3))))) {
       od_ref_pvq_encode_partition(&enc->ec, qg[i], theta[i], max_theta[i], y + off[i], size[i],
-       k[i], model, adapt, exg + i, ext + i, 1, gt0 + i, 1, i == 0 && (i < nb_bands - 1),
-       skip_rest, bs);
+       k[i], model, adapt, exg + i, ext + i, robust || is_keyframe, gt0 + i, is_keyframe,
+       i == 0 && (i < nb_bands - 1), skip_rest, bs);
     }
     if (i == 0 && !skip_rest && bs > 0) {
       od_encode_cdf_adapt(&enc->ec, skip_dir,
        &adapt->pvq.pvq_skip_dir_cdf[(pli != 0) + 2*(bs - 1)][0], 7,
        adapt->pvq.pvq_skip_dir_increment);
     }
-    if (pli != 0 && theta[i] != -1 && !cfl_encoded) {
+    if (pli != 0 && is_keyframe && theta[i] != -1 && !cfl_encoded) {
       od_ec_enc_bits(&enc->ec, flip, 1);
       cfl_encoded = 1;
     }
@@ -830,22 +858,34 @@ static int pvq_encode_keyframe(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
   /* the rate of skipping the AC instead (:778-787) */
   {
     double skip_rate;
-    skip_rate = -OD_LOG2((skip_cdf[2] - skip_cdf[1])/
+    int skip_flag;
+    skip_flag = 2 + (out[0] != 0);
+    skip_rate = -OD_LOG2((skip_cdf[skip_flag] - skip_cdf[skip_flag - 1])/
      (double)skip_cdf[3 + (pli == 0 && bs > 0)]);
     tell -= (int)floor(.5 + 8*skip_rate);
   }
   if (nb_bands == 0 || skip_diff <= OD_PVQ_LAMBDA/8*tell) {
     /* skip: everything back as it was (:788-813) */
-    out[0] = 0;
+    if (is_keyframe) out[0] = 0;
+    else {
+      dc_rate = -OD_LOG2((double)(skip_cdf[3] - skip_cdf[2])/(double)(skip_cdf[2] - skip_cdf[1]));
+      out[0] = od_rdo_quant(in[0] - ref[0], dc_quant, dc_rate);
+    }
     pvq_restore(&buf, enc, pli, bs, nb0, gt0);
-    od_encode_cdf_adapt(&enc->ec, 2, skip_cdf, 4 + (pli == 0 && bs > 0), adapt->skip_increment);
+    od_encode_cdf_adapt(&enc->ec, 2 + (out[0] != 0), skip_cdf, 4 + (pli == 0 && bs > 0),
+     adapt->skip_increment);
 #if OD_SIGNAL_Q_SCALING
     if (bs == OD_NBSIZES - 1 && pli == 0) {
-      od_encode_quantizer_scaling(enc, 0, bx >> (OD_NBSIZES - 1), by >> (OD_NBSIZES - 1), 1);
+      int skip;
+      skip = out[0] == 0;
+      if (skip) q_scaling = 0;
+      od_encode_quantizer_scaling(enc, q_scaling, bx >> (OD_NBSIZES - 1), by >> (OD_NBSIZES - 1),
+       skip);
     }
 #endif
-    for (i = 1; i < 1 << (2*bs + 4); i++) out[i] = 0;
-    return 1;
+    if (is_keyframe) for (i = 1; i < 1 << (2*bs + 4); i++) out[i] = 0;
+    else for (i = 1; i < 1 << (2*bs + 4); i++) out[i] = ref[i];
+    if (out[0] == 0) return 1;
   }
   return 0;
 }
@@ -879,10 +919,6 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
  const int16_t *qm_inv) {
   int n2;
   int ret;
-  if (!is_keyframe) {
-    return od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe,
-     q_scaling, bx, by, qm, qm_inv);
-  }
   n2 = 1 << (2*bs + 4);
   if (T.check) {
     /* OD_CHECKASM for the block: ours first, then the reference's own od_pvq_encode from
@@ -910,7 +946,7 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     offs0 = enc->ec.offs;
     sbi = (by >> (OD_NBSIZES - 1))*enc->state.nhsb + (bx >> (OD_NBSIZES - 1));
     sbq = enc->state.sb_q_scaling[sbi];
-    ret = pvq_encode_keyframe(enc, ref, in, out, q0, pli, bs, beta, robust, q_scaling, bx, by,
+    ret = pvq_encode_block(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
      qm, qm_inv);
     memcpy(out1, out, sizeof(od_coeff)*n2);
     memcpy(ref1, ref, sizeof(od_coeff)*n2);
@@ -940,7 +976,7 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     free(rb);
     return ret2;
   }
-  ret = pvq_encode_keyframe(enc, ref, in, out, q0, pli, bs, beta, robust, q_scaling, bx, by,
+  ret = pvq_encode_block(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
    qm, qm_inv);
   return ret;
 }
