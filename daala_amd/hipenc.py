@@ -237,6 +237,13 @@ def mc_stats():
     return int(out[0]), int(out[1])
 
 
+def tail_frames():
+    """Frames of the last decode whose pixel-domain stage (od_hip_decode_tail) ran on the device."""
+    f = hipenc().od_hipdec_tail_frames
+    f.restype = ctypes.c_long
+    return int(f())
+
+
 def decode_blob(prm, hdr, buf, nframes, use_device=0, device=0):
     """The same on a length-prefixed packet blob as od_hipenc_encode_frames writes it."""
     lib = hipenc()

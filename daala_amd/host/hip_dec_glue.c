@@ -76,20 +76,29 @@ typedef struct dec_tls {
 static __thread dec_tls D;
 
 static __thread long mc_dev_frames;
+static __thread long tail_dev_frames;     /* frames whose pixel-domain stage ran on the device */
+static long g_tail_dev_frames;
 static __thread long mc_check_fail;
 static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
 static long g_mc_check_fail;
+
+long od_hipdec_tail_frames(void) {
+  return g_tail_dev_frames;
+}
 
 void od_hipdec_mc_stats(long out[2]) {
   out[0] = g_mc_dev_frames;
   out[1] = g_mc_check_fail;
 }
 
-/* Device decode applies to DCT keyframes only (what the stage was verified for):
-   frame type and quantizers are known before the first block is parsed
-   (src/decode.c:1195, :989-993). */
+/* Device decode applies to DCT frames, I and P: the pixel-domain stage after the block
+   loop (src/decode.c:1032-1155) is the same for both except that only keyframes are
+   smoothed (:1140); every block of a P frame - skipped ones too - leaves its coefficients
+   in dtmp and goes through idct_2d (:637).  B frames are left to the reference.  Frame type
+   and quantizers are known before the first block is parsed (src/decode.c:1195, :989-993). */
 static int on_device(void) {
-  return D.ctx != NULL && D.dec != NULL && D.dec->state.frame_type == OD_I_FRAME
+  return D.ctx != NULL && D.dec != NULL
+   && (D.dec->state.frame_type == OD_I_FRAME || D.dec->state.frame_type == OD_P_FRAME)
    && D.dec->state.quantizer[0] > 0;
 }
 
@@ -184,11 +193,12 @@ static int device_frame(od_state *state) {
   }
   if (od_hip_set_decode_info(D.ctx, 0, state->dering_flags, bskip,
    state->skip_stride) != 0) return -3;
-  if (od_hip_decode_tail(D.ctx, 0, 1, thr, quant, 1) != 0) return -4;
+  if (od_hip_decode_tail(D.ctx, 0, 1, thr, quant, state->frame_type == OD_I_FRAME) != 0) return -4;
   for (pli = 0; pli < nplanes; pli++) {
     if (od_hip_download_recon(D.ctx, 0, pli, D.rec[pli]) != 0) return -5;
   }
   D.t_device += now_s() - t0;
+  tail_dev_frames++;
   return 0;
 }
 
@@ -427,6 +437,8 @@ static void *dworker(void *arg) {
   }
   J->t_device += D.t_device;
   g_mc_dev_frames += mc_dev_frames;
+  g_tail_dev_frames += tail_dev_frames;
+  tail_dev_frames = 0;
   g_mc_check_fail += mc_check_fail;
   mc_dev_frames = mc_check_fail = 0;
   {
@@ -638,6 +650,7 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   }
   if (use_device && od_hip_device_count() <= device) return OD_HIP_ENODEV;
   g_mc_dev_frames = g_mc_check_fail = 0;
+  g_tail_dev_frames = 0;
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;

@@ -219,7 +219,8 @@ def test_hip_encoder_stress_content(kind, quant, masking):
 
 def test_inter_stream_motion_compensation_on_the_device():
     """configs[3], first live step: an inter stream from the pure reference encoder decoded by
-    one worker with the device - keyframes through od_hip_decode_tail, every P frame's
+    one worker with the device - every frame's pixel-domain stage through od_hip_decode_tail
+    (P frames too: same stage minus the keyframe smoothing), every P frame's
     od_state_mc_predict (OBMC of the whole frame) through od_hip_mc_predict_blocks, in check
     mode (the reference's own prediction is computed beside it and compared).  Pictures must
     equal the plain reference decode, the last one the encoder's reconstruction."""
@@ -233,6 +234,7 @@ def test_inter_stream_motion_compensation_on_the_device():
     assert n0 == nf and nd == nf
     frames, bad = H.mc_stats()
     assert frames == 4 and bad == 0          # frames 1, 2, 3 and 5 are P frames
+    assert H.tail_frames() == nf             # I and P frames: inverse + filters + clamp on the device
     assert np.array_equal(got, want)
     assert np.array_equal(got[-1], rec)
 
