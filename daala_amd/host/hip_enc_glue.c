@@ -798,6 +798,7 @@ static void *worker(void *arg) {
   free(T.dist[1]);
   free(T.dist[2]);
   if (enc != NULL) daala_encode_free(enc);
+  od_hipenc_mc_cache_free();             /* this thread's prediction cache (hip_mc_host.c) */
   return NULL;
 }
 

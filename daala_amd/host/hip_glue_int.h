@@ -88,6 +88,7 @@ void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned c
 void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsigned char *src,
  int systride, int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz);
 void od_hipenc_mc_cache_flush(void);
+void od_hipenc_mc_cache_free(void);
 void od_hipenc_mc_cache_stats(int64_t *hits, int64_t *misses);
 
 /* hip_pvq_host.c */

@@ -313,6 +313,14 @@ void od_hipenc_mc_cache_flush(void) {
   }
 }
 
+/* called by a worker thread before it exits */
+void od_hipenc_mc_cache_free(void) {
+  free(mc_keys);
+  free(mc_data);
+  mc_keys = NULL;
+  mc_data = NULL;
+}
+
 void od_hipenc_mc_cache_stats(int64_t *hits, int64_t *misses) {
   *hits = mc_hits;
   *misses = mc_misses;
