@@ -183,9 +183,9 @@ static void mc_predict1fmv8_compute(od_state *state, unsigned char *dst, const u
     /* taps paired (1, 2), (3, 4), (0, 5): in every phase each pair holds at most one large
        positive tap (<= 122), so a pair sum of byte x tap products stays inside 16 bits
        (<= 255*122, >= -255*20*2) and the saturating multiply-add never saturates */
-    const __m128i c12 = _mm_set1_epi16((short)((fx[1] & 255) | (fx[2] << 8)));
-    const __m128i c34 = _mm_set1_epi16((short)((fx[3] & 255) | (fx[4] << 8)));
-    const __m128i c05 = _mm_set1_epi16((short)((fx[0] & 255) | (fx[5] << 8)));
+    const __m128i c12 = _mm_set1_epi16((short)(uint16_t)((fx[1] & 255) | ((unsigned)(fx[2] & 255) << 8)));
+    const __m128i c34 = _mm_set1_epi16((short)(uint16_t)((fx[3] & 255) | ((unsigned)(fx[4] & 255) << 8)));
+    const __m128i c05 = _mm_set1_epi16((short)(uint16_t)((fx[0] & 255) | ((unsigned)(fx[5] & 255) << 8)));
     const __m128i norm = _mm_set1_epi16((short)OD_SUBPEL_COEFF_NORMALIZE);
     for (j = -OD_SUBPEL_TOP_APRON_SZ; j < yblk_sz + OD_SUBPEL_BOTTOM_APRON_SZ; j++) {
       for (i = 0; i < xblk_sz; i += 8) {
@@ -228,9 +228,9 @@ static void mc_predict1fmv8_compute(od_state *state, unsigned char *dst, const u
   }
   buff_p = buff + xblk_sz*OD_SUBPEL_TOP_APRON_SZ;
   if (mvyf) {
-    const __m128i c01 = _mm_set1_epi32((fy[0] & 0xffff) | (fy[1] << 16));
-    const __m128i c23 = _mm_set1_epi32((fy[2] & 0xffff) | (fy[3] << 16));
-    const __m128i c45 = _mm_set1_epi32((fy[4] & 0xffff) | (fy[5] << 16));
+    const __m128i c01 = _mm_set1_epi32((int)((uint32_t)(fy[0] & 0xffff) | ((uint32_t)(fy[1] & 0xffff) << 16)));
+    const __m128i c23 = _mm_set1_epi32((int)((uint32_t)(fy[2] & 0xffff) | ((uint32_t)(fy[3] & 0xffff) << 16)));
+    const __m128i c45 = _mm_set1_epi32((int)((uint32_t)(fy[4] & 0xffff) | ((uint32_t)(fy[5] & 0xffff) << 16)));
     const __m128i rnd = _mm_set1_epi32(OD_SUBPEL_RND_OFFSET3);
     for (j = 0; j < yblk_sz; j++) {
       for (i = 0; i < xblk_sz; i += 8) {
