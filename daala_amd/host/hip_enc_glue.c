@@ -238,15 +238,12 @@ int od_hipenc_dist_hook(daala_enc_ctx *enc, const od_coeff *x, const od_coeff *y
    dtmp[0] plane at the block's position: exactly one block of the device's forward
    pyramid, which the feed carries.  Anything else (chroma, od_compute_dist's 8x8
    error transform into a stack buffer) runs the context's C transform. */
-static int fdct_min_bs = -1;      /* smallest block size served from the feed (HIPENC_FDCT_MIN_BS) */
+/* smallest block size served from the feed (HIPENC_FDCT_MIN_BS, read by od_hipenc_open
+   before any worker exists) */
+static int fdct_min_bs = FDCT_MIN_BS_DEFAULT;
 
 static void fdct_from_feed(int bs, od_coeff *y, int ystride, const od_coeff *x,
  int xstride) {
-  if (fdct_min_bs < 0) {
-    const char *e;
-    e = getenv("HIPENC_FDCT_MIN_BS");
-    fdct_min_bs = e != NULL ? atoi(e) : FDCT_MIN_BS_DEFAULT;
-  }
   if (bs >= fdct_min_bs && T.lev != NULL && T.enc != NULL
    && T.enc->state.frame_type == OD_I_FRAME) {
     const od_state *st;
@@ -847,6 +844,8 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     S->sample_every = e != NULL ? atoi(e) : 256;
     e = getenv("HIPENC_TIME");
     S->time_cpu = e != NULL && atoi(e) != 0;
+    e = getenv("HIPENC_FDCT_MIN_BS");
+    if (e != NULL) fdct_min_bs = atoi(e);
   }
   S->use_device = use_device;
   S->device = device;

@@ -135,6 +135,14 @@ static void rc_laplace_special(hip_rc *c, int x, unsigned decay, int max) {
   if (shift) c->nbits += shift;
 }
 
+/* min(254, 256*ex/(ex + 256)) for ex < 4096 (what ex is after laplace_encode's shift),
+   filled when the library is loaded: no first-use race between workers */
+static uint8_t decay_tab[4096];
+static void __attribute__((constructor)) decay_tab_fill(void) {
+  int e;
+  for (e = 0; e < 4096; e++) decay_tab[e] = (uint8_t)OD_MINI(254, 256*e/(e + 256));
+}
+
 /* laplace_encode (src/laplace_encoder.c:101-138) */
 static inline void rc_laplace(hip_rc *c, int x, int ex_q8, int k) {
   int shift;
@@ -147,16 +155,7 @@ static inline void rc_laplace(hip_rc *c, int x, int ex_q8, int k) {
   k = (k + (1 << shift >> 1)) >> shift;
   xs = (x + (1 << shift >> 1)) >> shift;
   /* decay = min(254, 256*ex/(ex + 256)): ex < 4096 after the shift above, tabulated once */
-  if (ex_q8 < 4096) {
-    static uint8_t decay_tab[4096];
-    static int decay_tab_ready;
-    if (!decay_tab_ready) {
-      int e;
-      for (e = 0; e < 4096; e++) decay_tab[e] = (uint8_t)OD_MINI(254, 256*e/(e + 256));
-      __atomic_store_n(&decay_tab_ready, 1, __ATOMIC_RELEASE);
-    }
-    decay = decay_tab[ex_q8];
-  }
+  if (ex_q8 < 4096) decay = decay_tab[ex_q8];
   else decay = OD_MINI(254, 256*ex_q8/(ex_q8 + 256));
   sym = xs;
   if (sym > 15) sym = 15;
