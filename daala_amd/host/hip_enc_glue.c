@@ -111,7 +111,7 @@ int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
   int w;
   int i;
   if (T.dr == NULL || T.enc == NULL || state != &T.enc->state || T.dr_error
-   || state->frame_type != OD_I_FRAME || pli < 0 || pli > 2) {
+   || (state->frame_type != OD_I_FRAME && state->frame_type != OD_P_FRAME) || pli < 0 || pli > 2) {
     return 0;
   }
   if (!T.dr_valid) {
@@ -237,7 +237,9 @@ int od_hipenc_dist_hook(daala_enc_ctx *enc, const od_coeff *x, const od_coeff *y
    lapped picture + the split filters of its ancestors as input and writes into the
    dtmp[0] plane at the block's position: exactly one block of the device's forward
    pyramid, which the feed carries.  Anything else (chroma, od_compute_dist's 8x8
-   error transform into a stack buffer) runs the context's C transform. */
+   error transform into a stack buffer) runs the context's C transform.  P frames are NOT
+   served: their input plane is not the picture's transform near the padding - the encoder
+   overwrites the padded samples of ctmp with the prediction's (src/encode.c:2443-2457). */
 /* smallest block size served from the feed (HIPENC_FDCT_MIN_BS, read by od_hipenc_open
    before any worker exists) */
 static int fdct_min_bs = FDCT_MIN_BS_DEFAULT;
