@@ -211,8 +211,16 @@ __device__ __attribute__((noinline)) double pvq_rsqrt_slow(int i) {
   return 1./sqrt((double)i);
 }
 
-__device__ __forceinline__ double pvq_rsqrt_tab(const double *tab, int i) {
-  if (__builtin_expect(i < PVQ_RSQ_TAB, 1)) return tab[i];
+#ifndef PVQ_RSQ_LDS
+#define PVQ_RSQ_LDS 0         /* entries of the table also kept in LDS per workgroup (0: none) */
+#endif
+struct PvqRsq {
+  const double *tab;          // global, PVQ_RSQ_TAB entries
+  const double *lds;          // LDS copy of the first PVQ_RSQ_LDS entries, or nullptr
+};
+__device__ __forceinline__ double pvq_rsqrt_tab(const PvqRsq &r, int i) {
+  if (PVQ_RSQ_LDS > 0 && i < PVQ_RSQ_LDS) return r.lds[i];
+  if (__builtin_expect(i < PVQ_RSQ_TAB, 1)) return r.tab[i];
   return pvq_rsqrt_slow(i);
 }
 
@@ -281,7 +289,7 @@ __device__ __forceinline__ void pvq_vec_finish(PvqVec<N> &v, int g, int lane) {
 // pulses of this lane's chunk.
 template <int N>
 __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int lane, int k,
-                                                double g2, const double *rsq,
+                                                double g2, const PvqRsq &rsq,
                                                 int (&y)[PvqGeom<N>::NL], int &npulse_greedy,
                                                 int &npulse_rdo) {
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL;
@@ -578,6 +586,14 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     if (live && g == 0) a.out.g[rec] = sqrt(acc);
     return;
   }
+#if PVQ_RSQ_LDS > 0
+  __shared__ double RsqL[PVQ_RSQ_LDS];
+  for (int e = lane; e < PVQ_RSQ_LDS; e += 64) RsqL[e] = aa.rsq[e];
+  __syncthreads();
+  const PvqRsq rsq{aa.rsq, RsqL};
+#else
+  const PvqRsq rsq{aa.rsq, nullptr};
+#endif
   const double cg = a.out.cg[rec];                 // companded on the host from out.g
   PvqVec<N> v;
   v.neg = 0;
@@ -599,7 +615,7 @@ __global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelAr
     const int k = has ? pvq_k_noref(qcg, N, beta) : 0;
     int y[NL];
     int npg = 0, npr = 0;
-    const double cd = pvq_search_v3<N>(v, g, lane, k, qcg*cg, aa.rsq, y, npg, npr);
+    const double cd = pvq_search_v3<N>(v, g, lane, k, qcg*cg, rsq, y, npg, npr);
     if (aa.stats && has && g == 0) {
       atomicAdd(&aa.stats[0], (unsigned long long)npg*N);
       atomicAdd(&aa.stats[1], (unsigned long long)npr*N);

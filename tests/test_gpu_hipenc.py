@@ -149,7 +149,7 @@ def test_hip_encoder_packets_identical_4k_geometry():
 
 
 @pytest.mark.parametrize('w,h,quant,masking', [(355, 291, 20, 1), (64, 48, 1, 1), (130, 66, 60, 0),
-                                               (32, 32, 400, 1), (200, 120, 8, 1)])
+                                               (32, 32, 400, 1), (200, 120, 8, 1), (17, 9, 20, 1)])
 def test_hip_encoder_odd_geometry_and_quantizers(w, h, quant, masking):
     """Picture sizes that are not multiples of the block sizes (padding, edge gating of
     the split lapping) and quantizer extremes: device feed == plain reference search,
