@@ -237,6 +237,14 @@ def mc_stats():
     return int(out[0]), int(out[1])
 
 
+def md_stats():
+    """(prediction-side transforms of P frames served from the device pyramid, check-mode
+    mismatches) of the last decode."""
+    out = (ctypes.c_long*2)()
+    hipenc().od_hipdec_md_stats(out)
+    return int(out[0]), int(out[1])
+
+
 def tail_frames():
     """Frames of the last decode whose pixel-domain stage (od_hip_decode_tail) ran on the device."""
     f = hipenc().od_hipdec_tail_frames

@@ -66,6 +66,11 @@ typedef struct dec_tls {
   unsigned char *rec[3];    /* device output of the current frame */
   int pinned[6];            /* rec[0..2], stage[0..2] page-locked */
   od_coeff *stage[3];       /* page-locked staging copies of the coefficient planes */
+  od_dct_func_2d fdct_cpu[OD_NBSIZES];
+  od_coeff *md[3][4];       /* P frames: forward pyramid of the prediction (page-locked), per plane/level */
+  int md_valid;             /* md[][] holds this frame's prediction */
+  long md_hits;
+  long md_check_fail;
   long idct_skipped;
   long haar_skipped;
   int failed;
@@ -78,9 +83,16 @@ static __thread dec_tls D;
 static __thread long mc_dev_frames;
 static __thread long tail_dev_frames;     /* frames whose pixel-domain stage ran on the device */
 static long g_tail_dev_frames;
+static long g_md_hits;            /* prediction-side transforms served from the device pyramid */
+static long g_md_check_fail;
 static __thread long mc_check_fail;
 static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
 static long g_mc_check_fail;
+
+void od_hipdec_md_stats(long out[2]) {
+  out[0] = g_md_hits;
+  out[1] = g_md_check_fail;
+}
 
 long od_hipdec_tail_frames(void) {
   return g_tail_dev_frames;
@@ -118,6 +130,136 @@ void od_haar_inv(od_coeff *x, int xstride, const od_coeff *y, int ystride, int l
     return;
   }
   od_haar_inv_cpu(x, xstride, y, ystride, ln);
+}
+
+/* P frames, prediction side.  The decoder turns the motion-compensated picture into the
+   PVQ reference of every block: od_ref_plane_to_coeff + od_apply_prefilter_frame_sbs over the
+   plane (src/decode.c:997-1008), od_prefilter_split down the recursion (:848) and one
+   forward transform per coded block (:565) - the same lapped multi-size transform the encoder
+   applies to its input, i.e. one block of the device's forward PYRAMID at the block's level.
+   md_pyramid() runs it right after the device prediction; the four entry points then have
+   nothing left to do for the mctmp / mdtmp planes.  (The block sizes are parsed along with
+   the coefficients, so every level is needed, as in the encoder's RDO.)  Check mode keeps the
+   host path and compares block by block. */
+static int md_plane_of(const od_state *st, const od_coeff *p, od_coeff *const planes[]) {
+  int pli;
+  for (pli = 0; pli < st->info.nplanes && pli < 3; pli++) {
+    size_t n;
+    n = (size_t)(st->frame_width >> (pli > 0))*(st->frame_height >> (pli > 0));
+    if (planes[pli] != NULL && p >= planes[pli] && p < planes[pli] + n) return pli;
+  }
+  return -1;
+}
+
+static int md_served(void) {
+  return D.md_valid && !D.check && D.dec != NULL && D.dec->state.quantizer[0] > 0;
+}
+
+void od_ref_plane_to_coeff_cpu(od_state *state, od_coeff *dst, int lossless_p, od_img *src,
+ int pli);
+void od_ref_plane_to_coeff(od_state *state, od_coeff *dst, int lossless_p, od_img *src,
+ int pli) {
+  if (md_served() && state == &D.dec->state && pli >= 0 && pli < 3 && dst == state->mctmp[pli]) return;
+  od_ref_plane_to_coeff_cpu(state, dst, lossless_p, src, pli);
+}
+
+void od_apply_prefilter_frame_sbs_cpu(od_coeff *c0, int stride, int nhsb, int nvsb, int xdec,
+ int ydec);
+void od_apply_prefilter_frame_sbs(od_coeff *c0, int stride, int nhsb, int nvsb, int xdec,
+ int ydec) {
+  if (md_served() && md_plane_of(&D.dec->state, c0, D.dec->state.mctmp) >= 0) return;
+  od_apply_prefilter_frame_sbs_cpu(c0, stride, nhsb, nvsb, xdec, ydec);
+}
+
+void od_prefilter_split_cpu(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter);
+void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, int vfilter) {
+  if (md_served() && md_plane_of(&D.dec->state, c0, D.dec->state.mctmp) >= 0) return;
+  od_prefilter_split_cpu(c0, stride, bs, f, hfilter, vfilter);
+}
+
+static void md_fdct(int bs, od_coeff *y, int ystride, const od_coeff *x, int xstride) {
+  if (D.md_valid && D.dec != NULL && D.dec->state.quantizer[0] > 0) {
+    const od_state *st;
+    int pli;
+    st = &D.dec->state;
+    pli = md_plane_of(st, y, st->mdtmp);
+    if (pli >= 0) {
+      int w;
+      int n;
+      int lvl;
+      size_t off;
+      w = st->frame_width >> (pli > 0);
+      n = 4 << bs;
+      lvl = (pli > 0 ? 2 : 3) - bs;
+      off = (size_t)(y - st->mdtmp[pli]);
+      if (ystride == w && lvl >= 0 && D.md[pli][lvl] != NULL && (off/w & (n - 1)) == 0
+       && (off%w & (n - 1)) == 0) {
+        const od_coeff *src;
+        int i;
+        src = D.md[pli][lvl] + off;
+        if (D.check) {
+          od_coeff tmp[32*32];
+          (*D.fdct_cpu[bs])(tmp, n, x, xstride);
+          for (i = 0; i < n; i++) {
+            if (memcmp(tmp + i*n, src + (size_t)i*w, sizeof(od_coeff)*n) != 0) {
+              D.md_check_fail++;
+              break;
+            }
+          }
+        }
+        for (i = 0; i < n; i++) memcpy(y + (size_t)i*ystride, src + (size_t)i*w, sizeof(od_coeff)*n);
+        D.md_hits++;
+        return;
+      }
+    }
+  }
+  (*D.fdct_cpu[bs])(y, ystride, x, xstride);
+}
+
+#define MD_FDCT_HOOK(name, bs) \
+  static void name(od_coeff *y, int ystride, const od_coeff *x, int xstride) { \
+    md_fdct(bs, y, ystride, x, xstride); \
+  }
+MD_FDCT_HOOK(hook_md_fdct4, 0)
+MD_FDCT_HOOK(hook_md_fdct8, 1)
+MD_FDCT_HOOK(hook_md_fdct16, 2)
+MD_FDCT_HOOK(hook_md_fdct32, 3)
+
+/* prediction planes -> device -> forward pyramid -> page-locked level planes */
+static int md_pyramid(od_state *state, od_img *pred) {
+  const unsigned char *planes[3];
+  int strides[3];
+  int pli;
+  int lvl;
+  double t0;
+  t0 = now_s();
+  for (pli = 0; pli < 3; pli++) {
+    int nl;
+    size_t np;
+    nl = pli > 0 ? 3 : 4;
+    np = (size_t)(state->frame_width >> (pli > 0))*(state->frame_height >> (pli > 0))*sizeof(od_coeff);
+    np = (np + 4095) & ~(size_t)4095;
+    for (lvl = 0; lvl < nl; lvl++) {
+      if (D.md[pli][lvl] == NULL) {
+        void *mem;
+        mem = NULL;
+        if (posix_memalign(&mem, 4096, np) != 0) return -1;
+        (void)od_hip_host_register(mem, np);        /* failure to lock only costs speed */
+        D.md[pli][lvl] = (od_coeff *)mem;
+      }
+    }
+    planes[pli] = pred->planes[pli].data;
+    strides[pli] = pred->planes[pli].ystride;
+  }
+  if (od_hip_upload_planes(D.ctx, 0, planes, strides) != 0) return -2;
+  if (od_hip_forward_pyramid(D.ctx, 0, 1) != 0) return -3;
+  for (pli = 0; pli < 3; pli++) {
+    for (lvl = 0; lvl < (pli > 0 ? 3 : 4); lvl++) {
+      if (od_hip_download_level(D.ctx, 0, pli, lvl, D.md[pli][lvl]) != 0) return -4;
+    }
+  }
+  D.t_device += now_s() - t0;
+  return 0;
 }
 
 #define IDCT_HOOK(name, bs) \
@@ -389,8 +531,12 @@ static void *dworker(void *arg) {
       }
     }
     for (i = 0; i < OD_NBSIZES; i++) {
+      static const od_dct_func_2d fhooks[OD_NBSIZES] = {hook_md_fdct4, hook_md_fdct8, hook_md_fdct16,
+       hook_md_fdct32};
       D.idct_cpu[i] = st->opt_vtbl.idct_2d[i];
       st->opt_vtbl.idct_2d[i] = hooks[i];
+      D.fdct_cpu[i] = st->opt_vtbl.fdct_2d[i];
+      st->opt_vtbl.fdct_2d[i] = fhooks[i];
     }
   }
   pthread_mutex_lock(&J->mu);
@@ -410,8 +556,10 @@ static void *dworker(void *arg) {
     dp.packet = (unsigned char *)J->pkt[f];
     dp.bytes = J->pkt_len[f];
     D.dec = (od_dec_ctx *)dec;
+    D.md_valid = 0;
     rc = daala_decode_packet_in(dec, &dp);
     D.dec = NULL;
+    D.md_valid = 0;
     if (rc >= 0) {
       /* This frame's picture (od_img_copy into output_img, src/decode.c:1268).
          daala_decode_img_out is called once per packet, as the reference's player
@@ -439,6 +587,8 @@ static void *dworker(void *arg) {
   g_mc_dev_frames += mc_dev_frames;
   g_tail_dev_frames += tail_dev_frames;
   tail_dev_frames = 0;
+  g_md_hits += D.md_hits;
+  g_md_check_fail += D.md_check_fail;
   g_mc_check_fail += mc_check_fail;
   mc_dev_frames = mc_check_fail = 0;
   {
@@ -448,6 +598,13 @@ static void *dworker(void *arg) {
   }
   pthread_mutex_unlock(&J->mu);
   for (pli = 0; pli < 3; pli++) {
+    int lvl;
+    for (lvl = 0; lvl < 4; lvl++) {
+      if (D.md[pli][lvl] != NULL) {
+        (void)od_hip_host_unregister(D.md[pli][lvl]);
+        free(D.md[pli][lvl]);
+      }
+    }
     if (D.pinned[pli]) od_hip_host_unregister(D.rec[pli]);
     if (D.pinned[3 + pli]) od_hip_host_unregister(D.stage[pli]);
     free(D.stage[pli]);
@@ -602,6 +759,10 @@ void od_state_mc_predict(od_state *state, od_img *img_dst) {
   if ((D.ctx != NULL || od_hipenc_device_thread()) && !D.failed) {
     if (mc_predict_device(state, img_dst) == 0) {
       mc_dev_frames++;
+      if (D.ctx != NULL && D.dec != NULL && state == &D.dec->state
+       && state->info.nplanes == 3 && state->frame_type == OD_P_FRAME) {
+        D.md_valid = md_pyramid(state, img_dst) == 0;
+      }
       if (D.check || od_hipenc_check_mode()) {
         /* OD_CHECKASM: the reference's own prediction of the same frame; its result stays */
         unsigned char *keep[3];
@@ -651,6 +812,7 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   if (use_device && od_hip_device_count() <= device) return OD_HIP_ENODEV;
   g_mc_dev_frames = g_mc_check_fail = 0;
   g_tail_dev_frames = 0;
+  g_md_hits = g_md_check_fail = 0;
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;

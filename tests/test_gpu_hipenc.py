@@ -235,8 +235,15 @@ def test_inter_stream_motion_compensation_on_the_device():
     frames, bad = H.mc_stats()
     assert frames == 4 and bad == 0          # frames 1, 2, 3 and 5 are P frames
     assert H.tail_frames() == nf             # I and P frames: inverse + filters + clamp on the device
+    hits, md_bad = H.md_stats()
+    assert hits > 0 and md_bad == 0          # check mode: device prediction pyramid == host transforms
     assert np.array_equal(got, want)
     assert np.array_equal(got[-1], rec)
+    # without check mode the prediction side of every P frame is the device pyramid alone
+    prm.check = 0
+    nd, got2, _, _ = H.decode(prm, hdr, pk, use_device=1)
+    hits2, _ = H.md_stats()
+    assert nd == nf and hits2 == hits and np.array_equal(got2, want)
 
 
 def test_stream_ordering_regression_many_workers_repeated():

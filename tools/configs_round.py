@@ -112,15 +112,20 @@ def main():
     nd0, pics0, s0, _ = H.decode(prm, hdr, want)
     nd1, pics1, s1, _ = H.decode(prm, hdr, want, use_device=DEV)
     frames_dev, bad = H.mc_stats()
+    md_hits, _ = H.md_stats()
+    tail = H.tail_frames()
     res['configs3_inter_1080p'] = {
         'frames': nf, 'keyframe_rate': 30, 'packets_equal_pure_reference': got == want,
         'reference_1thread_s': round(rs, 2), 'seam_s': round(st.t_total_s, 2),
         'decode_pictures_identical': bool(nd0 == nf and nd1 == nf and np.array_equal(pics0, pics1)),
         'decode_reference_s': round(s0, 3), 'decode_seam_s': round(s1, 3),
         'mc_frames_on_device_in_decode': int(frames_dev), 'mc_check_fail': int(bad),
-        'what': 'P frames: od_state_mc_predict (OBMC, all planes) on the device in both seams, input '
-                'forward transforms from the feed, deringing on the device; od_mv_est (EPZS + DP '
-                'refinement, src/mcenc.c) stays the reference host code and dominates'}
+        'tail_frames_on_device_in_decode': int(tail), 'prediction_transforms_from_device_pyramid': int(md_hits),
+        'what': 'P frames: od_state_mc_predict (OBMC, all planes) on the device in both seams; decoder: '
+                'forward pyramid of the prediction and the whole pixel-domain stage on the device too; '
+                'encoder: deringing and its distortions on the device, own PVQ path + vector-unit '
+                'motion-search leaves on the host; od_mv_est (EPZS + DP refinement, src/mcenc.c) stays '
+                'the reference host code and dominates'}
     print('configs[3]', res['configs3_inter_1080p'], file=sys.stderr, flush=True)
 
     # configs[4]: lossless

@@ -65,9 +65,11 @@ def main():
         nd0, p0, _, _ = H.decode(prm, hdr, want)
         nd1, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
         fdev, fbad = H.mc_stats()
+        mdh, mdbad = H.md_stats()
         ok = (got == want and st.check_fail == 0 and st.pvq_check_fail == 0 and st.lost_sync == 0
               and st.fdct_check_fail == 0 and st.dering_check_fail == 0 and st.dist_check_fail == 0
-              and nd0 == nf and nd1 == nf and np.array_equal(p0, p1) and fbad == 0)
+              and nd0 == nf and nd1 == nf and np.array_equal(p0, p1) and fbad == 0 and mdbad == 0
+              and mdh > 0 and H.tail_frames() == nf)
         print('%4dx%-4d q=%-3d masking=%d complexity=%d inter keyrate=%d: %s  (bytes %d, device OBMC frames in decode %d)'
               % (w, h, q, m, cx, keyrate, 'ok' if ok else 'MISMATCH', n, fdev), flush=True)
         bad += not ok
