@@ -1,6 +1,7 @@
-/* hip_pvq_host.c - host side of SURVEY rows A16/A19 for keyframes: od_pvq_encode()
- * and pvq_theta() restated so that they CONSUME the device feed instead of redoing the
- * device's work, plus a rate-only form of od_pvq_rate().
+/* hip_pvq_host.c - host side of SURVEY rows A16/A19: od_pvq_encode() and pvq_theta()
+ * restated (keyframes and inter frames) so that they CONSUME the device feed where there is
+ * one (keyframe luma) instead of redoing the device's work, plus a rate-only form of
+ * od_pvq_rate() and one search context per band for the searches that stay here.
  *
  * What the reference does per band (src/pvq_encoder.c:311-511) and what happens here:
  *   gain of x (:360, n multiply-adds + pow)   -> read from the feed (g exact from the
@@ -13,8 +14,11 @@
  *                                                 on (rng, bit count) only - the number
  *                                                 od_ec_enc_tell_frac() returns depends on
  *                                                 nothing else (src/entcode.c:65-91)
- *   with-reference theta search (:399-448)    -> unchanged arithmetic on the host (its
- *                                                 input depends on the serial reconstruction)
+ *   with-reference theta search (:399-448)    -> same arithmetic on the host (on keyframes its
+ *                                                 input depends on the serial reconstruction);
+ *                                                 what the candidates of one vector share is
+ *                                                 computed once (hip_pvq_search.c), equal
+ *                                                 codewords are priced once
  * and per block (src/pvq_encoder.c:645-815): the 19.7 KB od_encode_checkpoint() of the
  * whole adaptation context becomes a copy of the ~2 KB this function can modify.
  *
