@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the live seams on the GPU box: picture sizes, quantizers,
+masking, complexity, content kinds and keyframe rates drawn from a seeded generator; every
+case is encoded through the seam in check mode (every device answer and every own-C block
+compared with the reference's functions) and its packets are compared with the PURE reference
+build's; the stream is decoded through the seam and compared with the reference decoder.
+  python tools/fuzz_seams.py [--cases 40] [--seed 1]
+Exit code 1 on any difference."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+def content(rng, kind, w, h, nf):
+    from testlib import synth_plane
+    cw, ch = (w + 1)//2, (h + 1)//2
+    frames = []
+    for f in range(nf):
+        if kind == 'synth':
+            s = int(rng.integers(0, 1000))
+            pl = [synth_plane(w, h, s + f), synth_plane(cw, ch, s + f, 1), synth_plane(cw, ch, s + f + 1, 1)]
+        elif kind == 'noise':
+            pl = [rng.integers(0, 256, size=(h, w), dtype=np.uint8),
+                  rng.integers(0, 256, size=(ch, cw), dtype=np.uint8),
+                  rng.integers(0, 256, size=(ch, cw), dtype=np.uint8)]
+        elif kind == 'flat':
+            v = int(rng.integers(0, 256))
+            pl = [np.full((h, w), v, np.uint8), np.full((ch, cw), 255 - v, np.uint8),
+                  np.full((ch, cw), v//2, np.uint8)]
+        elif kind == 'bilevel':
+            pl = [(255*rng.integers(0, 2, size=(h, w))).astype(np.uint8),
+                  (255*rng.integers(0, 2, size=(ch, cw))).astype(np.uint8),
+                  (255*rng.integers(0, 2, size=(ch, cw))).astype(np.uint8)]
+        else:                                           # moving: a shifted window of one picture
+            if f == 0:
+                base = [synth_plane(w + 32, h + 32, 7), synth_plane(cw + 16, ch + 16, 8, 1),
+                        synth_plane(cw + 16, ch + 16, 9, 1)]
+            dy, dx = (2*f) % 30, (3*f) % 30
+            pl = [base[0][dy:dy + h, dx:dx + w], base[1][dy//2:dy//2 + ch, dx//2:dx//2 + cw],
+                  base[2][dy//2:dy//2 + ch, dx//2:dx//2 + cw]]
+        frames.append(pl)
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=40)
+    ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--no-device', action='store_true', help='dry run on a CPU-only box')
+    a = ap.parse_args()
+    import daala_amd.hipenc as H
+    import configs_round as C
+    rng = np.random.default_rng(a.seed)
+    dev = 0 if a.no_device else 1
+    bad = 0
+    for case in range(a.cases):
+        w = int(rng.integers(8, 260))*2
+        h = int(rng.integers(8, 200))*2
+        q = int(rng.choice([1, 2, 5, 9, 14, 20, 33, 60, 120, 300, 511]))
+        m = int(rng.integers(0, 2))
+        cx = int(rng.choice([0, 2, 7, 7, 10]))
+        keyrate = int(rng.choice([1, 1, 1, 3]))
+        nf = int(rng.integers(2, 5))
+        kind = str(rng.choice(['synth', 'noise', 'flat', 'bilevel', 'moving']))
+        buf = H.pack_frames(content(rng, kind, w, h, nf), w, h)
+        want, _ = C.reference(w, h, buf, nf, q, m, keyrate, cx)
+        workers = 1 if keyrate > 1 else int(rng.integers(1, 4))
+        prm = H.Params(w, h, q, cx, m, workers, 1, int(rng.choice([0, 0, 2])), keyrate)
+        n, got, st = H.encode(prm, buf, nf, use_device=dev)
+        hdr = H.headers(prm)
+        nd0, p0, _, _ = H.decode(prm, hdr, want)
+        nd1, p1, _, _ = H.decode(prm, hdr, want, use_device=dev)
+        _, mcbad = H.mc_stats()
+        _, mdbad = H.md_stats()
+        ok = (n > 0 and got == want and st.check_fail == 0 and st.pvq_check_fail == 0 and st.lost_sync == 0
+              and st.g2_mismatch == 0 and st.fdct_check_fail == 0 and st.dering_check_fail == 0
+              and st.dist_check_fail == 0 and nd0 == nf and nd1 == nf and np.array_equal(p0, p1)
+              and mcbad == 0 and mdbad == 0)
+        print('case %2d: %3dx%-3d q=%-3d masking=%d complexity=%-2d keyrate=%d frames=%d workers=%d %-8s %s (bytes %d)'
+              % (case, w, h, q, m, cx, keyrate, nf, workers, kind, 'ok' if ok else 'MISMATCH', n), flush=True)
+        bad += not ok
+    print('%d cases, %d bad' % (a.cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
