@@ -856,16 +856,17 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
       a.ntx = ntx;
       (void)sb;
       const dim3 grid(ntx, ctx->nvsb, nslots);
+      const dim3 gridf((ntx + RT_SEG - 1)/RT_SEG, ctx->nvsb, nslots);   // RT_SEG tiles per workgroup
       if (a.dec == 0) {
         { Timed tm(ctx, "k_inverse_sb_luma");
-          hipLaunchKernelGGL((k_inverse_rt_fused<32, 4>), grid, dim3(64), 0, ctx->stream, a); }
+          hipLaunchKernelGGL((k_inverse_rt_fused<32, 4>), gridf, dim3(64), 0, ctx->stream, a); }
         HIPCHK(hipGetLastError());
         { Timed tm(ctx, "k_inverse_strips_luma");
           hipLaunchKernelGGL((k_inverse_strips<32>), grid, dim3(64), 0, ctx->stream, a); }
       }
       else {
         { Timed tm(ctx, "k_inverse_sb_chroma");
-          hipLaunchKernelGGL((k_inverse_rt_fused<16, 3>), grid, dim3(64), 0, ctx->stream, a); }
+          hipLaunchKernelGGL((k_inverse_rt_fused<16, 3>), gridf, dim3(64), 0, ctx->stream, a); }
         HIPCHK(hipGetLastError());
         { Timed tm(ctx, "k_inverse_strips_chroma");
           hipLaunchKernelGGL((k_inverse_strips<16>), grid, dim3(64), 0, ctx->stream, a); }

@@ -443,82 +443,144 @@ __device__ __forceinline__ uint32_t clamp8(int32_t v) {
   return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
 }
 
+// RT_SEG > 1 (experiment, off): one workgroup walks RT_SEG consecutive tiles of a tile row and
+// finishes the boundaries between them itself - lane r keeps the last four columns of row r
+// of the tile just done, the first pass across the boundary (4-tap on the previous tile's
+// last two and this tile's first two columns, all rows - src/filter.c:1627-1633) runs once
+// the next tile is in LDS, and the delayed four bytes go out as one aligned word; column
+// strips and the strip kernel's first pass are then needed at SEGMENT edges only.  Measured on
+// MI355X (30 luma frames per launch, tile kernel + strip kernel, ms): RT_SEG 1: 0.155 + 0.037,
+// 2: 0.266 + 0.041, 4: 0.215 + 0.036, 8: 0.251 + 0.033; WRITE_SIZE of the pair 141 MB (1) vs
+// 138 MB (4), FETCH_SIZE equal: the delayed word is itself a lone partial-sector store, so the
+// counted traffic does not move while one wave doing its tiles back to back (141 VGPRs instead
+// of 76) costs time.  Default: one tile per workgroup.  Only stores of whole 64-byte row
+// segments that straddle the tile boundary (previous tile's right half kept in LDS) would
+// remove the partial sectors; not built - the pair is VALU bound, not traffic bound.
+#ifndef RT_SEG
+#define RT_SEG 1
+#endif
+#ifndef RT_FUSED_WAVES
+#define RT_FUSED_WAVES 1      /* min waves per SIMD asked of the compiler (VGPR cap) */
+#endif
 template <int SB, int NLEV>
-__global__ __launch_bounds__(64) void k_inverse_rt_fused(InvArgs a) {
+__global__ __launch_bounds__(64, RT_FUSED_WAVES) void k_inverse_rt_fused(InvArgs a) {
   using T = RowTile<SB>;
   __shared__ int32_t Z[SB*T::LDZ];
   __shared__ uint8_t bsz[16*T::NSB];
   const int lane = threadIdx.x;
-  int tx, sby, f;
-  rt_tile_coords(tx, sby, f);
-  const int x0 = tx*T::W, y0 = sby*SB;
-  const int sbx0 = tx*T::NSB;
-  const int nsb = min(T::NSB, a.nhsb - sbx0);
-  const int tw = min(T::W, a.w - x0);
-  for (int e = lane; e < 16*T::NSB; e += 64) {
-    const int s = e >> 4, c = e & 15;
-    bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
-                               (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
-                     : 3;
-  }
-  rt_load_tile<SB>(Z, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0);
-  rt_sync();
-  int mx = 0;
-  for (int e = lane; e < SB*T::W; e += 64) {
-    const int v = Z[(e >> 6)*T::LDZ + (e & 63)];
-    mx = max(mx, v < 0 ? -(v + 1) : v);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-  if (mx <= (1 << 18)) rt_inverse_body<SB, NLEV, true>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
-  else rt_inverse_body<SB, NLEV, false>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
-  // first pass on the tile-internal vertical superblock boundaries
-  if (lane < (T::NSB - 1)*SB) {
-    const int k = lane/SB + 1, r = lane%SB;
-    if (k < nsb) {
-      int32_t *p = Z + r*T::LDZ + k*SB - 2;
-      lap4_post(p[0], p[1], p[2], p[3]);
+  int seg, sby, f;
+  rt_tile_coords(seg, sby, f);
+  const int y0 = sby*SB;
+  int32_t pend[4] = {0, 0, 0, 0};     // lane r < SB: columns tw-4 .. tw-1 of row r of the previous tile
+  for (int t = 0; t < RT_SEG; t++) {
+    const int tx = seg*RT_SEG + t;
+    if (tx >= a.ntx) break;
+    const int x0 = tx*T::W;
+    const int sbx0 = tx*T::NSB;
+    const int nsb = min(T::NSB, a.nhsb - sbx0);
+    const int tw = min(T::W, a.w - x0);
+    const bool first = t == 0;                                   // the segment's left edge
+    const bool lastt = t == RT_SEG - 1 || tx == a.ntx - 1;       // the segment's right edge
+    for (int e = lane; e < 16*T::NSB; e += 64) {
+      const int s = e >> 4, c = e & 15;
+      bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
+                                 (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
+                       : 3;
     }
-  }
-  rt_sync();
-  // interior: final, 8 bit
-  {
-    uint8_t *rec = a.rec + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
-    const int r0 = lane & 3, c4 = (lane >> 2)*4;
+    rt_load_tile<SB>(Z, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0);
+    rt_sync();
+    int mx = 0;
+    for (int e = lane; e < SB*T::W; e += 64) {
+      const int v = Z[(e >> 6)*T::LDZ + (e & 63)];
+      mx = max(mx, v < 0 ? -(v + 1) : v);
+    }
 #pragma unroll
-    for (int it = 0; it < SB/4; it++) {
-      const int r = it*4 + r0;
-      if (r >= 2 && r < SB - 2 && c4 < tw) {
-        const int32_t *p = Z + r*T::LDZ + c4;
-        uint8_t *q = rec + (size_t)r*a.w + c4;
-        if (c4 == 0) *reinterpret_cast<uint16_t *>(q + 2) = (uint16_t)(clamp8(p[2]) | clamp8(p[3]) << 8);
-        else if (c4 == tw - 4) *reinterpret_cast<uint16_t *>(q) = (uint16_t)(clamp8(p[0]) | clamp8(p[1]) << 8);
-        else *reinterpret_cast<uint32_t *>(q) = clamp8(p[0]) | clamp8(p[1]) << 8 | clamp8(p[2]) << 16 | clamp8(p[3]) << 24;
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if (mx <= (1 << 18)) rt_inverse_body<SB, NLEV, true>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
+    else rt_inverse_body<SB, NLEV, false>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
+    // first pass on the tile-internal vertical superblock boundaries
+    if (lane < (T::NSB - 1)*SB) {
+      const int k = lane/SB + 1, r = lane%SB;
+      if (k < nsb) {
+        int32_t *p = Z + r*T::LDZ + k*SB - 2;
+        lap4_post(p[0], p[1], p[2], p[3]);
       }
     }
-  }
-  // row strips: tile rows 0, 1, SB-2, SB-1
-  int32_t *escp = a.c + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
-  {
-    const int k = lane >> 4, c4 = (lane & 15)*4;
-    const int r = k < 2 ? k : SB - 4 + k;
-    if (c4 < tw) {
-      const int32_t *p = Z + r*T::LDZ + c4;
-      int32_t *e = escp + (size_t)r*a.w + c4;
-      int16_t *q = a.rs + (size_t)f*a.rs_fstride + ((size_t)sby*4 + k)*a.w + x0 + c4;
-      const uint32_t lo = (uint16_t)strip_put(p[0], e) | (uint32_t)(uint16_t)strip_put(p[1], e + 1) << 16;
-      const uint32_t hi = (uint16_t)strip_put(p[2], e + 2) | (uint32_t)(uint16_t)strip_put(p[3], e + 3) << 16;
-      *reinterpret_cast<uint2 *>(q) = make_uint2(lo, hi);
+    uint8_t *rec = a.rec + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
+    int32_t *escp = a.c + (size_t)f*a.fstride + (size_t)y0*a.w + x0;
+    // first pass across the boundary to the previous tile of this segment; its delayed word
+    if (!first && lane < SB) {
+      int32_t *p = Z + lane*T::LDZ;
+      lap4_post(pend[2], pend[3], p[0], p[1]);
+      if (lane >= 2 && lane < SB - 2) {
+        *reinterpret_cast<uint32_t *>(rec + (size_t)lane*a.w - 4) =
+            clamp8(pend[0]) | clamp8(pend[1]) << 8 | clamp8(pend[2]) << 16 | clamp8(pend[3]) << 24;
+      }
+      else {
+        // a strip row: the previous tile left the last two entries of its row strip to this pass
+        const int k = lane < 2 ? lane : lane - (SB - 4);
+        int16_t *q = a.rs + (size_t)f*a.rs_fstride + ((size_t)sby*4 + k)*a.w + x0 - 2;
+        int32_t *e = escp + (size_t)lane*a.w - 2;
+        *reinterpret_cast<uint32_t *>(q) =
+            (uint16_t)strip_put(pend[2], e) | (uint32_t)(uint16_t)strip_put(pend[3], e + 1) << 16;
+      }
     }
-  }
-  // column strips: tile columns 0, 1, tw-2, tw-1 of every row
-  if (lane < SB) {
-    const int32_t *p = Z + lane*T::LDZ;
-    int32_t *e = escp + (size_t)lane*a.w;
-    int16_t *q = a.cs + (size_t)f*a.cs_fstride + ((size_t)tx*a.h + y0 + lane)*4;
-    const uint32_t lo = (uint16_t)strip_put(p[0], e) | (uint32_t)(uint16_t)strip_put(p[1], e + 1) << 16;
-    const uint32_t hi = (uint16_t)strip_put(p[tw - 2], e + tw - 2) | (uint32_t)(uint16_t)strip_put(p[tw - 1], e + tw - 1) << 16;
-    *reinterpret_cast<uint2 *>(q) = make_uint2(lo, hi);
+    rt_sync();
+    // interior: final, 8 bit
+    {
+      const int r0 = lane & 3, c4 = (lane >> 2)*4;
+#pragma unroll
+      for (int it = 0; it < SB/4; it++) {
+        const int r = it*4 + r0;
+        if (r >= 2 && r < SB - 2 && c4 < tw) {
+          const int32_t *p = Z + r*T::LDZ + c4;
+          uint8_t *q = rec + (size_t)r*a.w + c4;
+          const uint32_t word = clamp8(p[0]) | clamp8(p[1]) << 8 | clamp8(p[2]) << 16 | clamp8(p[3]) << 24;
+          if (c4 == tw - 4 && !lastt) { /* delayed: written with the next tile's boundary pass */ }
+          else if (c4 == 0 && first && c4 == tw - 4) { /* a 4-column tile: strips only */ }
+          else if (c4 == 0 && first) *reinterpret_cast<uint16_t *>(q + 2) = (uint16_t)(word >> 16);
+          else if (c4 == tw - 4 && lastt) *reinterpret_cast<uint16_t *>(q) = (uint16_t)word;
+          else *reinterpret_cast<uint32_t *>(q) = word;
+        }
+      }
+    }
+    // row strips: tile rows 0, 1, SB-2, SB-1
+    {
+      const int k = lane >> 4, c4 = (lane & 15)*4;
+      const int r = k < 2 ? k : SB - 4 + k;
+      if (c4 < tw) {
+        const int32_t *p = Z + r*T::LDZ + c4;
+        int32_t *e = escp + (size_t)r*a.w + c4;
+        int16_t *q = a.rs + (size_t)f*a.rs_fstride + ((size_t)sby*4 + k)*a.w + x0 + c4;
+        const uint32_t lo = (uint16_t)strip_put(p[0], e) | (uint32_t)(uint16_t)strip_put(p[1], e + 1) << 16;
+        if (c4 == tw - 4 && !lastt) {
+          // the last two columns wait for the pass across the boundary to the next tile
+          *reinterpret_cast<uint32_t *>(q) = lo;
+        }
+        else {
+          const uint32_t hi = (uint16_t)strip_put(p[2], e + 2) | (uint32_t)(uint16_t)strip_put(p[3], e + 3) << 16;
+          *reinterpret_cast<uint2 *>(q) = make_uint2(lo, hi);
+        }
+      }
+    }
+    // column strips at the segment's edges; the last four columns of every row for the next tile
+    if (lane < SB) {
+      const int32_t *p = Z + lane*T::LDZ;
+      int32_t *e = escp + (size_t)lane*a.w;
+      int16_t *q = a.cs + (size_t)f*a.cs_fstride + ((size_t)tx*a.h + y0 + lane)*4;
+      if (first) {
+        *reinterpret_cast<uint32_t *>(q) =
+            (uint16_t)strip_put(p[0], e) | (uint32_t)(uint16_t)strip_put(p[1], e + 1) << 16;
+      }
+      if (lastt) {
+        *reinterpret_cast<uint32_t *>(q + 2) =
+            (uint16_t)strip_put(p[tw - 2], e + tw - 2) | (uint32_t)(uint16_t)strip_put(p[tw - 1], e + tw - 1) << 16;
+      }
+      else {
+        pend[0] = p[tw - 4]; pend[1] = p[tw - 3]; pend[2] = p[tw - 2]; pend[3] = p[tw - 1];
+      }
+    }
+    rt_sync();                       // Z is reloaded by the next tile
   }
 }
 
@@ -535,7 +597,10 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
   const int16_t *rs = a.rs + (size_t)f*a.rs_fstride;
   const int32_t *esc = a.c + (size_t)f*a.fstride;
   uint8_t *rec = a.rec + (size_t)f*a.fstride;
-  const bool left = tx > 0, right = tx < a.ntx - 1, top = sby > 0, last = sby == a.nvsb - 1;
+  // tile boundaries inside a segment were finished by k_inverse_rt_fused (values in the row
+  // strips and bytes already final there): only segment edges are handled here
+  const bool lseg = tx%RT_SEG == 0, rseg = tx%RT_SEG == RT_SEG - 1 || tx == a.ntx - 1;
+  const bool left = tx > 0 && lseg, right = tx < a.ntx - 1 && rseg, top = sby > 0, last = sby == a.nvsb - 1;
   // the four strip columns of row y of tile t: its columns 0, 1, tw_t-2, tw_t-1
   auto csrow = [&](int t, int y) -> int4 {
     const uint2 u = *reinterpret_cast<const uint2 *>(cs + ((size_t)t*a.h + y)*4);
@@ -547,21 +612,28 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
   auto rsat = [&](int row4, size_t col, int y) -> int32_t {
     return strip_get(rs[(size_t)row4*a.w + col], esc + (size_t)y*a.w + col);
   };
-  // first pass across the left tile boundary, this tile's interior rows
+  // first pass across the left segment boundary, this tile's interior rows
   if (lane < SB) {
     const int r = lane;
-    const int4 cur = csrow(tx, y0 + r);
-    int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
-    if (left) {
-      const int4 prv = csrow(tx - 1, y0 + r);
-      v0 = prv.z; v1 = prv.w;
-      lap4_post(v0, v1, v2, v3);
+    const bool inner = r >= 2 && r < SB - 2;
+    uint8_t *q = rec + (size_t)(y0 + r)*a.w + x0;
+    if (lseg) {
+      const int4 cur = csrow(tx, y0 + r);
+      int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
+      if (left) {
+        const int4 prv = csrow(tx - 1, y0 + r);
+        v0 = prv.z; v1 = prv.w;
+        lap4_post(v0, v1, v2, v3);
+      }
+      if (inner) {
+        if (left) *reinterpret_cast<uint16_t *>(q - 2) = (uint16_t)(clamp8(v0) | clamp8(v1) << 8);
+        *reinterpret_cast<uint16_t *>(q) = (uint16_t)(clamp8(v2) | clamp8(v3) << 8);
+      }
     }
-    if (r >= 2 && r < SB - 2) {
-      uint8_t *q = rec + (size_t)(y0 + r)*a.w + x0;
-      if (left) *reinterpret_cast<uint16_t *>(q - 2) = (uint16_t)(clamp8(v0) | clamp8(v1) << 8);
-      *reinterpret_cast<uint16_t *>(q) = (uint16_t)(clamp8(v2) | clamp8(v3) << 8);
-      if (!right) *reinterpret_cast<uint16_t *>(q + tw - 2) = (uint16_t)(clamp8(cur.z) | clamp8(cur.w) << 8);
+    if (tx == a.ntx - 1 && inner) {
+      // the frame's right edge has no boundary: its last two columns are only clamped
+      const int4 cur = csrow(tx, y0 + r);
+      *reinterpret_cast<uint16_t *>(q + tw - 2) = (uint16_t)(clamp8(cur.z) | clamp8(cur.w) << 8);
     }
   }
   // the first pass redone for the rows of the horizontal boundary above this tile
@@ -572,7 +644,9 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
     const bool need = k < 4 ? (y >= 0) : last;
     if (need) {
       const int4 cur = csrow(tx, y);
-      if (side == 0) {
+      if (side == 0 && !lseg) { /* finished in the tile kernel */ }
+      else if (side == 1 && !rseg) { /* likewise */ }
+      else if (side == 0) {
         int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
         if (left) {
           const int4 prv = csrow(tx - 1, y);
@@ -596,7 +670,7 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
   // second pass across the horizontal boundary above this tile, one column per lane
   if (lane < tw) {
     const int c = lane;
-    const int ei = c < 2 ? c : c >= tw - 2 ? c - (tw - 4) : -1;
+    const int ei = (c < 2 && lseg) ? c : (c >= tw - 2 && rseg) ? c - (tw - 4) : -1;
     const size_t col = (size_t)x0 + c;
     int32_t v[4];
     if (top) {
