@@ -124,7 +124,10 @@ __device__ __forceinline__ int tail_dir_cost(const int32_t *p, int d) {
   return cost;
 }
 
-__global__ __launch_bounds__(256) void k_decode_tail(TailArgs a) {
+#ifndef TAIL_WAVES
+#define TAIL_WAVES 6           /* min waves per SIMD asked of the compiler (VGPR cap): 92 -> <= 85 VGPRs, tail 1.61 -> 1.52 ms */
+#endif
+__global__ __launch_bounds__(256, TAIL_WAVES) void k_decode_tail(TailArgs a) {
   __shared__ int16_t in0[TAIL_BSTRIDE*TAIL_BSTRIDE];   // unfiltered tile + border
   __shared__ int16_t in1[TAIL_BSTRIDE*TAIL_BSTRIDE];   // border + direction-filtered interior
   __shared__ int32_t out[32*32];
