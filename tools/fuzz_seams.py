@@ -53,6 +53,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=40)
     ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--max-w', type=int, default=520, help='largest picture width drawn')
+    ap.add_argument('--max-h', type=int, default=400)
     ap.add_argument('--no-device', action='store_true', help='dry run on a CPU-only box')
     a = ap.parse_args()
     import daala_amd.hipenc as H
@@ -61,8 +63,8 @@ def main():
     dev = 0 if a.no_device else 1
     bad = 0
     for case in range(a.cases):
-        w = int(rng.integers(8, 260))*2
-        h = int(rng.integers(8, 200))*2
+        w = int(rng.integers(8, a.max_w//2))*2
+        h = int(rng.integers(8, a.max_h//2))*2
         q = int(rng.choice([1, 2, 5, 9, 14, 20, 33, 60, 120, 300, 511]))
         m = int(rng.integers(0, 2))
         cx = int(rng.choice([0, 2, 7, 7, 10]))
