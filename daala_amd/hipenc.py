@@ -11,7 +11,8 @@ import os
 
 import numpy as np
 
-HIPENC_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host', 'build', 'libdaala_hipenc.so')
+HIPENC_SO = os.environ.get('OD_HIPENC_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host', 'build',
+                                                             'libdaala_hipenc.so')
 I32P = ctypes.POINTER(ctypes.c_int32)
 I16P = ctypes.POINTER(ctypes.c_int16)
 U8P = ctypes.POINTER(ctypes.c_uint8)
