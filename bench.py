@@ -357,7 +357,7 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workers', type=int, default=0, help='host workers per GPU (0: CPU quota / ranks)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
