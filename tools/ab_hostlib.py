@@ -2,7 +2,8 @@
 """A/B of integration-library builds on ONE box (the box-to-box spread of the host-bound number
 is larger than most build-flag effects): alternates the 30-frame 1080p end-to-end encode through
 a session between the libraries given, a few rounds each, and prints Mpixels/s per round.
-  python tools/ab_hostlib.py daala_amd/host/build/libdaala_hipenc.so daala_amd/host/build_old/libdaala_hipenc.so"""
+  python tools/ab_hostlib.py daala_amd/host/build/libdaala_hipenc.so daala_amd/host/build_old/libdaala_hipenc.so
+  python tools/ab_hostlib.py OD_HIP_SPIN_SYNC=0 OD_HIP_SPIN_SYNC=1        (environment variants)"""
 import json
 import os
 import subprocess
@@ -27,6 +28,10 @@ print(' '.join('%%.2f' %% (30*bench.PIC_W*bench.PIC_H/t/1e6) for t in ts))
 
 for rnd in range(2):
     for lib in sys.argv[1:]:
-        env = dict(os.environ, OD_HIPENC_LIB=os.path.abspath(lib))
+        if '=' in lib and not os.path.exists(lib):       # NAME=VALUE: an environment variant of the default build
+            k, v = lib.split('=', 1)
+            env = dict(os.environ, **{k: v})
+        else:
+            env = dict(os.environ, OD_HIPENC_LIB=os.path.abspath(lib))
         out = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True)
         print(lib, out.stdout.strip() or out.stderr.strip()[-300:], flush=True)
