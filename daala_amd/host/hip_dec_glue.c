@@ -31,6 +31,16 @@
 
 #include "hip_enc_glue.h"
 
+/* hip_dct_host.c */
+void od_hipenc_fdct4x4(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_fdct8x8(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_fdct16x16(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_fdct32x32(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_idct4x4(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hipenc_idct8x8(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hipenc_idct16x16(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hipenc_idct32x32(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+
 /* the reference's definitions, renamed by the build (integration build recipe) */
 void od_postfilter_split_cpu(od_coeff *c0, int stride, int bs, int f, int q,
  unsigned char *skip, int skip_stride, int hfilter, int vfilter);
@@ -533,9 +543,15 @@ static void *dworker(void *arg) {
     for (i = 0; i < OD_NBSIZES; i++) {
       static const od_dct_func_2d fhooks[OD_NBSIZES] = {hook_md_fdct4, hook_md_fdct8, hook_md_fdct16,
        hook_md_fdct32};
-      D.idct_cpu[i] = st->opt_vtbl.idct_2d[i];
+      static const od_dct_func_2d vfdct[OD_NBSIZES] = {od_hipenc_fdct4x4, od_hipenc_fdct8x8,
+       od_hipenc_fdct16x16, od_hipenc_fdct32x32};
+      static const od_dct_func_2d vidct[OD_NBSIZES] = {od_hipenc_idct4x4, od_hipenc_idct8x8,
+       od_hipenc_idct16x16, od_hipenc_idct32x32};
+      /* what the device does not take runs on the host vector unit (hip_dct_host.c), except
+         in check mode where the reference's C transforms are the checker */
+      D.idct_cpu[i] = D.check ? st->opt_vtbl.idct_2d[i] : vidct[i];
       st->opt_vtbl.idct_2d[i] = hooks[i];
-      D.fdct_cpu[i] = st->opt_vtbl.fdct_2d[i];
+      D.fdct_cpu[i] = D.check ? st->opt_vtbl.fdct_2d[i] : vfdct[i];
       st->opt_vtbl.fdct_2d[i] = fhooks[i];
     }
   }

@@ -698,9 +698,16 @@ static void *worker(void *arg) {
     static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
      hook_fdct32};
     int i;
+    static const od_dct_func_2d vfdct[OD_NBSIZES] = {od_hipenc_fdct4x4, od_hipenc_fdct8x8,
+     od_hipenc_fdct16x16, od_hipenc_fdct32x32};
+    static const od_dct_func_2d vidct[OD_NBSIZES] = {od_hipenc_idct4x4, od_hipenc_idct8x8,
+     od_hipenc_idct16x16, od_hipenc_idct32x32};
     for (i = 0; i < OD_NBSIZES; i++) {
-      T.fdct_cpu[i] = enc->state.opt_vtbl.fdct_2d[i];
+      /* the transforms that stay on the host run on its vector unit (hip_dct_host.c); check
+         mode keeps the reference's C functions: they are the checker there */
+      T.fdct_cpu[i] = T.check ? enc->state.opt_vtbl.fdct_2d[i] : vfdct[i];
       enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
+      if (!T.check) enc->state.opt_vtbl.idct_2d[i] = vidct[i];
     }
     /* the motion search's per-block leaves (hip_mc_host.c) */
     enc->state.opt_vtbl.mc_blend_full = od_hipenc_mc_blend_full8;

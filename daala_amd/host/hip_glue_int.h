@@ -82,6 +82,16 @@ double od_hip_search_run(od_hip_search *S, int k, od_coeff *ypulse, double g2);
 double od_hip_pvq_search_host(const double *xcoeff, int n, int k, od_coeff *ypulse,
  double g2);
 
+/* hip_dct_host.c: the 2-D lifting DCTs on the host vector unit (od_dct_func_2d signatures) */
+void od_hipenc_fdct4x4(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_fdct8x8(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_fdct16x16(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_fdct32x32(od_coeff *y, int ystride, const od_coeff *x, int xstride);
+void od_hipenc_idct4x4(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hipenc_idct8x8(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hipenc_idct16x16(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+void od_hipenc_idct32x32(od_coeff *x, int xstride, const od_coeff *y, int ystride);
+
 /* hip_mc_host.c: od_state_opt_vtbl leaves of the motion search, host vector unit */
 void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned char *src[4],
  int log_xblk_sz, int log_yblk_sz);

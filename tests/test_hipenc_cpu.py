@@ -399,3 +399,45 @@ def test_motion_search_leaves_equal_reference():
     hits, misses = ctypes.c_int64(), ctypes.c_int64()
     lib.od_hipenc_mc_cache_stats(ctypes.byref(hits), ctypes.byref(misses))
     assert hits.value >= 900 and misses.value >= 900
+
+
+def test_host_vector_transforms_equal_reference():
+    """hip_dct_host.c (the 2-D lifting DCTs that stay on the host, eight columns per vector,
+    generated from the same step lists as the device kernels) against the reference's
+    od_bin_fdctNxN / od_bin_idctNxN: random blocks at coefficient scale and far beyond,
+    strides that are not the block width, in-place use."""
+    lib = H.hipenc()
+    r = ref()
+    I32P = ctypes.POINTER(ctypes.c_int32)
+    rng = np.random.default_rng(31)
+    for n in (4, 8, 16, 32):
+        fh = getattr(lib, 'od_hipenc_fdct%dx%d' % (n, n))
+        ih = getattr(lib, 'od_hipenc_idct%dx%d' % (n, n))
+        fr = getattr(r, 'od_bin_fdct%dx%d' % (n, n))
+        ir = getattr(r, 'od_bin_idct%dx%d' % (n, n))
+        for f in (fh, ih, fr, ir):
+            f.restype = None
+            f.argtypes = [I32P, ctypes.c_int, I32P, ctypes.c_int]
+        for trial in range(300):
+            amp = [255 << 4, 40000, 1 << 22][trial % 3]
+            xs, ys = n + int(rng.integers(0, 7)), n + int(rng.integers(0, 7))
+            x = rng.integers(-amp, amp + 1, size=(n, xs)).astype(np.int32)
+            ya, yb = np.zeros((n, ys), np.int32), np.zeros((n, ys), np.int32)
+            fh(ya.ctypes.data_as(I32P), ys, x.ctypes.data_as(I32P), xs)
+            fr(yb.ctypes.data_as(I32P), ys, x.ctypes.data_as(I32P), xs)
+            assert np.array_equal(ya[:, :n], yb[:, :n]), ('fdct', n, trial)
+            xa, xb = np.zeros((n, xs), np.int32), np.zeros((n, xs), np.int32)
+            ih(xa.ctypes.data_as(I32P), xs, yb.ctypes.data_as(I32P), ys)
+            ir(xb.ctypes.data_as(I32P), xs, yb.ctypes.data_as(I32P), ys)
+            assert np.array_equal(xa[:, :n], xb[:, :n]) and np.array_equal(xa[:, :n], x[:, :n]), ('idct', n, trial)
+            # arbitrary (not transform-generated) coefficients through the inverse
+            c = rng.integers(-amp, amp + 1, size=(n, ys)).astype(np.int32)
+            ih(xa.ctypes.data_as(I32P), xs, c.ctypes.data_as(I32P), ys)
+            ir(xb.ctypes.data_as(I32P), xs, c.ctypes.data_as(I32P), ys)
+            assert np.array_equal(xa[:, :n], xb[:, :n]), ('idct arbitrary', n, trial)
+            # in place (the encoder's od_compute_dist transforms a stack block in place? no - but
+            # od_bin_* allow y == x only through z; exercise it anyway for the 2-D wrappers)
+            za, zb = x[:, :n].copy(), x[:, :n].copy()
+            fh(za.ctypes.data_as(I32P), n, za.ctypes.data_as(I32P), n)
+            fr(zb.ctypes.data_as(I32P), n, zb.ctypes.data_as(I32P), n)
+            assert np.array_equal(za, zb), ('in place', n, trial)
