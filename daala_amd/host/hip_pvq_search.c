@@ -48,6 +48,9 @@ static inline double rsqrt_int(int i) {
    the verification pass (measured: 7 and 14 coefficients 103/292 ns scalar vs 142/370 ns
    with lanes; 31: 1.07 vs 0.99 us; 127: 9.8 vs 6.4 us). */
 #define OD_HIP_SEARCH_MIN_N (24)
+#ifndef OD_HIP_RDO_LANES_MIN_N
+#define OD_HIP_RDO_LANES_MIN_N (24)
+#endif
 
 /* One vector, many searches.  pvq_theta (src/pvq_encoder.c:399-481) searches the SAME input
    once per (gain, theta) candidate, changing only K and g2.  Of what pvq_search_rdo_double
@@ -58,7 +61,9 @@ static inline double rsqrt_int(int i) {
    its RDO pulses only - every value still comes out of the reference's operations in the
    reference's order. */
 void od_hip_search_begin(od_hip_search *S, const double *xcoeff, int n) {
-  od_hip_search_begin_ex(S, xcoeff, n, n >= OD_HIP_SEARCH_MIN_N);
+  /* bit 0: lane scans in the greedy phase (pays from 24 coefficients: the verification pass
+     is overhead), bit 1: in the RDO phase (a plain maximum: pays from OD_HIP_RDO_LANES_MIN_N) */
+  od_hip_search_begin_ex(S, xcoeff, n, (n >= OD_HIP_SEARCH_MIN_N ? 1 : 0) | (n >= OD_HIP_RDO_LANES_MIN_N ? 2 : 0));
 }
 
 void od_hip_search_begin_ex(od_hip_search *S, const double *xcoeff, int n, int lanes) {
@@ -431,7 +436,7 @@ double od_hip_search_run(od_hip_search *S, int k, od_coeff *ypulse, double g2) {
     }
     for (j = n; j < nv; j++) yi[j] = 0;
     if (i < k - rdo_pulses) {
-      if (!S->lanes) greedy_scalar(S, yi, &xy, &yy, i, k - rdo_pulses);
+      if (!(S->lanes & 1)) greedy_scalar(S, yi, &xy, &yy, i, k - rdo_pulses);
       else greedy_lanes(S, yi, &xy, &yy, i, k - rdo_pulses);
       i = k - rdo_pulses;
     }
@@ -445,7 +450,7 @@ double od_hip_search_run(od_hip_search *S, int k, od_coeff *ypulse, double g2) {
     }
   }
   if (i < k) {
-    if (!S->lanes) rdo_scalar(S, yi, &xy, &yy, i, k, lambda);
+    if (!(S->lanes & 2)) rdo_scalar(S, yi, &xy, &yy, i, k, lambda);
     else rdo_lanes(S, yi, &xy, &yy, i, k, lambda);
   }
   for (j = 0; j < n; j++) ypulse[j] = S->xcoeff[j] < 0 ? -yi[j] : yi[j];

@@ -251,7 +251,7 @@ def test_host_codeword_search_equals_reference_search():
             for c in range(nc):
                 want_c[c] = lib.od_ref_pvq_search_rdo_double_cpu(
                     x.ctypes.data_as(F64P), n, int(ks[c]), want_y[c].ctypes.data_as(I32P), float(g2[c]))
-            for lanes in (0, 1):
+            for lanes in (0, 1, 2, 3):                # bit 0: greedy phase, bit 1: RDO phase on lanes
                 y, cd = np.zeros((nc, n), np.int32), np.zeros(nc)
                 lib.od_hip_pvq_search_multi(x.ctypes.data_as(F64P), n, lanes, nc, ks.ctypes.data_as(I32P),
                                             g2.ctypes.data_as(F64P), y.ctypes.data_as(I32P),
