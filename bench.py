@@ -288,10 +288,10 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
                       'concurrent_side_streams': bool(concurrent),
                       # FP64-VALU bound, not HBM bound: utilisation from the SQ
                       # counters of the committed PMC passes (4-cycle wave64 FP64 issue)
-                      'sq_counters': measured_pmc({'k_pvq_noref<128>': 'k_pvq_noref_v3<128, false>',
-                                                   'k_pvq_noref<32>': 'k_pvq_noref_v3<32, false>',
-                                                   'k_pvq_noref<15>': 'k_pvq_noref_v3<15, false>',
-                                                   'k_pvq_noref<8>': 'k_pvq_noref_v3<8, false>'})}
+                      'sq_counters': measured_pmc({'k_pvq_noref<128>': 'k_pvq_noref_v4<128, false>',
+                                                   'k_pvq_noref<32>': 'k_pvq_noref_v4<32, false>',
+                                                   'k_pvq_noref<15>': 'k_pvq_noref_v4<15, false>',
+                                                   'k_pvq_noref<8>': 'k_pvq_noref_v4<8, false>'})}
     if 'pvq' in out:
         # Algorithmic FP64 work of the searches (device counters, one extra untimed step):
         # element steps of the greedy scans (add, add, add, mul, 2 mul + compare per element:

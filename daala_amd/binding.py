@@ -39,7 +39,7 @@ class FeedLevel(ctypes.Structure):
     _fields_ = [('n', ctypes.c_int32), ('nbands', ctypes.c_int32), ('nblk', ctypes.c_int32),
                 ('nbx', ctypes.c_int32), ('off', ctypes.c_int32*11), ('pad', ctypes.c_int32),
                 ('cg', F64P), ('g', F64P), ('ncand', I32P), ('qg', I32P), ('k', I32P), ('cos_dist', F64P),
-                ('y', I32P), ('lev', I32P), ('lev_stride', ctypes.c_int32), ('pad2', ctypes.c_int32)]
+                ('y', I16P), ('lev', I32P), ('lev_stride', ctypes.c_int32), ('pad2', ctypes.c_int32)]
 
 
 PVQ_BAND_DTYPE = np.dtype([('cg', 'f8'), ('g', 'f8'), ('cos_dist', 'f8', 2), ('dist', 'f8', 2),
@@ -494,7 +494,7 @@ class DaalaHip(object):
         out = []
         for v in lev:
             nrec = v.nbands*v.nblk
-            ny = 2*v.nblk*(min(v.n*v.n, 512) - 1)
+            ny = 2*v.nblk*min(v.n*v.n, 512)      # int16, bands padded to even (daala_hip.h 4b)
             out.append({'n': v.n, 'nbands': v.nbands, 'nblk': v.nblk, 'nbx': v.nbx,
                         'off': list(v.off)[:v.nbands + 1],
                         'cg': np.ctypeslib.as_array(v.cg, (nrec,)).copy(),

@@ -75,28 +75,26 @@ int od_hip_gather_strips(od_hip_ctx *ctx, od_hip_comm *c, int slot, const int *s
       if (!with_pvq) continue;
       for (int l = 0; l < ctx->nlev[p]; l++) {
         if (!ctx->pvq_alloc[p][l]) continue;
-        const int n = sb >> l, bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
-        int offb[11];
-        const int nb = od_hip_band_offsets(bs, offb);
-        const long nbx = ctx->pw[p]/n, nblk = nbx*(ctx->ph[p]/n);
-        const int ncoded = n*n < 512 ? n*n : 512;
-        const size_t nrec = (size_t)nb*nblk, ny = (size_t)2*nblk*(ncoded - 1);
+        const PvqLevelLayout &Y = ctx->arena[p].lev[l];
+        const int n = Y.n, nb = Y.nb;
+        const long nbx = ctx->pw[p]/n, nblk = Y.nblk;
+        const size_t nrec = Y.nrec;
         const long first = (long)r0*(sb/n)*nbx, count = (long)(r1 - r0)*(sb/n)*nbx;
-        PvqSoA &o = ctx->pvq[p][l];
+        const PvqSoA o = pvq_slot(ctx->pvq[p][l], slot);
         for (int b = 0; b < nb; b++) {
-          const size_t e = (size_t)slot*nrec + (size_t)b*nblk + first;
+          const size_t e = (size_t)b*nblk + first;
           NCCLCHK(ncclBroadcast(o.cg + e, o.cg + e, count*8, ncclChar, r, c->comm, ctx->stream));
           NCCLCHK(ncclBroadcast(o.g + e, o.g + e, count*8, ncclChar, r, c->comm, ctx->stream));
           NCCLCHK(ncclBroadcast(o.ncand + e, o.ncand + e, count*4, ncclChar, r, c->comm, ctx->stream));
-          const int nn = offb[b + 1] - offb[b];
+          const int ns = pvq_ns(Y.off, b);
           for (int cd = 0; cd < 2; cd++) {
-            const size_t e2 = (size_t)slot*2*nrec + (size_t)cd*nrec + (size_t)b*nblk + first;
+            const size_t e2 = (size_t)cd*nrec + (size_t)b*nblk + first;
             NCCLCHK(ncclBroadcast(o.qg + e2, o.qg + e2, count*4, ncclChar, r, c->comm, ctx->stream));
             NCCLCHK(ncclBroadcast(o.k + e2, o.k + e2, count*4, ncclChar, r, c->comm, ctx->stream));
             NCCLCHK(ncclBroadcast(o.cos_dist + e2, o.cos_dist + e2, count*8, ncclChar, r, c->comm, ctx->stream));
             NCCLCHK(ncclBroadcast(o.dist + e2, o.dist + e2, count*8, ncclChar, r, c->comm, ctx->stream));
-            int32_t *y = o.y + (size_t)slot*ny + (size_t)2*nblk*(offb[b] - 1) + ((size_t)cd*nblk + first)*nn;
-            NCCLCHK(ncclBroadcast(y, y, (size_t)count*nn*4, ncclChar, r, c->comm, ctx->stream));
+            int16_t *y = o.y + (size_t)2*nblk*pvq_yo(Y.off, b) + ((size_t)cd*nblk + first)*ns;
+            NCCLCHK(ncclBroadcast(y, y, (size_t)count*ns*2, ncclChar, r, c->comm, ctx->stream));
           }
         }
       }

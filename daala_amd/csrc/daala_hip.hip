@@ -126,6 +126,26 @@ void dct_one(int bs, bool inv, od_coeff *out, int ostride, const od_coeff *in, i
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// Layout of one (plane, level) inside the plane's per-slot arenas (byte offsets from the
+// slot's start), see PvqSoA in pvq_kernels.hpp.
+struct PvqLevelLayout {
+  int n = 0, bs = 0, nb = 0, nblk = 0, ncoded = 0, off[11] = {};
+  size_t nrec = 0, ny = 0;                   // records per frame; int16 pulse entries per frame
+  size_t o_cd = 0, o_qg = 0, o_k = 0, o_nc = 0, o_y = 0;   // out arena
+  size_t o_g = 0;                            // g arena
+  size_t o_cg = 0, o_perm = 0;               // in arena
+};
+struct PvqArena {
+  PvqLevelLayout lev[4];
+  size_t out_slot = 0, g_slot = 0, in_slot = 0;   // bytes per frame slot
+  char *out = nullptr, *g = nullptr, *in = nullptr;
+  double *dist = nullptr;                    // [slot][level...] not transferred
+  size_t dist_slot = 0, o_dist[4] = {0, 0, 0, 0};
+};
+
+inline int pvq_yo(const int *off, int b) { return b == 0 ? 0 : off[b]; }
+inline int pvq_ns(const int *off, int b) { return ((off[b + 1] - off[b]) + 1) & ~1; }
+
 struct od_hip_ctx {
   od_hip_geometry geo;
   int device;
@@ -152,18 +172,19 @@ struct od_hip_ctx {
   // levels) go round-robin over a few side streams so that the tail of one kernel - a
   // few waves with large K - overlaps the next kernels instead of idling the chip.
   // They are joined back into `stream` lazily, before anything else touches the context.
-  static constexpr int NAUX = 4;
-  hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t aux_done[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int NAUX = 16;
+  hipStream_t aux[NAUX] = {};
+  hipEvent_t aux_done[NAUX] = {};
   hipEvent_t aux_dep = nullptr;
   int naux = 3;                              // OD_HIP_PVQ_STREAMS (0: everything on `stream`); 3 measured best
   int aux_rr = 0;
   bool aux_pending = false;
   hipEvent_t phase_a = nullptr;              // start of the PVQ batch in flight (timing only)
   int16_t *qm_slots = nullptr;               // [plane][level][1024]: one QM copy per (plane, level)
-  // PVQ results per (plane, level)
-  PvqSoA pvq[OD_HIP_NPLANES_MAX][4];         // device SoA, all slots
-  bool pvq_alloc[OD_HIP_NPLANES_MAX][4];
+  // PVQ results per (plane, level): pointers of slot 0 into the plane's arenas
+  PvqSoA pvq[OD_HIP_NPLANES_MAX][4];
+  bool pvq_alloc[OD_HIP_NPLANES_MAX][4];     // the plane's arenas exist (all levels at once)
+  PvqArena arena[OD_HIP_NPLANES_MAX];
   // timing
   struct Span { hipEvent_t a, b; };
   std::map<std::string, std::vector<Span>> spans;
@@ -253,9 +274,15 @@ void launch_pvq(const PvqLevelArgs &a, int nlist, long nblk_unused, int nslots, 
   aa.a = a;
   aa.rsq = rsq;
   aa.stats = stats;
-  dim3 grid((unsigned)((nblk + BPW - 1)/BPW), nlist, nslots);
-  if (gain_only) hipLaunchKernelGGL((k_pvq_noref_v3<N, true>), grid, dim3(64), 0, s, aa);
-  else hipLaunchKernelGGL((k_pvq_noref_v3<N, false>), grid, dim3(64), 0, s, aa);
+  if (gain_only) {
+    dim3 grid((unsigned)((nblk + BPW - 1)/BPW), nlist, nslots);
+    hipLaunchKernelGGL((k_pvq_gain<N>), grid, dim3(64), 0, s, aa);
+  }
+  else {
+    // one lane group per candidate: the band's work list has two entries per block
+    dim3 grid((unsigned)((2*nblk + BPW - 1)/BPW), nlist, nslots);
+    hipLaunchKernelGGL((k_pvq_cand<N>), grid, dim3(64), 0, s, aa);
+  }
 }
 
 // od_gain_compand (src/pvq.c:422-425) with the HOST's libm: the value the reference
@@ -270,35 +297,41 @@ inline bool pvq_sort_enabled() {
   return on != 0;
 }
 
-// Work-balancing order of the blocks of one band (performance only, any permutation is
-// correct): descending K of the larger gain candidate (counting sort), so that the lane slots
-// of a wave - which runs until its slowest band is done - hold similar K and the long
-// searches start first.  K as pvq_k_noref (src/pvq.c:508-514).
+// Work list of one band for the search kernel (performance only, any permutation of the
+// entries is correct): entry 2*block + candidate for both gain candidates of every block,
+// ordered by descending K (counting sort), so that the lane slots of a wave - which runs
+// until its slowest slot is done - hold similar K, the long searches start first and the
+// candidates that do not exist (K = 0) gather at the tail.  Candidates as pvq_theta's
+// no-reference loop (src/pvq_encoder.c:457): i = max(1, floor(cg)) + c while i <= ceil(cg);
+// K as od_pvq_compute_k (src/pvq.c:508-514).  perm: 2*count entries.
 inline void pvq_block_order(const double *cg, long first, long count, int n, double beta, bool sort,
                             int32_t *perm) {
   if (!sort) {
-    for (long i = 0; i < count; i++) perm[i] = (int32_t)(first + i);
+    for (long i = 0; i < 2*count; i++) perm[i] = (int32_t)(2*first + i);
     return;
   }
-  std::vector<uint8_t> key(count);
+  std::vector<uint8_t> key(2*count);
   long hist[257];
   for (int i = 0; i < 257; i++) hist[i] = 0;
   const double sq = sqrt((double)((n + 3)/2));
   for (long i = 0; i < count; i++) {
-    int k = 0;
-    if (cg[i] > 0) {
-      const double q = ceil(cg[i]) < 1 ? 1 : ceil(cg[i]);
-      if (n == 15 && q == 1 && beta > 1.25) k = 1;
-      else {
-        const double v = floor(.5 + (q - .2)*sq/beta);
-        k = v < 1 ? 1 : v > 255 ? 255 : (int)v;
+    const double lo = floor(cg[i]) < 1 ? 1 : floor(cg[i]), hi = ceil(cg[i]);
+    for (int c = 0; c < 2; c++) {
+      const double q = lo + c;
+      int k = 0;
+      if (q <= hi) {
+        if (n == 15 && q == 1 && beta > 1.25) k = 1;
+        else {
+          const double v = floor(.5 + (q - .2)*sq/beta);
+          k = v < 1 ? 1 : v > 255 ? 255 : (int)v;
+        }
       }
+      key[2*i + c] = (uint8_t)(255 - k);
+      hist[key[2*i + c] + 1]++;
     }
-    key[i] = (uint8_t)(255 - k);
-    hist[key[i] + 1]++;
   }
   for (int i = 0; i < 256; i++) hist[i + 1] += hist[i];
-  for (long i = 0; i < count; i++) perm[hist[key[i]]++] = (int32_t)(first + i);
+  for (long i = 0; i < 2*count; i++) perm[hist[key[i]]++] = (int32_t)(2*first + i);
 }
 }  // namespace
 
@@ -669,9 +702,9 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
     if (ctx->rs[p]) (void)hipFree(ctx->rs[p]);
     if (ctx->cs[p]) (void)hipFree(ctx->cs[p]);
     if (ctx->bskip[p]) (void)hipFree(ctx->bskip[p]);
-    for (int l = 0; l < 4; l++) {
-      PvqSoA &o = ctx->pvq[p][l];
-      void *ptrs[] = {o.cg, o.g, o.cos_dist, o.dist, o.qg, o.k, o.ncand, o.y, o.perm_rw};
+    {
+      PvqArena &A = ctx->arena[p];
+      void *ptrs[] = {A.out, A.g, A.in, A.dist};
       for (void *q : ptrs) if (q) (void)hipFree(q);
     }
   }
@@ -1005,6 +1038,69 @@ struct PvqCall {
   PvqSoA *o;
 };
 
+// The plane's arenas (all levels), allocated on first use.
+int pvq_arena(od_hip_ctx *ctx, int pli) {
+  PvqArena &A = ctx->arena[pli];
+  if (A.out) return 0;
+  const size_t ns = ctx->geo.nslots;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t out = 0, gb = 0, in = 0, db = 0;
+  for (int l = 0; l < ctx->nlev[pli]; l++) {
+    PvqLevelLayout &L = A.lev[l];
+    L.n = (32 >> ctx->geo.xdec[pli]) >> l;
+    L.bs = L.n == 4 ? 0 : L.n == 8 ? 1 : L.n == 16 ? 2 : 3;
+    L.nb = od_hip_band_offsets(L.bs, L.off);
+    L.nblk = (ctx->pw[pli]/L.n)*(ctx->ph[pli]/L.n);
+    L.ncoded = L.n*L.n < 512 ? L.n*L.n : 512;
+    L.nrec = (size_t)L.nb*L.nblk;
+    L.ny = (size_t)2*L.nblk*L.ncoded;
+    L.o_cd = out; out = al(out + 2*L.nrec*8);
+    L.o_qg = out; out = al(out + 2*L.nrec*4);
+    L.o_k = out; out = al(out + 2*L.nrec*4);
+    L.o_nc = out; out = al(out + L.nrec*4);
+    L.o_y = out; out = al(out + L.ny*2);
+    L.o_g = gb; gb = al(gb + L.nrec*8);
+    L.o_cg = in; in = al(in + L.nrec*8);
+    L.o_perm = in; in = al(in + 2*L.nrec*4);
+    A.o_dist[l] = db; db = al(db + 2*L.nrec*8);
+  }
+  A.out_slot = out; A.g_slot = gb; A.in_slot = in; A.dist_slot = db;
+  HIPCHK(hipMalloc((void **)&A.out, ns*out));
+  HIPCHK(hipMalloc((void **)&A.g, ns*gb));
+  HIPCHK(hipMalloc((void **)&A.in, ns*in));
+  HIPCHK(hipMalloc((void **)&A.dist, ns*db));
+  HIPCHK(hipMemsetAsync(A.in, 0xff, ns*in, ctx->stream));     // no work list yet: every slot idle
+  HIPCHK(hipMemsetAsync(A.out, 0, ns*out, ctx->stream));
+  for (int l = 0; l < ctx->nlev[pli]; l++) {
+    const PvqLevelLayout &L = A.lev[l];
+    PvqSoA &o = ctx->pvq[pli][l];
+    o.cos_dist = (double *)(A.out + L.o_cd);
+    o.qg = (int32_t *)(A.out + L.o_qg);
+    o.k = (int32_t *)(A.out + L.o_k);
+    o.ncand = (int32_t *)(A.out + L.o_nc);
+    o.y = (int16_t *)(A.out + L.o_y);
+    o.g = (double *)(A.g + L.o_g);
+    o.cg = (double *)(A.in + L.o_cg);
+    o.perm = (const int32_t *)(A.in + L.o_perm);
+    o.dist = (double *)((char *)A.dist + A.o_dist[l]);
+    o.fs_cd = out/8; o.fs_qg = o.fs_k = o.fs_nc = out/4; o.fs_y = out/2;
+    o.fs_g = gb/8;
+    o.fs_cg = in/8; o.fs_perm = in/4;
+    o.fs_dist = db/8;
+    ctx->pvq_alloc[pli][l] = true;
+  }
+  return 0;
+}
+
+// pointers of frame slot `slot` (PvqSoA holds slot 0)
+PvqSoA pvq_slot(const PvqSoA &o, size_t slot) {
+  PvqSoA r = o;
+  r.cg += slot*o.fs_cg; r.g += slot*o.fs_g; r.cos_dist += slot*o.fs_cd; r.dist += slot*o.fs_dist;
+  r.qg += slot*o.fs_qg; r.k += slot*o.fs_k; r.ncand += slot*o.fs_nc; r.y += slot*o.fs_y;
+  r.perm += slot*o.fs_perm;
+  return r;
+}
+
 // Argument block of one (plane, level) PVQ launch group (+ lazy allocation of its outputs).
 int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, const int16_t *qm,
                 const int32_t *q, const double *beta, PvqCall &c) {
@@ -1012,27 +1108,16 @@ int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, cons
   if (!q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
   c.nblk = od_hip_pvq_nblocks(ctx, pli, level);
   if (c.nblk < 0) return c.nblk;
-  const int n = c.n = (32 >> ctx->geo.xdec[pli]) >> level;
-  const int bs = c.bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
-  const int ncoded = n*n < 512 ? n*n : 512;
-  const size_t ns = ctx->geo.nslots;
+  if (int rc = pvq_arena(ctx, pli)) return rc;
+  const PvqLevelLayout &L = ctx->arena[pli].lev[level];
+  const int n = c.n = L.n;
+  const int bs = c.bs = L.bs;
   PvqLevelArgs &a = c.a;
   a.nbands = od_hip_band_offsets(bs, a.off);
-  const size_t nrec = c.nrec = (size_t)a.nbands*c.nblk, ny = c.ny = (size_t)2*c.nblk*(ncoded - 1);
+  c.nrec = L.nrec;
+  c.ny = L.ny;
   PvqSoA &o = ctx->pvq[pli][level];
   c.o = &o;
-  if (!ctx->pvq_alloc[pli][level]) {
-    HIPCHK(hipMalloc((void **)&o.cg, ns*nrec*8));
-    HIPCHK(hipMalloc((void **)&o.g, ns*nrec*8));
-    HIPCHK(hipMalloc((void **)&o.cos_dist, ns*2*nrec*8));
-    HIPCHK(hipMalloc((void **)&o.dist, ns*2*nrec*8));
-    HIPCHK(hipMalloc((void **)&o.qg, ns*2*nrec*4));
-    HIPCHK(hipMalloc((void **)&o.k, ns*2*nrec*4));
-    HIPCHK(hipMalloc((void **)&o.ncand, ns*nrec*4));
-    HIPCHK(hipMalloc((void **)&o.y, ns*ny*4));
-    HIPCHK(hipMalloc((void **)&o.perm_rw, ns*nrec*4));
-    ctx->pvq_alloc[pli][level] = true;
-  }
   // one QM copy per (plane, level): kernels of earlier calls may still be running on the
   // side streams when the next call uploads its table
   int16_t *qm_d = ctx->qm_slots + ((size_t)pli*4 + level)*1024;
@@ -1046,17 +1131,7 @@ int pvq_prepare(od_hip_ctx *ctx, int slot0, int nslots, int pli, int level, cons
   for (int i = 0; i < a.nbands; i++) { a.q[i] = q[i]; a.beta[i] = beta[i]; }
   a.tab = ctx->tab[bs];
   a.qm = qm_d;
-  a.rec_fstride = nrec;
-  a.y_fstride = ny;
-  a.out.cg = o.cg + slot0*nrec;
-  a.out.g = o.g + slot0*nrec;
-  a.out.ncand = o.ncand + slot0*nrec;
-  a.out.cos_dist = o.cos_dist + slot0*2*nrec;
-  a.out.dist = o.dist + slot0*2*nrec;
-  a.out.qg = o.qg + slot0*2*nrec;
-  a.out.k = o.k + slot0*2*nrec;
-  a.out.y = o.y + slot0*ny;
-  a.out.perm = o.perm_rw + slot0*nrec;          // written by the companding stage (od_hip_pvq_compand_level / feed)
+  a.out = pvq_slot(o, slot0);                   // cg and the work lists are written by the companding stage
   // the strip's blocks of this level: block rows are superblock rows times 32/n (luma units)
   {
     const int per_sb = (32 >> ctx->geo.xdec[pli])/n;
@@ -1120,13 +1195,24 @@ int od_hip_pvq_stats(od_hip_ctx *ctx, int enable, uint64_t out[3]) {
   if (out) {
     out[0] = out[1] = out[2] = 0;
     if (ctx->pvq_stats) {
-      HIPCHK(hipMemcpyAsync(out, ctx->pvq_stats, 24, hipMemcpyDeviceToHost, ctx->stream));
+      uint64_t all[64];
+      HIPCHK(hipMemcpyAsync(all, ctx->pvq_stats, sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
+      out[0] = all[0]; out[1] = all[1]; out[2] = all[2];
+      if (getenv("OD_HIP_PVQ_STAMPS")) {           // diagnostic builds (-DPVQ_STAMPS): cycles per phase
+        static const char *cls[4] = {"15", "8", "32", "128"};
+        for (int c = 0; c < 4; c++) {
+          const uint64_t *p = all + 8 + 8*c;
+          if (p[7]) fprintf(stderr, "pvq_stamps N=%s waves=%llu list=%.0f gather=%.0f norms=%.0f search=%.0f out=%.0f (cycles per wave)\n",
+                            cls[c], (unsigned long long)p[7], (double)p[0]/p[7], (double)p[1]/p[7], (double)p[2]/p[7],
+                            (double)p[3]/p[7], (double)p[4]/p[7]);
+        }
+      }
     }
   }
   if (enable) {
-    if (!ctx->pvq_stats) HIPCHK(hipMalloc((void **)&ctx->pvq_stats, 24));
-    HIPCHK(hipMemsetAsync(ctx->pvq_stats, 0, 24, ctx->stream));
+    if (!ctx->pvq_stats) HIPCHK(hipMalloc((void **)&ctx->pvq_stats, 64*8));
+    HIPCHK(hipMemsetAsync(ctx->pvq_stats, 0, 64*8, ctx->stream));
   }
   else if (ctx->pvq_stats) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1163,27 +1249,27 @@ int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, in
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
       HIPCHK(hipMemcpyAsync(g.data() + ((size_t)s*c.a.nbands + b)*per,
-                            c.a.out.g + (size_t)s*c.nrec + (size_t)b*c.nblk + first, per*8,
+                            c.a.out.g + (size_t)s*c.a.out.fs_g + (size_t)b*c.nblk + first, per*8,
                             hipMemcpyDeviceToHost, ctx->stream));
     }
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  std::vector<int32_t> perm(tot);
+  std::vector<int32_t> perm(2*tot);
   const bool whole = ctx->strip0 == 0 && ctx->strip1 == ctx->nvsb && pvq_sort_enabled();
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
       const size_t o = ((size_t)s*c.a.nbands + b)*per;
       for (size_t i = 0; i < per; i++) cg[o + i] = host_gain_compand(g[o + i], q[b], beta[b]);
-      pvq_block_order(cg.data() + o, first, count, c.a.off[b + 1] - c.a.off[b], beta[b], whole, perm.data() + o);
+      pvq_block_order(cg.data() + o, first, count, c.a.off[b + 1] - c.a.off[b], beta[b], whole, perm.data() + 2*o);
     }
   }
   for (int s = 0; s < nslots; s++) {
     for (int b = 0; b < c.a.nbands; b++) {
-      HIPCHK(hipMemcpyAsync(c.a.out.cg + (size_t)s*c.nrec + (size_t)b*c.nblk + first,
+      HIPCHK(hipMemcpyAsync(c.a.out.cg + (size_t)s*c.a.out.fs_cg + (size_t)b*c.nblk + first,
                             cg.data() + ((size_t)s*c.a.nbands + b)*per, per*8,
                             hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(c.o->perm_rw + (size_t)(slot0 + s)*c.nrec + (size_t)b*c.nblk + first,
-                            perm.data() + ((size_t)s*c.a.nbands + b)*per, per*4,
+      HIPCHK(hipMemcpyAsync(const_cast<int32_t *>(c.a.out.perm) + (size_t)s*c.a.out.fs_perm + (size_t)b*2*c.nblk + 2*first,
+                            perm.data() + 2*((size_t)s*c.a.nbands + b)*per, 2*per*4,
                             hipMemcpyHostToDevice, ctx->stream));
     }
   }
@@ -1213,24 +1299,22 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
   int nblk = od_hip_pvq_nblocks(ctx, pli, level);
   if (nblk < 0) return nblk;
   if (!ctx->pvq_alloc[pli][level]) return fail(OD_HIP_EINVAL, "no PVQ results for this level");
-  int n = (32 >> ctx->geo.xdec[pli]) >> level;
-  int bs = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
-  int off[11];
-  int nb = od_hip_band_offsets(bs, off);
-  int ncoded = n*n < 512 ? n*n : 512;
-  size_t nrec = (size_t)nb*nblk, ny = (size_t)2*nblk*(ncoded - 1);
-  PvqSoA &o = ctx->pvq[pli][level];
+  const PvqLevelLayout &L = ctx->arena[pli].lev[level];
+  const int *off = L.off;
+  const int nb = L.nb, ncoded = L.ncoded;
+  const size_t nrec = L.nrec, ny = L.ny;
+  const PvqSoA o = pvq_slot(ctx->pvq[pli][level], slot);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (bands) {
     std::vector<double> cg(nrec), g(nrec), cd(2*nrec), di(2*nrec);
     std::vector<int32_t> qg(2*nrec), k(2*nrec), nc(nrec);
-    HIPCHK(hipMemcpyAsync(cg.data(), o.cg + slot*nrec, nrec*8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(g.data(), o.g + slot*nrec, nrec*8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(cd.data(), o.cos_dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(di.data(), o.dist + slot*2*nrec, 2*nrec*8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(qg.data(), o.qg + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(k.data(), o.k + slot*2*nrec, 2*nrec*4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(nc.data(), o.ncand + slot*nrec, nrec*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cg.data(), o.cg, nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(g.data(), o.g, nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cd.data(), o.cos_dist, 2*nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(di.data(), o.dist, 2*nrec*8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(qg.data(), o.qg, 2*nrec*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(k.data(), o.k, 2*nrec*4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nc.data(), o.ncand, nrec*4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < nb; b++) {
       for (int blk = 0; blk < nblk; blk++) {
@@ -1245,18 +1329,19 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
     }
   }
   if (y) {
-    // device: band-major [band][cand][block][n_b]  ->  API: [block][cand][ncoded]
-    std::vector<int32_t> yd(ny);
-    HIPCHK(hipMemcpyAsync(yd.data(), o.y + slot*ny, ny*4, hipMemcpyDeviceToHost, ctx->stream));
+    // device: band-major int16 [band][cand][block][ns_b]  ->  API: int32 [block][cand][ncoded]
+    std::vector<int16_t> yd(ny);
+    HIPCHK(hipMemcpyAsync(yd.data(), o.y, ny*2, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memset(y, 0, (size_t)nblk*2*ncoded*sizeof(int32_t));
     for (int b = 0; b < nb; b++) {
-      int nbnd = off[b + 1] - off[b];
-      const int32_t *src = yd.data() + (size_t)2*nblk*(off[b] - 1);
+      const int nbnd = off[b + 1] - off[b], ns = pvq_ns(off, b);
+      const int16_t *src = yd.data() + (size_t)2*nblk*pvq_yo(off, b);
       for (int c = 0; c < 2; c++) {
         for (int blk = 0; blk < nblk; blk++) {
-          memcpy(y + ((size_t)blk*2 + c)*ncoded + off[b],
-                 src + ((size_t)c*nblk + blk)*nbnd, nbnd*sizeof(int32_t));
+          int32_t *dst = y + ((size_t)blk*2 + c)*ncoded + off[b];
+          const int16_t *sp = src + ((size_t)c*nblk + blk)*ns;
+          for (int j = 0; j < nbnd; j++) dst[j] = sp[j];
         }
       }
     }

@@ -18,18 +18,16 @@ struct od_hip_enc_feed {
   od_coeff *haar[3] = {nullptr, nullptr, nullptr};   // lossless frames: pinned [slot][h][w] Haar planes (lazy)
   std::vector<char> lossless;             // slot holds Haar planes, not the PVQ feed
   std::vector<char> pending;              // slot has a copy in flight / landed
+  // Pinned host mirrors of the luma plane's per-slot arenas (PvqArena): ONE transfer per frame
+  // slot and direction - records + pulses down, gains down, companded gains + work lists up -
+  // and one for the four level planes of a slot (they are contiguous in the context).
+  char *h_out = nullptr, *h_g = nullptr, *h_in = nullptr;
+  od_coeff *h_planes = nullptr;           // [slot][level][h][w]
   struct Lev {
-    int n, bs, nb, nblk, nbx, off[11];
-    size_t nrec, ny;
     bool set = false;
     std::vector<int16_t> qm;
     int32_t q[11];
     double beta[11];
-    // pinned host mirrors, all slots: [slot][...]
-    int32_t *ncand = nullptr, *k = nullptr, *qg = nullptr, *y = nullptr;
-    int32_t *perm = nullptr;              // pinned: block order of every band (host -> device)
-    double *cos_dist = nullptr, *cg = nullptr, *g = nullptr;
-    od_coeff *plane = nullptr;            // [slot][h][w] the pyramid level itself
   } lev[4];
 };
 
@@ -39,17 +37,10 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   if (f->copy) (void)hipStreamSynchronize(f->copy);
-  for (auto &l : f->lev) {
-    if (l.ncand) (void)hipHostFree(l.ncand);
-    if (l.perm) (void)hipHostFree(l.perm);
-    if (l.k) (void)hipHostFree(l.k);
-    if (l.qg) (void)hipHostFree(l.qg);
-    if (l.cg) (void)hipHostFree(l.cg);
-    if (l.g) (void)hipHostFree(l.g);
-    if (l.y) (void)hipHostFree(l.y);
-    if (l.cos_dist) (void)hipHostFree(l.cos_dist);
-    if (l.plane) (void)hipHostFree(l.plane);
-  }
+  if (f->h_out) (void)hipHostFree(f->h_out);
+  if (f->h_g) (void)hipHostFree(f->h_g);
+  if (f->h_in) (void)hipHostFree(f->h_in);
+  if (f->h_planes) (void)hipHostFree(f->h_planes);
   for (auto &h : f->haar) if (h) (void)hipHostFree(h);
   for (auto e : f->ready) if (e) (void)hipEventDestroy(e);
   for (auto e : f->gready) if (e) (void)hipEventDestroy(e);
@@ -85,25 +76,13 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
   f->pending.assign(ns, 0);
   for (size_t s = 0; ok && s < ns; s++)
     ok = hipEventCreateWithFlags(&f->ready[s], hipEventDisableTiming) == hipSuccess;
-  for (int l = 0; ok && l < 4; l++) {
-    auto &L = f->lev[l];
-    L.n = 32 >> l;
-    L.bs = 3 - l;
-    L.nb = od_hip_band_offsets(L.bs, L.off);
-    L.nbx = ctx->pw[0]/L.n;
-    L.nblk = L.nbx*(ctx->ph[0]/L.n);
-    int ncoded = L.n*L.n < 512 ? L.n*L.n : 512;
-    L.nrec = (size_t)L.nb*L.nblk;
-    L.ny = (size_t)2*L.nblk*(ncoded - 1);
-    ok = ok && hipHostMalloc((void **)&L.ncand, ns*L.nrec*4) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.perm, ns*L.nrec*4) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.k, ns*2*L.nrec*4) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.qg, ns*2*L.nrec*4) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.cg, ns*L.nrec*8) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.g, ns*L.nrec*8) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.cos_dist, ns*2*L.nrec*8) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.y, ns*L.ny*4) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&L.plane, ns*ctx->psz[0]*sizeof(od_coeff)) == hipSuccess;
+  ok = ok && pvq_arena(ctx, 0) == 0;
+  if (ok) {
+    const PvqArena &A = ctx->arena[0];
+    ok = hipHostMalloc((void **)&f->h_out, ns*A.out_slot) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&f->h_g, ns*A.g_slot) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&f->h_in, ns*A.in_slot) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&f->h_planes, ns*ctx->nlev[0]*ctx->psz[0]*sizeof(od_coeff)) == hipSuccess;
   }
   if (!ok) {
     fail(OD_HIP_ENODEV, "encoder feed allocation failed");
@@ -118,8 +97,9 @@ int od_hip_enc_feed_set_level(od_hip_enc_feed *f, int level, const int16_t *qm,
   if (!f || !qm || !q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
   if (level < 0 || level > 3) return fail(OD_HIP_EINVAL, "level out of range");
   auto &L = f->lev[level];
-  L.qm.assign(qm, qm + L.n*L.n);
-  for (int b = 0; b < L.nb; b++) { L.q[b] = q[b]; L.beta[b] = beta[b]; }
+  const PvqLevelLayout &Y = f->ctx->arena[0].lev[level];
+  L.qm.assign(qm, qm + Y.n*Y.n);
+  for (int b = 0; b < Y.nb; b++) { L.q[b] = q[b]; L.beta[b] = beta[b]; }
   L.set = true;
   return 0;
 }
@@ -142,12 +122,10 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
   // the level planes are final here: their copies overlap everything that follows
   HIPCHK(hipEventRecord(f->transformed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->transformed, 0));
+  const size_t pl = (size_t)ctx->nlev[0]*ctx->psz[0];
   for (int s = slot0; s < slot0 + nslots; s++) {
-    for (int l = 0; l < 4; l++) {
-      HIPCHK(hipMemcpyAsync(f->lev[l].plane + (size_t)s*ctx->psz[0],
-                            ctx->lev[0] + ((size_t)s*ctx->nlev[0] + l)*ctx->psz[0],
-                            ctx->psz[0]*sizeof(od_coeff), hipMemcpyDeviceToHost, f->copy));
-    }
+    HIPCHK(hipMemcpyAsync(f->h_planes + (size_t)s*pl, ctx->lev[0] + (size_t)s*pl, pl*sizeof(od_coeff),
+                          hipMemcpyDeviceToHost, f->copy));
   }
   for (int l = 0; l < 4; l++) {
     auto &L = f->lev[l];
@@ -155,40 +133,39 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
   }
   HIPCHK(hipEventRecord(f->gains_done, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->up, f->gains_done, 0));
+  const PvqArena &A = ctx->arena[0];
   for (int s = slot0; s < slot0 + nslots; s++) {
-    for (int l = 0; l < 4; l++) {
-      auto &L = f->lev[l];
-      HIPCHK(hipMemcpyAsync(L.g + s*L.nrec, ctx->pvq[0][l].g + s*L.nrec, L.nrec*8, hipMemcpyDeviceToHost, f->up));
-    }
+    HIPCHK(hipMemcpyAsync(f->h_g + (size_t)s*A.g_slot, A.g + (size_t)s*A.g_slot, A.g_slot, hipMemcpyDeviceToHost, f->up));
     HIPCHK(hipEventRecord(f->gready[s], f->up));
   }
   return 0;
 }
 
 // Phase 2, per slot, any host thread (slots are independent): cg = od_gain_compand(g) with
-// the host's libm for every band of the slot, then the upload.
+// the host's libm for every band of the slot and the work lists of the searches, then the upload.
 int od_hip_enc_feed_compand(od_hip_enc_feed *f, int slot) {
   if (!f) return fail(OD_HIP_EFAULT, "null feed");
   od_hip_ctx *ctx = f->ctx;
   if (slot < 0 || slot >= ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipEventSynchronize(f->gready[slot]));
+  const PvqArena &A = ctx->arena[0];
   for (int l = 0; l < 4; l++) {
     auto &L = f->lev[l];
-    const double *g = L.g + slot*L.nrec;
-    double *cg = L.cg + slot*L.nrec;
-    for (int b = 0; b < L.nb; b++) {
+    const PvqLevelLayout &Y = A.lev[l];
+    const double *g = (const double *)(f->h_g + (size_t)slot*A.g_slot + Y.o_g);
+    double *cg = (double *)(f->h_in + (size_t)slot*A.in_slot + Y.o_cg);
+    int32_t *perm = (int32_t *)(f->h_in + (size_t)slot*A.in_slot + Y.o_perm);
+    for (int b = 0; b < Y.nb; b++) {
       const int q0 = L.q[b];
       const double beta = L.beta[b];
-      const size_t o = (size_t)b*L.nblk;
-      for (int i = 0; i < L.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
-      pvq_block_order(cg + o, 0, L.nblk, L.off[b + 1] - L.off[b], beta, pvq_sort_enabled(),
-                      L.perm + slot*L.nrec + o);
+      const size_t o = (size_t)b*Y.nblk;
+      for (int i = 0; i < Y.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
+      pvq_block_order(cg + o, 0, Y.nblk, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
     }
-    HIPCHK(hipMemcpyAsync(ctx->pvq[0][l].cg + slot*L.nrec, cg, L.nrec*8, hipMemcpyHostToDevice, f->up));
-    HIPCHK(hipMemcpyAsync(ctx->pvq[0][l].perm_rw + slot*L.nrec, L.perm + slot*L.nrec, L.nrec*4,
-                          hipMemcpyHostToDevice, f->up));
   }
+  HIPCHK(hipMemcpyAsync(A.in + (size_t)slot*A.in_slot, f->h_in + (size_t)slot*A.in_slot, A.in_slot,
+                        hipMemcpyHostToDevice, f->up));
   HIPCHK(hipEventRecord(f->cgup[slot], f->up));
   f->companded[slot] = 1;
   return 0;
@@ -210,16 +187,10 @@ int od_hip_enc_feed_search(od_hip_enc_feed *f, int slot0, int nslots) {
   if (int rc = join_aux(ctx)) return rc;          // the PVQ launches run on side streams
   HIPCHK(hipEventRecord(f->computed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
+  const PvqArena &A = ctx->arena[0];
   for (int s = slot0; s < slot0 + nslots; s++) {
-    for (int l = 0; l < 4; l++) {
-      auto &L = f->lev[l];
-      PvqSoA &o = ctx->pvq[0][l];
-      HIPCHK(hipMemcpyAsync(L.ncand + s*L.nrec, o.ncand + s*L.nrec, L.nrec*4, hipMemcpyDeviceToHost, f->copy));
-      HIPCHK(hipMemcpyAsync(L.qg + s*2*L.nrec, o.qg + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
-      HIPCHK(hipMemcpyAsync(L.k + s*2*L.nrec, o.k + s*2*L.nrec, 2*L.nrec*4, hipMemcpyDeviceToHost, f->copy));
-      HIPCHK(hipMemcpyAsync(L.cos_dist + s*2*L.nrec, o.cos_dist + s*2*L.nrec, 2*L.nrec*8, hipMemcpyDeviceToHost, f->copy));
-      HIPCHK(hipMemcpyAsync(L.y + s*L.ny, o.y + s*L.ny, L.ny*4, hipMemcpyDeviceToHost, f->copy));
-    }
+    HIPCHK(hipMemcpyAsync(f->h_out + (size_t)s*A.out_slot, A.out + (size_t)s*A.out_slot, A.out_slot,
+                          hipMemcpyDeviceToHost, f->copy));
     HIPCHK(hipEventRecord(f->ready[s], f->copy));
     f->pending[s] = 1;
   }
@@ -286,23 +257,27 @@ int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4])
   if (!f->pending[slot] || f->lossless[slot]) return fail(OD_HIP_EINVAL, "no feed run covers this slot");
   HIPCHK(hipSetDevice(f->ctx->device));       // callers are host worker threads
   HIPCHK(hipEventSynchronize(f->ready[slot]));
+  const PvqArena &A = f->ctx->arena[0];
+  const char *out = f->h_out + (size_t)slot*A.out_slot;
+  const char *in = f->h_in + (size_t)slot*A.in_slot;
+  const char *hg = f->h_g + (size_t)slot*A.g_slot;
   for (int l = 0; l < 4; l++) {
-    auto &L = f->lev[l];
+    const PvqLevelLayout &Y = A.lev[l];
     od_hip_feed_level &v = lev[l];
-    v.n = L.n;
-    v.nbands = L.nb;
-    v.nblk = L.nblk;
-    v.nbx = L.nbx;
-    for (int i = 0; i < 11; i++) v.off[i] = i <= L.nb ? L.off[i] : 0;
+    v.n = Y.n;
+    v.nbands = Y.nb;
+    v.nblk = Y.nblk;
+    v.nbx = f->ctx->pw[0]/Y.n;
+    for (int i = 0; i < 11; i++) v.off[i] = i <= Y.nb ? Y.off[i] : 0;
     v.pad = 0;
-    v.ncand = L.ncand + slot*L.nrec;
-    v.k = L.k + slot*2*L.nrec;
-    v.qg = L.qg + slot*2*L.nrec;
-    v.cg = L.cg + slot*L.nrec;
-    v.g = L.g + slot*L.nrec;
-    v.cos_dist = L.cos_dist + slot*2*L.nrec;
-    v.y = L.y + slot*L.ny;
-    v.lev = L.plane + (size_t)slot*f->ctx->psz[0];
+    v.ncand = (const int32_t *)(out + Y.o_nc);
+    v.k = (const int32_t *)(out + Y.o_k);
+    v.qg = (const int32_t *)(out + Y.o_qg);
+    v.cos_dist = (const double *)(out + Y.o_cd);
+    v.y = (const int16_t *)(out + Y.o_y);
+    v.cg = (const double *)(in + Y.o_cg);
+    v.g = (const double *)(hg + Y.o_g);
+    v.lev = f->h_planes + ((size_t)slot*f->ctx->nlev[0] + l)*f->ctx->psz[0];
     v.lev_stride = f->ctx->pw[0];
     v.pad2 = 0;
   }

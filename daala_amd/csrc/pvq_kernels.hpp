@@ -144,21 +144,27 @@ struct PvqBandRec {      // mirrors od_hip_pvq_band (include/daala_hip.h); host-
   int32_t pad;
 };
 
-// Device-side result layout of one (plane, level), per frame slot: structure of
-// arrays, band-major, so that a wave (64 consecutive blocks of one band) writes
-// contiguous memory.  All arrays are [band][block]:
+// Device-side result layout of one (plane, level): structure of arrays, band-major, so that
+// a wave writes contiguous memory.  All record arrays are [band][block]; every array has its
+// own distance between frame slots (fs_*, in elements) because the arrays that cross PCIe
+// live in per-slot arenas - one transfer per frame slot and direction:
+//   out arena  [slot]{level 0: cos_dist, qg, k, ncand, y; level 1: ...}    device -> host
+//   g arena    [slot]{level 0: g; level 1: ...}                            device -> host
+//   in arena   [slot]{level 0: cg, perm; level 1: ...}                     host -> device
 struct PvqSoA {
   double *cg, *g;           // [nbands*nblk]
-  double *cos_dist, *dist;  // [2][nbands*nblk] per frame
-  int32_t *qg, *k;          // [2][nbands*nblk] per frame
+  double *cos_dist, *dist;  // [2][nbands*nblk]
+  int32_t *qg, *k;          // [2][nbands*nblk]
   int32_t *ncand;           // [nbands*nblk]
-  // pulses: band b occupies y + 2*nblk*(off[b]-1), laid out [cand][block][n_b]
-  int32_t *y;
-  // work-balancing order (performance only): perm[band*nblk + i] = the block the i-th lane
-  // slot of that band processes; written by the host with the companded gains, which fix
-  // every K.  nullptr: blocks in raster order.
+  // pulses, int16 (|y| <= K <= 738): band b occupies y + 2*nblk*yo[b], laid out
+  // [cand][block][ns[b]] with ns = the band size rounded up to even (one pad entry for the
+  // 15-coefficient band: runs start 4-byte aligned) and yo = 0, off[1], off[2], ...
+  int16_t *y;
+  // work list of the search kernel (performance only): perm[band*2*nblk + i] = entry
+  // 2*block + candidate of the i-th lane slot of that band; written by the host with the
+  // companded gains, which fix every K.
   const int32_t *perm;
-  int32_t *perm_rw;         // host side: the allocation perm points into (all slots)
+  size_t fs_cg, fs_g, fs_cd, fs_dist, fs_qg, fs_k, fs_nc, fs_y, fs_perm;
 };
 
 struct PvqLevelArgs {
@@ -174,9 +180,7 @@ struct PvqLevelArgs {
   int band_list[10];       // bands handled by this launch (all of size N)
   const uint16_t *tab;     // coding index -> raster offset (y*n + x)
   const int16_t *qm;       // n*n, coding order
-  PvqSoA out;              // frame 0
-  size_t rec_fstride;      // nbands*nblk (elements between frames of the record arrays)
-  size_t y_fstride;        // 2*nblk*(ncoded-1)
+  PvqSoA out;              // frame 0 of the launch
   long blk_first, blk_end; // blocks [blk_first, blk_end) of the level are processed (a strip of SB rows)
 };
 
@@ -211,21 +215,8 @@ __device__ __attribute__((noinline)) double pvq_rsqrt_slow(int i) {
   return 1./sqrt((double)i);
 }
 
-#ifndef PVQ_RSQ_LDS
-#define PVQ_RSQ_LDS 0         /* entries of the table also kept in LDS per workgroup (0: none) */
-#endif
-struct PvqRsq {
-  const double *tab;          // global, PVQ_RSQ_TAB entries
-  const double *lds;          // LDS copy of the first PVQ_RSQ_LDS entries, or nullptr
-};
-__device__ __forceinline__ double pvq_rsqrt_tab(const PvqRsq &r, int i) {
-  if (PVQ_RSQ_LDS > 0 && i < PVQ_RSQ_LDS) return r.lds[i];
-  if (__builtin_expect(i < PVQ_RSQ_TAB, 1)) return r.tab[i];
-  return pvq_rsqrt_slow(i);
-}
-
 #ifndef PVQ_G128
-#define PVQ_G128 8            /* lanes per 128-coefficient band (A/B on MI355X: 4 -> 8.5 ms, 8 -> 4.6, 16 -> 5.9) */
+#define PVQ_G128 16           /* lanes per 128-coefficient band (round 3, tree combine: 8 -> 0.97 ms per launch, 16 -> 0.90) */
 #endif
 #ifndef PVQ_G32
 #define PVQ_G32 4             /* lanes per 31/32-coefficient band (1: LDS kernel 3.05 ms, 2 -> 2.84, 4 -> 2.30, 8 -> 3.18) */
@@ -283,27 +274,86 @@ __device__ __forceinline__ void pvq_vec_finish(PvqVec<N> &v, int g, int lane) {
   v.l1_inv = 1./(l1 > 1e-100 ? l1 : 1e-100);
 }
 
+// 1/sqrt(i) for the RDO scans: the first PVQ_RSQ_L entries of the table live in LDS (one
+// copy per workgroup), the rest in global memory, anything beyond PVQ_RSQ_TAB is computed.
+#ifndef PVQ_RSQ_L
+#define PVQ_RSQ_L(N) ((N) == 128 ? 1024 : (N) == 32 ? 512 : 256)
+#endif
+
+// Data-parallel-primitive moves inside a row of 16 lanes (the G <= 16 lanes of a band are
+// consecutive and aligned, so a band never straddles a row): lane i reads lane i + S of its
+// row (row_shl:S), lanes beyond the row read 0.  VALU rate, no LDS round trip.
+template <int S>
+__device__ __forceinline__ int pvq_dpp_next_i(int v) {
+  static_assert(S >= 1 && S <= 15, "row shift");
+  return __builtin_amdgcn_update_dpp(0, v, 0x100 | S, 0xf, 0xf, true);
+}
+template <int S>
+__device__ __forceinline__ double pvq_dpp_next_d(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = pvq_dpp_next_i<S>(u.i[0]);
+  u.i[1] = pvq_dpp_next_i<S>(u.i[1]);
+  return u.d;
+}
+
+// Ordered tree combine of the lanes' RDO-scan winners: plain doubles, a total order, so the tree's winner IS the
+// sequential scan's (strictly greater replaces, the lower index stays on ties).
+template <int G, int S = 1>
+__device__ __forceinline__ void pvq_tree_rdo(double &c, double &t, int &code, int &yw) {
+  if constexpr (S < G) {
+    const double rc = pvq_dpp_next_d<S>(c), rt = pvq_dpp_next_d<S>(t);
+    const int rcode = pvq_dpp_next_i<S>(code), ry = pvq_dpp_next_i<S>(yw);
+    if (rc > c) { c = rc; t = rt; code = rcode; yw = ry; }
+    pvq_tree_rdo<G, 2*S>(c, t, code, yw);
+  }
+}
+
+// Ordered tree combine of the lanes' greedy-scan winners (a, b, t, code): after log2(G) steps
+// the band's first lane holds the winner of the pairwise rounded compares, the lower lane
+// kept on "not strictly greater" (first index wins).  The tree need not agree with the
+// sequential scan when rounding makes the compare non-transitive: its winner is verified.
+template <int G, int S = 1>
+__device__ __forceinline__ void pvq_tree_greedy(double &a, double &b, double &t, int &code) {
+  if constexpr (S < G) {
+    const double ra = pvq_dpp_next_d<S>(a), rb = pvq_dpp_next_d<S>(b), rt = pvq_dpp_next_d<S>(t);
+    const int rc = pvq_dpp_next_i<S>(code);
+    if (ra*b > a*rb) { a = ra; b = rb; t = rt; code = rc; }
+    pvq_tree_greedy<G, 2*S>(a, b, t, code);
+  }
+}
+
 // One codeword search (pvq_search_rdo_double, src/pvq_encoder.c:121-225) for the
-// band owned by this lane group.  `act`: this band really has a candidate (lanes
-// of inactive bands run with k = 0).  Returns the cosine distance; y = unsigned
-// pulses of this lane's chunk.
+// band owned by this lane group.  Lanes of bands without a candidate run with k = 0.
+// Returns the cosine distance; y = unsigned pulses of this lane's chunk.
+//
+// Round 3 (v4).  What the round-2 profile showed as "waves parked 64-77 %" was serialised
+// memory latency, not arithmetic: the per-element `y > 3` table look-up of the RDO scan sat in
+// its own branch (one global load + wait per element and pulse) and the scans carried the
+// winner's x and y out through a second select chain.  Now: every 1/sqrt of a pulse is read
+// in ONE batch (LDS copy of the table, or one batch of independent global loads beyond it),
+// the scans carry the unsquared sum and the new yy of the winner (they ARE the reference's
+// next xy and yy: same operands, same operation), and no branch is left inside a scan.
 template <int N>
-__device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int lane, int k,
-                                                double g2, const PvqRsq &rsq,
+__device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int lane, int k,
+                                                double g2, const double *__restrict__ rsq,
+                                                const double *rsqL,
                                                 int (&y)[PvqGeom<N>::NL], int &npulse_greedy,
                                                 int &npulse_rdo) {
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL;
+  static_assert(G*NL == N, "every lane of a band owns NL coefficients (no padding elements in the scans)");
   const int base = (lane/G)*G;                  // first lane of my band
-  const int nvalid = (N - g*NL) < NL ? (N - g*NL) : NL;
   const double lambda = PVQ_LAMBDA/(1e-30 + g2);
   const double delta_rate = 3./N;
   double xy = 0, yy = 0;
   int i = 0;
+  int ymax = 0;                                 // largest pulse count of this lane's chunk
   if (k > 2) {
 #pragma unroll
     for (int j = 0; j < NL; j++) {
       int p = (int)floor(k*v.x[j]*v.l1_inv);
       y[j] = p > 0 ? p : 0;
+      ymax = y[j] > ymax ? y[j] : ymax;
     }
     xy = pvq_chain_sum<N>(g, lane, [&](int j) { return v.x[j]*y[j]; });
     int s2 = 0, s1 = 0;
@@ -315,8 +365,6 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
       s1 += __shfl_xor(s1, o, 64);
     }
     // yy accumulates exact integers in double (< 2^53): any order is exact.
-    // NOTE: the reference adds ypulse[j]*ypulse[j] as int products one by one;
-    // each partial sum is an exactly representable integer, so the value is the same.
     yy = (double)s2;
     i = s1;
   }
@@ -329,42 +377,44 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
   // wave-uniform trip count: bands that are done idle (masked) meanwhile
   while (__any(i < k - rdo_pulses)) {
     const bool run = i < k - rdo_pulses;
-    double ba = 0, bb = 1;
+    // local scan of this lane's chunk; bt/bb = the winner's xy + x and yy + 2y + 1
+    double bt = xy + v.x[0];
+    double bb = yy + (double)(2*y[0] + 1);
+    double ba = bt*bt;
     int bpos = 0;
 #pragma unroll
-    for (int j = 0; j < NL; j++) {
-      if (G*NL == N || j < nvalid) {
-        double a = xy + v.x[j];
-        const double b = yy + (2*y[j] + 1);
-        a *= a;
-        if (j == 0 || a*bb > ba*b) { ba = a; bb = b; bpos = j; }
-      }
+    for (int j = 1; j < NL; j++) {
+      const double t = xy + v.x[j];
+      const double b = yy + (double)(2*y[j] + 1);
+      const double a = t*t;
+      if (a*bb > ba*b) { ba = a; bb = b; bt = t; bpos = j; }
     }
-    int wl = bpos, wg = 0;            // winner: local index and owning lane group index
+    int wl = bpos, wg = 0;            // winner: local index and owning lane of the group
+    double nxy = bt, nyy = bb;
     if (G > 1) {
-      double ca = __shfl(ba, base, 64), cb = __shfl(bb, base, 64);
-      int cp = __shfl(bpos, base, 64);
-      wg = 0;
-#pragma unroll
-      for (int r = 1; r < G; r++) {
-        const double ra = __shfl(ba, base + r, 64), rb = __shfl(bb, base + r, 64);
-        const int rp = __shfl(bpos, base + r, 64);
-        if (ra*cb > ca*rb) { ca = ra; cb = rb; cp = rp; wg = r; }
-      }
-      wl = cp;
+      double ca = ba, cb = bb, ct = bt;
+      int code = g*NL + bpos;
+      pvq_tree_greedy<G>(ca, cb, ct, code);
+      ca = __shfl(ca, base, 64);
+      cb = __shfl(cb, base, 64);
+      ct = __shfl(ct, base, 64);
+      code = __shfl(code, base, 64);
+      wg = code/NL;
+      wl = code%NL;
       // verification: w = (wg, wl) must strictly beat every earlier element and
       // must not be strictly beaten by any later one
       bool ok = true;
 #pragma unroll
       for (int j = 0; j < NL; j++) {
-        if (j < nvalid) {
-          double a = xy + v.x[j];
-          const double b = yy + (2*y[j] + 1);
-          a *= a;
+        {
+          const double t = xy + v.x[j];
+          const double b = yy + (double)(2*y[j] + 1);
+          const double a = t*t;
+          const double p1 = ca*b, p2 = a*cb;
           const bool before = g < wg || (g == wg && j < wl);
-          const bool after = g > wg || (g == wg && j > wl);
-          if (before) ok = ok && (ca*b > a*cb);
-          if (after) ok = ok && !(a*cb > ca*b);
+          const bool self = g == wg && j == wl;
+          // before: p1 > p2 required; after: !(p2 > p1)
+          ok = ok && (self || (before ? p1 > p2 : !(p2 > p1)));
         }
       }
       if (__any(run && !ok)) {
@@ -376,7 +426,7 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
           if (g == r) {
 #pragma unroll
             for (int j = 0; j < NL; j++) {
-              if (j < nvalid) {
+              {
                 double a = xy + v.x[j];
                 const double b = yy + (2*y[j] + 1);
                 a *= a;
@@ -392,26 +442,26 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
         }
         wl = __shfl(ip, base + G - 1, 64);
         wg = __shfl(ig, base + G - 1, 64);
+        cb = __shfl(ib, base + G - 1, 64);
+        // the sequential winner need not be a local winner: its lane recomputes xy + x
+        double tw = 0;
+#pragma unroll
+        for (int j = 0; j < NL; j++) tw = j == wl ? xy + v.x[j] : tw;
+        ct = __shfl(tw, base + wg, 64);
       }
+      nxy = ct;
+      nyy = cb;
     }
     // apply the pulse
-    double xw = 0;
-    int yw = 0;
+    const int ap = (run && (G == 1 || g == wg)) ? wl : -1;
 #pragma unroll
-    for (int j = 0; j < NL; j++) {
-      if (j == wl) { xw = v.x[j]; yw = y[j]; }
-    }
-    if (G > 1) {
-      xw = __shfl(xw, base + wg, 64);
-      yw = __shfl(yw, base + wg, 64);
-    }
+    for (int j = 0; j < NL; j++) y[j] += (j == ap);
     if (run) {
-      xy = xy + xw;
-      yy = yy + (2*yw + 1);
-      if (g == wg) {
-#pragma unroll
-        for (int j = 0; j < NL; j++) y[j] += (j == wl);
-      }
+      // the winner now holds (nyy - yy + 1)/2 pulses (an upper bound for every lane of the band)
+      const int yn = ((int)(nyy - yy) + 1) >> 1;
+      ymax = yn > ymax ? yn : ymax;
+      xy = nxy;
+      yy = nyy;
       i++;
       npulse_greedy++;
     }
@@ -422,51 +472,106 @@ __device__ __forceinline__ double pvq_search_v3(const PvqVec<N> &v, int g, int l
   while (__any(i < k)) {
     const bool run = i < k;
     const int iy = (int)yy;
-    // the reference tabulates y = 0..3 per pulse (:205); same values here
-    const double r0 = pvq_rsqrt_tab(rsq, iy + 1), r1 = pvq_rsqrt_tab(rsq, iy + 3);
-    const double r2 = pvq_rsqrt_tab(rsq, iy + 5), r3 = pvq_rsqrt_tab(rsq, iy + 7);
-    double bc = 0;
-    int bpos = 0;
+    const int hi = iy + 2*ymax + 1;           // largest table index this lane asks for
+    // keep lambda*j*delta_rate inside the loop: hoisted, it would pin 2 NL registers per lane
+    double lam = lambda;
+    asm volatile("" : "+v"(lam));
+    // The scans carry the winner's table index ix = iy + 2*y + 1 (not y itself: a select chain
+    // over y[] is folded into a dynamically indexed read of y, which sends y[] to scratch).
+    double bt, bc;
+    int bpos, bix;
+    if (!__any(hi >= PVQ_RSQ_L(N))) {
+      bix = iy + 2*y[0] + 1;
+      bt = xy + v.x[0];
+      bc = 2*bt*v.norm_1*rsqL[bix] - lam*(g*NL)*delta_rate;
+      bpos = 0;
 #pragma unroll
-    for (int j = 0; j < NL; j++) {
-      if (G*NL == N || j < nvalid) {
+      for (int j = 1; j < NL; j++) {
+        const int ix = iy + 2*y[j] + 1;
+        const double t = xy + v.x[j];
+        const double c = 2*t*v.norm_1*rsqL[ix] - lam*(g*NL + j)*delta_rate;
+        if (c > bc) { bc = c; bt = t; bpos = j; bix = ix; }
+      }
+    }
+    else if (N >= 32 && !__any(ymax > 3)) {
+      // long bands, beyond the LDS copy but every y <= 3: the reference's own 4-entry table of
+      // the pulse (od_fill_dynamic_rqrt_table, src/pvq_encoder.c:205): one batch of four loads
+      const double r0 = rsq[iy + 1 < PVQ_RSQ_TAB ? iy + 1 : 0], r1 = rsq[iy + 3 < PVQ_RSQ_TAB ? iy + 3 : 0];
+      const double r2 = rsq[iy + 5 < PVQ_RSQ_TAB ? iy + 5 : 0], r3 = rsq[iy + 7 < PVQ_RSQ_TAB ? iy + 7 : 0];
+      double q0 = r0, q1 = r1, q2 = r2, q3 = r3;
+      if (__any(iy + 7 >= PVQ_RSQ_TAB)) {
+        if (iy + 1 >= PVQ_RSQ_TAB) q0 = pvq_rsqrt_slow(iy + 1);
+        if (iy + 3 >= PVQ_RSQ_TAB) q1 = pvq_rsqrt_slow(iy + 3);
+        if (iy + 5 >= PVQ_RSQ_TAB) q2 = pvq_rsqrt_slow(iy + 5);
+        if (iy + 7 >= PVQ_RSQ_TAB) q3 = pvq_rsqrt_slow(iy + 7);
+      }
+      bt = 0; bc = 0; bpos = 0; bix = 0;
+#pragma unroll
+      for (int j = 0; j < NL; j++) {
         const int yj = y[j];
-        double rs = yj == 0 ? r0 : yj == 1 ? r1 : yj == 2 ? r2 : r3;
-        if (__builtin_expect(yj > 3, 0)) rs = pvq_rsqrt_tab(rsq, iy + 2*yj + 1);
-        double c = xy + v.x[j];
-        c = 2*c*v.norm_1*rs - lambda*(g*NL + j)*delta_rate;
-        if (j == 0 || c > bc) { bc = c; bpos = j; }
+        const double rs = yj == 0 ? q0 : yj == 1 ? q1 : yj == 2 ? q2 : q3;
+        const double t = xy + v.x[j];
+        const double c = 2*t*v.norm_1*rs - lam*(g*NL + j)*delta_rate;
+        if (j == 0 || c > bc) { bc = c; bt = t; bpos = j; bix = iy + 2*yj + 1; }
+      }
+    }
+    else {
+      // batches of independent loads from the global table (it stays in L1/L2), then the
+      // rare values beyond the table
+      constexpr int CHK = NL < 8 ? NL : 8;
+      bt = 0; bc = 0; bpos = 0; bix = 0;
+#pragma unroll
+      for (int j0 = 0; j0 < NL; j0 += CHK) {
+        double rs[CHK];
+#pragma unroll
+        for (int j = 0; j < CHK; j++) {
+          if (j0 + j < NL) {
+            const int ix = iy + 2*y[j0 + j] + 1;
+            rs[j] = rsq[ix < PVQ_RSQ_TAB ? ix : PVQ_RSQ_TAB - 1];
+          }
+        }
+        if (__any(hi >= PVQ_RSQ_TAB)) {
+#pragma unroll
+          for (int j = 0; j < CHK; j++) {
+            if (j0 + j < NL) {
+              const int ix = iy + 2*y[j0 + j] + 1;
+              if (ix >= PVQ_RSQ_TAB) rs[j] = pvq_rsqrt_slow(ix);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CHK; j++) {
+          if (j0 + j < NL) {
+            int ix = iy + 2*y[j0 + j] + 1;
+            asm volatile("" : "+v"(ix));       // opaque: no "bix = table[bpos]" rewrite through scratch
+            const double t = xy + v.x[j0 + j];
+            const double c = 2*t*v.norm_1*rs[j] - lam*(g*NL + j0 + j)*delta_rate;
+            if (j0 + j == 0 || c > bc) { bc = c; bt = t; bpos = j0 + j; bix = ix; }
+          }
+        }
       }
     }
     int wl = bpos, wg = 0;
+    double nxy = bt;
     if (G > 1) {
-      double cc = __shfl(bc, base, 64);
-      int cp = __shfl(bpos, base, 64);
+      double cc = bc, ct = bt;
+      int code = g*NL + bpos, cix = bix;
+      pvq_tree_rdo<G>(cc, ct, code, cix);
+      nxy = __shfl(ct, base, 64);
+      code = __shfl(code, base, 64);
+      bix = __shfl(cix, base, 64);
+      wg = code/NL;
+      wl = code%NL;
+    }
+    const int ap = (run && (G == 1 || g == wg)) ? wl : -1;
 #pragma unroll
-      for (int r = 1; r < G; r++) {
-        const double rc = __shfl(bc, base + r, 64);
-        const int rp = __shfl(bpos, base + r, 64);
-        if (rc > cc) { cc = rc; cp = rp; wg = r; }
-      }
-      wl = cp;
-    }
-    double xw = 0;
-    int yw = 0;
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-      if (j == wl) { xw = v.x[j]; yw = y[j]; }
-    }
-    if (G > 1) {
-      xw = __shfl(xw, base + wg, 64);
-      yw = __shfl(yw, base + wg, 64);
-    }
+    for (int j = 0; j < NL; j++) y[j] += (j == ap);
     if (run) {
-      xy = xy + xw;
-      yy = yy + (2*yw + 1);
-      if (g == wg) {
-#pragma unroll
-        for (int j = 0; j < NL; j++) y[j] += (j == wl);
-      }
+      // bix - iy = 2*y + 1 of the winner before its new pulse
+      const int yn = ((bix - iy) + 1) >> 1;
+      ymax = yn > ymax ? yn : ymax;
+      xy = nxy;
+      yy = yy + (bix - iy);
       i++;
       npulse_rdo++;
     }
@@ -488,167 +593,259 @@ struct PvqLevelArgs3 {
 #ifndef PVQ_STAGE_MIN_N
 #define PVQ_STAGE_MIN_N 32    /* bands longer than this are gathered through LDS (measured: pays for 128 only) */
 #endif
-#ifndef PVQ_V3_WAVES
-#define PVQ_V3_WAVES(N) 3     /* min waves/SIMD: 3 measured best for every N (4+ spills, 1-2 starves) */
+#ifndef PVQ_V4_WAVES
+/* min waves/SIMD asked of the register allocator (512/w registers per lane) */
+#define PVQ_V4_WAVES(N) 3     /* no spills at 168 registers for every N; 4 and more spill into the scans */
 #endif
-// Two launches per level: GAIN_ONLY computes the exact uncompanded gain g = sqrt(acc) of
+
+// LDS hand-over inside ONE wave (these kernels run single-wave workgroups): the LDS
+// operations of a wave execute in issue order, so a read issued after a write sees it; only the
+// compiler must keep the order, and the counter wait must not cover vector memory - a
+// workgroup barrier's fence would drain every load in flight and turn the kernel's start-up
+// into a chain of full memory round trips.  lgkmcnt(0); vmcnt / expcnt untouched.
+__device__ __forceinline__ void pvq_wave_lds_sync() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Gather of the band of the wave's lane slots (shared by the gain and the search kernel).
+// The wave loads cooperatively with lane = coefficient-within-block - consecutive lanes read
+// one block's few 64-byte segments - all NL loads of a lane issued back to back (the raster
+// offsets of the band come from an LDS copy, not from a dependent global load), stages the
+// values in LDS and every lane then picks up its own chunk.  Two memory round trips in all:
+// {work list, coding-order table, QM} and {coefficients}; the sampled in-kernel stamps of
+// round 3 (profiles/r03_pvq_stamps.txt) showed four, each 2-6 k cycles, against 5-15 k cycles
+// of search in a short-band wave.
+// pe: this lane's work-list entry as loaded (lane < BPW), or anything for other lanes.
+template <int N, typename ENTRY>
+__device__ __forceinline__ void pvq_gather(const PvqLevelArgs &a, int f, int o0, int lane, int g, int inst,
+                                           int nslot_here, ENTRY entry_of_lane, int32_t *Pe, int32_t *Yst,
+                                           int32_t *Org, bool &live, long &blk, const double *cg_band,
+                                           double &cg, int32_t (&cf)[PvqGeom<N>::NL],
+                                           int (&qi)[PvqGeom<N>::NL]) {
+  constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
+  constexpr int CH = NL + 1;                       // padded chunk stride in LDS
+  constexpr int LDSN = (G*CH) | 1;                 // odd per-band stride
+  constexpr int NR = (N + 63)/64;
+  __shared__ int32_t Ro[N];                        // raster offset of every coefficient of the band
+  const int lg = a.n == 4 ? 2 : a.n == 8 ? 3 : a.n == 16 ? 4 : 5;
+  // round trip 1: list entry, table, QM
+  const int32_t e_mine = entry_of_lane();
+  int rt[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) rt[q] = a.tab[o0 + (lane + 64*q < N ? lane + 64*q : 0)];
+#pragma unroll
+  for (int j = 0; j < NL; j++) qi[j] = a.qm[o0 + g*NL + j];
+  if (lane < BPW) {
+    Pe[lane] = e_mine;
+    const long bb = e_mine >= 0 ? e_mine >> 1 : 0;   // idle slots read block 0: a valid address
+    const int bx = bb%a.nbx, by = bb/a.nbx;
+    Org[lane] = (by*a.n)*a.w + bx*a.n;
+  }
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    if (lane + 64*q < N) Ro[lane + 64*q] = (rt[q] >> lg)*a.w + (rt[q] & (a.n - 1));
+  }
+  pvq_wave_lds_sync();
+  // round trip 2: the coefficients
+  const int32_t *plane = a.lev + (size_t)f*a.lev_fstride;
+  const int total = nslot_here*N;
+  int32_t val[NL];
+#pragma unroll
+  for (int it = 0; it < NL; it++) {
+    const int e = lane + 64*it;
+    const int ec = e < total ? e : 0;
+    const int b = ec/N, jj = ec - b*N;
+    val[it] = plane[(size_t)Org[b] + Ro[jj]];
+  }
+  const int32_t en = Pe[inst];
+  live = en >= 0;
+  blk = live ? en >> 1 : 0;
+  cg = cg_band ? cg_band[blk] : 0;                 // the band's companded gain rides the same round trip
+#pragma unroll
+  for (int it = 0; it < NL; it++) {
+    const int e = lane + 64*it;
+    const int b = e/N, jj = e - b*N;
+    if (e < total) Yst[b*LDSN + (jj/NL)*CH + jj%NL] = val[it];
+  }
+  pvq_wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    cf[j] = live ? Yst[inst*LDSN + g*CH + j] : 0;
+    qi[j] = live ? qi[j] : 0;
+  }
+  pvq_wave_lds_sync();                             // Yst is reused for the pulses
+}
+
+// Two launches per level.  k_pvq_gain computes the exact uncompanded gain g = sqrt(acc) of
 // every band (A13 up to the companding); the host then turns g into cg with ITS libm
 // (od_gain_compand's pow, src/pvq.c:422 - the one operation on this path that is not
 // +,-,*,/,sqrt,floor, and the only one whose result depends on the libm in use) and the
 // search launch reads cg back: the device never evaluates a transcendental.
-template <int N, bool GAIN_ONLY>
-__global__ __launch_bounds__(64, PVQ_V3_WAVES(N)) void k_pvq_noref_v3(PvqLevelArgs3 aa) {
+template <int N>
+__global__ __launch_bounds__(64) void k_pvq_gain(PvqLevelArgs3 aa) {
   const PvqLevelArgs &a = aa.a;
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
-  __shared__ int32_t Yst[BPW*(N + G + 2) + 1];      // >= BPW*N (output) and >= BPW*LDSN (staging)
+  __shared__ int32_t Yst[BPW*(N + G + 2) + 1];
   __shared__ int32_t Org[64];
+  __shared__ int32_t Pe[64];
   const int lane = threadIdx.x;
   const int g = lane%G, inst = lane/G;
-  __shared__ int32_t Pb[64];                        // the blocks of this wave's lane slots
   const long idx0 = a.blk_first + (long)blockIdx.x*BPW;
   const int band = a.band_list[blockIdx.y], f = blockIdx.z;
   const long nblk = (long)a.nbx*a.nby;
-  // Waves run until their slowest band is done (trip count = max K of the wave), so the
-  // host orders the blocks of every band by K: neighbouring lane slots get similar K.
-  const int32_t *perm = (!GAIN_ONLY && a.out.perm) ? a.out.perm + (size_t)f*a.rec_fstride + (size_t)band*nblk : nullptr;
-  if (lane < BPW) {
-    const long i = idx0 + lane;
-    Pb[lane] = i < a.blk_end ? (perm ? perm[i] : (int32_t)i) : -1;
-  }
-  __syncthreads();
-  const bool live = idx0 + inst < a.blk_end;
-  const long blk = live ? Pb[inst] : 0;
-  const long blk0 = idx0;
-  const int o0 = a.off[band];
-  const int q0 = a.q[band];
-  const double beta = a.beta[band];
-  const size_t rin = (size_t)band*nblk + (live ? blk : 0);
-  const size_t rec = (size_t)f*a.rec_fstride + rin;
-  const size_t rec2 = (size_t)f*2*a.rec_fstride + rin;
-  // Gather the band of the wave's BPW blocks.  Reading "lane = block" straight
-  // from the raster level plane costs one L1 transaction per lane (64 per load):
-  // the first profile showed the N = 15 kernel bound by exactly that rate.  So
-  // the wave loads cooperatively with lane = coefficient-within-block (lanes that
-  // share a block share its few 64-byte sectors), stages in LDS and every lane
-  // then picks up its own chunk.
-  constexpr int CH = NL + 1;                       // padded chunk stride in LDS
-  constexpr int LDSN = (G*CH) | 1;                 // odd per-band stride
+  const int nslot_here = (int)(a.blk_end - idx0 < BPW ? a.blk_end - idx0 : BPW);
   int32_t cf[NL];
   int qi[NL];
-  constexpr bool STAGE = N > PVQ_STAGE_MIN_N;
-  if (!STAGE) {
-    const long bsafe = live ? blk : 0;
-    const int bx = bsafe%a.nbx, by = bsafe/a.nbx;
-    const int32_t *src = a.lev + (size_t)f*a.lev_fstride + (size_t)(by*a.n)*a.w + bx*a.n;
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-      const int jj = g*NL + j;
-      if (live && jj < N) {
-        const int ro = a.tab[o0 + jj];
-        cf[j] = src[(size_t)(ro/a.n)*a.w + (ro%a.n)];
-        qi[j] = a.qm[o0 + jj];
-      }
-      else { cf[j] = 0; qi[j] = 0; }
-    }
-  }
-  else {
-    const int32_t *plane = a.lev + (size_t)f*a.lev_fstride;
-    const int nb_here = (int)(a.blk_end - blk0 < BPW ? a.blk_end - blk0 : BPW);
-    if (lane < nb_here) {                          // block origins: one division per block
-      const long bb = Pb[lane];
-      const int bx = bb%a.nbx, by = bb/a.nbx;
-      Org[lane] = (by*a.n)*a.w + bx*a.n;
-    }
-    __syncthreads();
-    const int lg = a.n == 4 ? 2 : a.n == 8 ? 3 : a.n == 16 ? 4 : 5;
-    for (int e = lane; e < nb_here*N; e += 64) {
-      const int b = e/N, jj = e%N;
-      const int ro = a.tab[o0 + jj];
-      Yst[b*LDSN + (jj/NL)*CH + jj%NL] = plane[(size_t)Org[b] + (ro >> lg)*a.w + (ro & (a.n - 1))];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-      const int jj = g*NL + j;
-      if (live && jj < N) {
-        cf[j] = Yst[inst*LDSN + g*CH + j];
-        qi[j] = a.qm[o0 + jj];
-      }
-      else { cf[j] = 0; qi[j] = 0; }
-    }
-    __syncthreads();
-  }
-  if (GAIN_ONLY) {
-    // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
-    const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
-      return cf[j]*(double)cf[j]*qi[j]*PVQ_QM_SCALE_1*qi[j]*PVQ_QM_SCALE_1;
-    });
-    if (live && g == 0) a.out.g[rec] = sqrt(acc);
-    return;
-  }
-#if PVQ_RSQ_LDS > 0
-  __shared__ double RsqL[PVQ_RSQ_LDS];
-  for (int e = lane; e < PVQ_RSQ_LDS; e += 64) RsqL[e] = aa.rsq[e];
-  __syncthreads();
-  const PvqRsq rsq{aa.rsq, RsqL};
+  bool live;
+  long blk;
+  double cg_unused;
+  // entries in raster order: "candidate 0" of block idx0 + lane
+  pvq_gather<N>(a, f, a.off[band], lane, g, inst, nslot_here,
+                [&]() { return idx0 + lane < a.blk_end ? (int32_t)(2*(idx0 + lane)) : -1; },
+                Pe, Yst, Org, live, blk, nullptr, cg_unused, cf, qi);
+  // od_pvq_compute_gain: five sequential multiplies per term (src/pvq.c:460-463)
+  const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
+    return cf[j]*(double)cf[j]*qi[j]*PVQ_QM_SCALE_1*qi[j]*PVQ_QM_SCALE_1;
+  });
+  if (live && g == 0) a.out.g[(size_t)f*a.out.fs_g + (size_t)band*nblk + blk] = sqrt(acc);
+}
+
+// The searches: one lane group per CANDIDATE (round 2: per band, its two gain candidates one
+// after the other).  The host's companding stage knows cg of every band, hence which
+// candidates exist and their K; it writes, per band, the work list a.out.perm of entries
+// 2*block + candidate ordered by descending K (counting sort; any order is correct).  Lane
+// slots of a wave then hold similar K - a wave runs until its slowest slot is done - the long
+// searches start first, and candidates that do not exist (K = 0: they only write their zero
+// records) gather at the tail.  No-reference candidates of pvq_theta (src/pvq_encoder.c:
+// 352-357, :452-481): gain i = max(1, floor(cg)) + candidate while i <= ceil(cg).
+// (Measured and dropped, tools/ab_libs.sh on MI355X: waves that walk several batches of the
+// list and load batch i + 1 while they search batch i - 0.160 -> 0.185 ms for N = 15, the
+// start-up loads are not what these waves wait for; a single-precision candidate scan in
+// front of the verification for G > 1 - no gain, the scans are bound by their dependent
+// compare -> select chain, not by double-precision issue.)
+#ifdef PVQ_STAMPS
+/* diagnostic build only (OD_HIP_PVQ_STAMPS=1, od_hip_pvq_stats): cycles of a wave's life per
+   phase, kept in registers and added to stats[8 + 8*class + phase] when the wave ends (class:
+   N = 15, 8, 32, 128); no output depends on them */
+#define PVQ_STAMP(ph) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  t_acc[ph] = t_ - t_prev; t_prev = t_; } while (0)
 #else
-  const PvqRsq rsq{aa.rsq, nullptr};
+#define PVQ_STAMP(ph) do { } while (0)
 #endif
-  const double cg = a.out.cg[rec];                 // companded on the host from out.g
-  PvqVec<N> v;
-  v.neg = 0;
+template <int N>
+__global__ __launch_bounds__(64, PVQ_V4_WAVES(N)) void k_pvq_cand(PvqLevelArgs3 aa) {
+  const PvqLevelArgs &a = aa.a;
+#ifdef PVQ_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long t_acc[5] = {0, 0, 0, 0, 0};
+#endif
+  constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
+  __shared__ int32_t Yst[BPW*(N + G + 2) + 1];      // >= BPW*N (output) and >= BPW*LDSN (staging)
+  __shared__ int32_t Org[64];
+  __shared__ int32_t Pe[64];                        // its work-list entry (2*block + candidate), -1: idle
+  // the head of the 1/sqrt table in LDS (one copy per workgroup): an RDO pulse reads NL
+  // entries per lane
+  __shared__ double RsqL[PVQ_RSQ_L(N)];
+  const int lane = threadIdx.x;
+  const int g = lane%G, inst = lane/G;
+  const long idx0 = 2*a.blk_first + (long)blockIdx.x*BPW;      // position in the band's work list
+  const long idx_end = 2*a.blk_end;
+  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
+  const long nblk = (long)a.nbx*a.nby;
+  const int32_t *list = a.out.perm ? a.out.perm + (size_t)f*a.out.fs_perm + (size_t)band*2*nblk : nullptr;
+  const int nslot_here = (int)(idx_end - idx0 < BPW ? idx_end - idx0 : BPW);
+  const int o0 = a.off[band];
+  const double beta = a.beta[band];
+  // the table head travels with the first round trip of the gather
+  constexpr int NQ = PVQ_RSQ_L(N)/64;
+  double rq[NQ];
 #pragma unroll
-  for (int j = 0; j < NL; j++) {
-    const int pr = cf[j]*qi[j];                    // the reference's int*int product (:455)
-    v.x[j] = fabs(pr*PVQ_QM_SCALE_1);
-    v.neg |= (uint32_t)(pr < 0) << j;
+  for (int q = 0; q < NQ; q++) rq[q] = aa.rsq[lane + 64*q];
+  PvqVec<N> v;
+  bool live;
+  long blk;
+  double cg;                                       // companded on the host from out.g
+  {
+    int32_t cf[NL];
+    int qi[NL];
+    pvq_gather<N>(a, f, o0, lane, g, inst, nslot_here,
+                  [&]() {
+                    const long i = idx0 + lane;
+                    int32_t e = (lane < BPW && i < idx_end) ? (list ? list[i] : (int32_t)i) : -1;
+                    if (e < 0 || (e >> 1) >= nblk) e = -1;   // a list that was never written: idle slot
+                    return e;
+                  },
+                  Pe, Yst, Org, live, blk, a.out.cg + (size_t)f*a.out.fs_cg + (size_t)band*nblk, cg, cf, qi);
+    v.neg = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int pr = cf[j]*qi[j];                  // the reference's int*int product (:455)
+      v.x[j] = fabs(pr*PVQ_QM_SCALE_1);
+      v.neg |= (uint32_t)(pr < 0) << j;
+    }
   }
+#pragma unroll
+  for (int q = 0; q < NQ; q++) RsqL[lane + 64*q] = rq[q];
+  pvq_wave_lds_sync();
+  PVQ_STAMP(1);                                    // gather
+  const int c = live ? Pe[inst] & 1 : 0;
+  const size_t rin = (size_t)band*nblk + blk;       // record of the band
+  const size_t rin2 = (size_t)c*a.nbands*nblk + rin;   // record of the candidate
   pvq_vec_finish<N>(v, g, lane);
   int i0 = (int)floor(cg);
   if (i0 < 1) i0 = 1;
-  const int i1 = live ? (int)ceil(cg) : 0;
-  int nc = 0;
-  for (int c = 0; c < 2; c++) {
-    const int gi = i0 + c;
-    const bool has = live && gi <= i1;
-    const double qcg = gi;
-    const int k = has ? pvq_k_noref(qcg, N, beta) : 0;
-    int y[NL];
-    int npg = 0, npr = 0;
-    const double cd = pvq_search_v3<N>(v, g, lane, k, qcg*cg, rsq, y, npg, npr);
-    if (aa.stats && has && g == 0) {
-      atomicAdd(&aa.stats[0], (unsigned long long)npg*N);
-      atomicAdd(&aa.stats[1], (unsigned long long)npr*N);
-      atomicAdd(&aa.stats[2], 1ull);
-    }
-    if (live && g == 0) {
-      a.out.qg[c*a.rec_fstride + rec2] = has ? gi : 0;
-      a.out.k[c*a.rec_fstride + rec2] = k;
-      a.out.cos_dist[c*a.rec_fstride + rec2] = has ? cd : 0;
-      a.out.dist[c*a.rec_fstride + rec2] =
-          has ? 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd) : 0;
-    }
-    nc += has;
-    // signed pulses -> LDS -> coalesced [cand][block][N] store
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-      const int jj = g*NL + j;
-      if (jj < N) Yst[inst*N + jj] = has ? (((v.neg >> j) & 1) ? -y[j] : y[j]) : 0;
-    }
-    __syncthreads();
-    {
-      // [cand][block][N]: every block's N pulses are one contiguous run (whole runs of
-      // neighbouring blocks when the order is the raster order)
-      int32_t *yo = a.out.y + (size_t)f*a.y_fstride + (size_t)2*nblk*(o0 - 1) + (size_t)c*nblk*N;
-      const long lim = (a.blk_end - blk0 < BPW ? a.blk_end - blk0 : BPW)*N;
-      for (int e = lane; e < lim; e += 64) {
-        const int b = e/N;
-        yo[(size_t)Pb[b]*N + (e - b*N)] = Yst[e];
-      }
-    }
-    __syncthreads();
+  const int i1 = (int)ceil(cg);
+  const int gi = i0 + c;
+  const bool has = live && gi <= i1;
+  const double qcg = gi;
+  const int k = has ? pvq_k_noref(qcg, N, beta) : 0;
+  int y[NL];
+  int npg = 0, npr = 0;
+  PVQ_STAMP(2);                                    // norms + companded gain
+  const double cd = pvq_search_v4<N>(v, g, lane, k, qcg*cg, aa.rsq, RsqL, y, npg, npr);
+  PVQ_STAMP(3);                                    // the search
+#ifndef PVQ_STAMPS               /* the diagnostic build times the phases without this traffic */
+  if (aa.stats && has && g == 0) {
+    atomicAdd(&aa.stats[0], (unsigned long long)npg*N);
+    atomicAdd(&aa.stats[1], (unsigned long long)npr*N);
+    atomicAdd(&aa.stats[2], 1ull);
   }
-  if (live && g == 0) a.out.ncand[rec] = nc;
-  (void)q0;
-  (void)beta;
+#endif
+  if (live && g == 0) {
+    a.out.qg[(size_t)f*a.out.fs_qg + rin2] = has ? gi : 0;
+    a.out.k[(size_t)f*a.out.fs_k + rin2] = k;
+    a.out.cos_dist[(size_t)f*a.out.fs_cd + rin2] = has ? cd : 0;
+    a.out.dist[(size_t)f*a.out.fs_dist + rin2] = has ? 1.4*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cd) : 0;
+    if (c == 0) a.out.ncand[(size_t)f*a.out.fs_nc + rin] = (i0 <= i1) + (i0 + 1 <= i1);
+  }
+  // signed pulses -> LDS (int16 pairs) -> coalesced [cand][block][NS] store, one dword = two
+  // pulses: every candidate's run is contiguous and 4-byte aligned
+  constexpr int NS = (N + 1) & ~1, NW = NS/2;
+  int16_t *Y16 = reinterpret_cast<int16_t *>(Yst);
+#pragma unroll
+  for (int j = 0; j < NL; j++) Y16[inst*NS + g*NL + j] = (int16_t)(has ? (((v.neg >> j) & 1) ? -y[j] : y[j]) : 0);
+  if (NS != N && g == G - 1) Y16[inst*NS + N] = 0;
+  pvq_wave_lds_sync();
+  {
+    const int yo_band = o0 == 1 ? 0 : o0;
+    uint32_t *yo = reinterpret_cast<uint32_t *>(a.out.y + (size_t)f*a.out.fs_y + (size_t)2*nblk*yo_band);
+    const uint32_t *Yw = reinterpret_cast<const uint32_t *>(Yst);
+    const int lim = nslot_here*NW;
+#pragma unroll
+    for (int it = 0; it < (BPW*NW + 63)/64; it++) {
+      const int e = lane + 64*it;
+      const int b = e/NW;
+      const int32_t en = e < lim ? Pe[b] : -1;
+      if (en >= 0) yo[((size_t)(en & 1)*nblk + (en >> 1))*NW + (e - b*NW)] = Yw[e];
+    }
+  }
+  PVQ_STAMP(4);                                    // records + pulses issued
+#ifdef PVQ_STAMPS
+  if (aa.stats && threadIdx.x == 0 && (blockIdx.x & 63) == 0) {      // one wave in 64: no hot-address traffic
+    unsigned long long *st = aa.stats + 8 + 8*(N == 15 ? 0 : N == 8 ? 1 : N == 32 ? 2 : 3);
+    for (int q = 0; q < 5; q++) atomicAdd(&st[q], t_acc[q]);
+    atomicAdd(&st[7], 1ull);
+  }
+#endif
 }

@@ -83,7 +83,8 @@ typedef struct dec_tls {
   long md_check_fail;
   long idct_skipped;
   long haar_skipped;
-  int failed;
+  int failed;               /* a device stage of the current packet / frame failed: surfaced as an error code */
+  int haar_frame;           /* the frame being decoded uses the Haar wavelet with a quantizer > 0: host path */
   int check;
   double t_device;
 } dec_tls;
@@ -119,16 +120,48 @@ void od_hipdec_mc_stats(long out[2]) {
    in dtmp and goes through idct_2d (:637).  B frames are left to the reference.  Frame type
    and quantizers are known before the first block is parsed (src/decode.c:1195, :989-993). */
 static int on_device(void) {
-  return D.ctx != NULL && D.dec != NULL
+  return D.ctx != NULL && D.dec != NULL && !D.haar_frame && !D.failed
    && (D.dec->state.frame_type == OD_I_FRAME || D.dec->state.frame_type == OD_P_FRAME)
    && D.dec->state.quantizer[0] > 0;
+}
+
+void od_ref_plane_to_coeff_cpu(od_state *state, od_coeff *dst, int lossless_p, od_img *src,
+ int pli);
+
+/* The Haar-wavelet flag of a frame is a decoded bit (src/decode.c:1206) that the quantizer
+   says nothing about: a stream may carry Haar frames with a quantizer > 0 (the reference's
+   encoder writes them when built with OD_USE_HAAR_WAVELET).  Such a frame never reaches the
+   DCT hooks; the decoder's first od_haar / od_haar_inv call reveals it before anything of
+   the frame's pixel stage has been skipped, and the frame then takes the reference's host
+   path entirely.  On a P frame the prediction's coefficient planes were going to come from
+   the device pyramid (od_ref_plane_to_coeff skipped): they are rebuilt here, without the
+   lapping filter a Haar frame does not apply (src/decode.c:1004). */
+static void haar_frame_seen(void) {
+  od_state *st;
+  int pli;
+  if (D.dec == NULL || D.ctx == NULL || D.haar_frame || D.dec->state.quantizer[0] == 0) return;
+  D.haar_frame = 1;
+  st = &D.dec->state;
+  if (D.md_valid && !D.check) {
+    od_img *rec;
+    rec = st->ref_imgs + st->ref_imgi[OD_FRAME_SELF];
+    for (pli = 0; pli < st->info.nplanes; pli++) {
+      od_ref_plane_to_coeff_cpu(st, st->mctmp[pli], st->quantizer[pli] == 0, rec, pli);
+    }
+  }
+  D.md_valid = 0;
+}
+
+/* called by the od_haar binding (hip_enc_glue.c) */
+void od_hipdec_haar_notify(void) {
+  haar_frame_seen();
 }
 
 /* Lossless keyframes (quantizer 0: Haar wavelet of every whole superblock instead of
    lapping + DCT, src/decode.c:785, :1036): od_haar_inv per superblock (:621) and the shift-0
    od_coeff_to_ref_plane are one od_hip_inverse_haar pass per frame. */
 static int on_device_lossless(void) {
-  return D.ctx != NULL && D.dec != NULL && D.dec->state.frame_type == OD_I_FRAME
+  return D.ctx != NULL && D.dec != NULL && !D.failed && D.dec->state.frame_type == OD_I_FRAME
    && D.dec->state.quantizer[0] == 0 && D.dec->state.quantizer[1] == 0
    && D.dec->state.quantizer[2] == 0 && D.dec->state.info.nplanes == 3;
 }
@@ -139,6 +172,7 @@ void od_haar_inv(od_coeff *x, int xstride, const od_coeff *y, int ystride, int l
     D.haar_skipped++;
     return;
   }
+  haar_frame_seen();
   od_haar_inv_cpu(x, xstride, y, ystride, ln);
 }
 
@@ -165,8 +199,6 @@ static int md_served(void) {
   return D.md_valid && !D.check && D.dec != NULL && D.dec->state.quantizer[0] > 0;
 }
 
-void od_ref_plane_to_coeff_cpu(od_state *state, od_coeff *dst, int lossless_p, od_img *src,
- int pli);
 void od_ref_plane_to_coeff(od_state *state, od_coeff *dst, int lossless_p, od_img *src,
  int pli) {
   if (md_served() && state == &D.dec->state && pli >= 0 && pli < 3 && dst == state->mctmp[pli]) return;
@@ -319,6 +351,8 @@ void od_smooth_recursive(od_coeff *c, unsigned char *bsize, int bstride, int bx,
    quantizer, pli);
 }
 
+static int injected_failure(void);
+
 static int device_frame(od_state *state) {
   const unsigned char *bskip[3];
   int32_t thr[3];
@@ -326,6 +360,7 @@ static int device_frame(od_state *state) {
   int pli;
   int nplanes;
   double t0;
+  if (injected_failure()) return -9;
   t0 = now_s();
   nplanes = state->info.nplanes;
   if (od_hip_set_bsize(D.ctx, 0, state->bsize, state->bstride) != 0) return -1;
@@ -382,14 +417,24 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
   int w;
   int h;
   int y;
+  if (D.failed && D.dec != NULL && state == &D.dec->state) {
+    od_coeff_to_ref_plane_cpu(state, dst, pli, src, lossless_p);
+    return;
+  }
   if (lossless_p && on_device_lossless()) {
     if (pli == 0) {
       if (D.haar_skipped == 0 || device_frame_lossless(state) != 0) {
-        fprintf(stderr, "hip_dec_glue: device lossless decode failed: %s\n", od_hip_last_error());
+        /* The inverse transforms of this frame were skipped for the device pass that has now
+           failed: there is no picture.  The frame is reported as failed (daala_decode_packet_in
+           returns OD_EFAULT, see the binding below); the plane is written from what is there so
+           that no caller reads uninitialised memory. */
         D.failed = 1;
-        abort();
       }
       D.haar_skipped = 0;
+    }
+    if (D.failed) {
+      od_coeff_to_ref_plane_cpu(state, dst, pli, src, lossless_p);
+      return;
     }
     ip = dst->planes + pli;
     w = state->frame_width >> ip->xdec;
@@ -405,13 +450,17 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
   }
   if (pli == 0) {
     if (D.idct_skipped == 0 || device_frame(state) != 0) {
-      /* A frame that never reached the DCT path (Haar) or a device failure: there
-         is no C fallback for a half-skipped frame, fail loudly. */
-      fprintf(stderr, "hip_dec_glue: device decode failed: %s\n", od_hip_last_error());
+      /* The device pass for a frame whose inverse transforms were skipped has failed (or,
+         idct_skipped == 0, a frame reached this point without a single block: malformed).
+         No picture exists: the frame is reported as failed - daala_decode_packet_in returns
+         OD_EFAULT - and the plane is written from what is there. */
       D.failed = 1;
-      abort();
     }
     D.idct_skipped = 0;
+  }
+  if (D.failed) {
+    od_coeff_to_ref_plane_cpu(state, dst, pli, src, lossless_p);
+    return;
   }
   ip = dst->planes + pli;
   w = state->frame_width >> ip->xdec;
@@ -419,6 +468,48 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
   for (y = 0; y < h; y++) {
     memcpy(ip->data + (size_t)y*ip->ystride, D.rec[pli] + (size_t)y*w, w);
   }
+}
+
+/* daala_decode_packet_in (src/decode.c:1159), the decoder's entry point, keeps its signature
+   and its error contract: the build renames the reference's definition to *_cpu and this
+   binding runs it.  On a thread that decodes through the device a failed device stage -
+   prediction, prediction pyramid, pixel-domain tail - makes the call return OD_EFAULT
+   instead of a picture that was not computed; nothing in the library aborts. */
+int daala_decode_packet_in_cpu(daala_dec_ctx *dec, const daala_packet *op);
+int daala_decode_packet_in(daala_dec_ctx *dec, const daala_packet *op) {
+  int rc;
+  if (D.ctx == NULL || dec == NULL) return daala_decode_packet_in_cpu(dec, op);
+  D.dec = (od_dec_ctx *)dec;
+  D.md_valid = 0;
+  D.haar_frame = 0;
+  D.failed = 0;
+  D.idct_skipped = 0;
+  D.haar_skipped = 0;
+  rc = daala_decode_packet_in_cpu(dec, op);
+  D.dec = NULL;
+  D.md_valid = 0;
+  if (rc >= 0 && D.failed) rc = OD_EFAULT;
+  return rc;
+}
+
+/* Encoder threads: od_state_mc_predict below serves them too.  Returns and clears this
+   thread's failure flag (hip_enc_glue.c fails the frame). */
+int od_hipdec_take_failure(void) {
+  int f;
+  f = D.failed;
+  D.failed = 0;
+  return f;
+}
+
+/* Test hook: the next device pass of this process's decoder threads fails as if the
+   runtime had returned an error (n > 0: the n-th from now). */
+static int g_fail_after;
+void od_hipdec_test_fail_after(int n) {
+  g_fail_after = n;
+}
+static int injected_failure(void) {
+  if (g_fail_after > 0 && __sync_sub_and_fetch(&g_fail_after, 1) == 0) return 1;
+  return 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -571,11 +662,7 @@ static void *dworker(void *arg) {
     memset(&dp, 0, sizeof(dp));
     dp.packet = (unsigned char *)J->pkt[f];
     dp.bytes = J->pkt_len[f];
-    D.dec = (od_dec_ctx *)dec;
-    D.md_valid = 0;
     rc = daala_decode_packet_in(dec, &dp);
-    D.dec = NULL;
-    D.md_valid = 0;
     if (rc >= 0) {
       /* This frame's picture (od_img_copy into output_img, src/decode.c:1268).
          daala_decode_img_out is called once per packet, as the reference's player
@@ -773,11 +860,12 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
 
 void od_state_mc_predict(od_state *state, od_img *img_dst) {
   if ((D.ctx != NULL || od_hipenc_device_thread()) && !D.failed) {
-    if (mc_predict_device(state, img_dst) == 0) {
+    if (!injected_failure() && mc_predict_device(state, img_dst) == 0) {
       mc_dev_frames++;
       if (D.ctx != NULL && D.dec != NULL && state == &D.dec->state
        && state->info.nplanes == 3 && state->frame_type == OD_P_FRAME) {
         D.md_valid = md_pyramid(state, img_dst) == 0;
+        if (!D.md_valid) D.failed = 1;      /* surfaced by daala_decode_packet_in, no silent host path */
       }
       if (D.check || od_hipenc_check_mode()) {
         /* OD_CHECKASM: the reference's own prediction of the same frame; its result stays */
@@ -808,7 +896,10 @@ void od_state_mc_predict(od_state *state, od_img *img_dst) {
       }
       return;
     }
-    D.failed = 1;          /* reported by the driver: no silent C path */
+    /* the frame fails: daala_decode_packet_in returns OD_EFAULT on decoder threads,
+       encode_frame (hip_enc_glue.c) fails the job on encoder threads; the reference's
+       prediction below only keeps the memory defined */
+    D.failed = 1;
   }
   od_state_mc_predict_cpu(state, img_dst);
 }

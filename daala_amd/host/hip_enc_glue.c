@@ -339,8 +339,12 @@ void od_encode_rollback(daala_enc_ctx *enc, const od_rollback_buffer *rbuf) {
    that transforms a whole superblock of the current frame into its dtmp position is a
    block copy.  The build renames the reference's definition to od_haar_cpu. */
 void od_haar_cpu(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln);
+void od_hipdec_haar_notify(void);        /* hip_dec_glue.c */
+int od_hipdec_take_failure(void);
 
 void od_haar(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln) {
+  /* decoder threads: a Haar frame with a quantizer > 0 takes the host path (hip_dec_glue.c) */
+  if (T.enc == NULL) od_hipdec_haar_notify();
   if (T.haar[0] != NULL && T.enc != NULL && T.enc->state.frame_type == OD_I_FRAME) {
     const od_state *st;
     int pli;
@@ -629,8 +633,11 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   T.dist_valid = 0;
   T.dist_sb = -1;
   od_hipenc_mc_cache_flush();          /* reference frames change between frames */
+  (void)od_hipdec_take_failure();
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
   if (T.dr_error) return -4;
+  /* od_state_mc_predict's device pass (hip_dec_glue.c) failed for this frame */
+  if (od_hipdec_take_failure()) return -5;
   J->pkt_len[f] = 0;
   while (daala_encode_packet_out(enc, 0, &dp) > 0) {
     unsigned char *q;
@@ -680,6 +687,31 @@ static void pin_worker(int idx) {
   }
 }
 
+/* One reference encoder context with the worker's vtable entries installed. */
+static daala_enc_ctx *worker_encoder(const od_hipenc *S) {
+  static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
+   hook_fdct32};
+  static const od_dct_func_2d vfdct[OD_NBSIZES] = {od_hipenc_fdct4x4, od_hipenc_fdct8x8,
+   od_hipenc_fdct16x16, od_hipenc_fdct32x32};
+  static const od_dct_func_2d vidct[OD_NBSIZES] = {od_hipenc_idct4x4, od_hipenc_idct8x8,
+   od_hipenc_idct16x16, od_hipenc_idct32x32};
+  daala_enc_ctx *enc;
+  int i;
+  enc = make_encoder(&S->p, S->p.pic_width, S->p.pic_height);
+  if (enc == NULL) return NULL;
+  for (i = 0; i < OD_NBSIZES; i++) {
+    /* the transforms that stay on the host run on its vector unit (hip_dct_host.c); check
+       mode keeps the reference's C functions: they are the checker there */
+    T.fdct_cpu[i] = T.check ? enc->state.opt_vtbl.fdct_2d[i] : vfdct[i];
+    enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
+    if (!T.check) enc->state.opt_vtbl.idct_2d[i] = vidct[i];
+  }
+  /* the motion search's per-block leaves (hip_mc_host.c) */
+  enc->state.opt_vtbl.mc_blend_full = od_hipenc_mc_blend_full8;
+  enc->state.opt_vtbl.mc_predict1fmv = od_hipenc_mc_predict1fmv8;
+  return enc;
+}
+
 static void *worker(void *arg) {
   od_hipenc *S;
   daala_enc_ctx *enc;
@@ -693,26 +725,7 @@ static void *worker(void *arg) {
   T.time_cpu = S->time_cpu;
   T.host_pvq = S->host_pvq;
   T.sample_every = S->sample_every;
-  enc = make_encoder(&S->p, S->p.pic_width, S->p.pic_height);
-  if (enc != NULL) {
-    static const od_dct_func_2d hooks[OD_NBSIZES] = {hook_fdct4, hook_fdct8, hook_fdct16,
-     hook_fdct32};
-    int i;
-    static const od_dct_func_2d vfdct[OD_NBSIZES] = {od_hipenc_fdct4x4, od_hipenc_fdct8x8,
-     od_hipenc_fdct16x16, od_hipenc_fdct32x32};
-    static const od_dct_func_2d vidct[OD_NBSIZES] = {od_hipenc_idct4x4, od_hipenc_idct8x8,
-     od_hipenc_idct16x16, od_hipenc_idct32x32};
-    for (i = 0; i < OD_NBSIZES; i++) {
-      /* the transforms that stay on the host run on its vector unit (hip_dct_host.c); check
-         mode keeps the reference's C functions: they are the checker there */
-      T.fdct_cpu[i] = T.check ? enc->state.opt_vtbl.fdct_2d[i] : vfdct[i];
-      enc->state.opt_vtbl.fdct_2d[i] = hooks[i];
-      if (!T.check) enc->state.opt_vtbl.idct_2d[i] = vidct[i];
-    }
-    /* the motion search's per-block leaves (hip_mc_host.c) */
-    enc->state.opt_vtbl.mc_blend_full = od_hipenc_mc_blend_full8;
-    enc->state.opt_vtbl.mc_predict1fmv = od_hipenc_mc_predict1fmv8;
-  }
+  enc = worker_encoder(S);
   if (enc != NULL && S->ctx != NULL) {
     int xdec[3] = {0, 1, 1};
     int pli;
@@ -746,8 +759,25 @@ static void *worker(void *arg) {
     while (!S->quit && (S->J == NULL || S->job_seq == seen_seq)) pthread_cond_wait(&S->cv, &S->mu);
     if (S->quit) break;
     J = S->J;
+    /* One stream per call (hip_enc_glue.h).  With inter frames the encoder context carries
+       the GOP position and the reference frames of the stream it coded last: a new job gets
+       a fresh context, so its first frame is a keyframe and nothing refers to another
+       stream.  Keyframe-only sessions keep theirs (encode_frame sets the only history a
+       keyframe packet carries). */
+    if (S->p.keyframe_rate > 1 && seen_seq != 0 && enc != NULL) {
+      daala_enc_ctx *fresh;
+      pthread_mutex_unlock(&S->mu);
+      fresh = worker_encoder(S);
+      pthread_mutex_lock(&S->mu);
+      if (fresh != NULL) {
+        daala_encode_free(enc);
+        enc = fresh;
+      }
+      else J->failed = 1;
+    }
     seen_seq = S->job_seq;
     memset(&T.st, 0, sizeof(T.st));
+    T.dr_error = 0;            /* a failed device pass fails ITS job, not every later one */
     for (;;) {
       int f;
       if (J->failed || S->setup_failed) break;

@@ -343,6 +343,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
   double x[MAXN];
   double r[MAXN];
   od_coeff y_tmp[MAXN];
+  od_coeff feed_y[2][MAXN];       /* the feed's 16-bit pulses of the two candidates, widened */
   const od_coeff *y_best;
   int i;
   int k;
@@ -545,7 +546,7 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
       for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++) nc++;
       from_feed = nc == L->ncand[rec] && nc <= 2;
       for (c = 0; from_feed && c < nc; c++) {
-        const od_coeff *yc;
+        const int16_t *yc;
         double cd;
         int sum;
         int j;
@@ -553,8 +554,9 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
         if (L->qg[c*nrec + rec] != i
          || L->k[c*nrec + rec] != od_pvq_compute_k(i, -1, -1, 1, n, beta, robust || is_keyframe)) from_feed = 0;
         /* a codeword of the search has exactly K pulses and a cosine in [0, 1]: cheap
-           integrity checks of the two fields that are taken on trust */
-        yc = L->y + (size_t)2*L->nblk*(L->off[band] - 1) + ((size_t)c*L->nblk + blk)*n;
+           integrity checks of the two fields that are taken on trust.  16-bit pulses, band b
+           at 2*nblk*yo[b] in runs of ns[b] (include/daala_hip.h section 4b). */
+        yc = L->y + (size_t)2*L->nblk*(band == 0 ? 0 : L->off[band]) + ((size_t)c*L->nblk + blk)*((n + 1) & ~1);
         sum = 0;
         for (j = 0; j < n; j++) sum += abs(yc[j]);
         cd = L->cos_dist[c*nrec + rec];
@@ -563,18 +565,22 @@ static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, 
       if (!from_feed) T.st.lost_sync++;
     }
     if (from_feed) {
-      const od_coeff *yb;
-      yb = L->y + (size_t)2*L->nblk*(L->off[band] - 1) + (size_t)blk*n;
+      const int16_t *yb;
+      int ns;
+      ns = (n + 1) & ~1;
+      yb = L->y + (size_t)2*L->nblk*(band == 0 ? 0 : L->off[band]) + (size_t)blk*ns;
       c = 0;
       for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++, c++) {
         double cos_dist;
         double cost;
         double qcg;
-        const od_coeff *yc;
+        od_coeff *yc;
+        int j;
         qcg = i;
         k = L->k[c*nrec + rec];
         cos_dist = L->cos_dist[c*nrec + rec];
-        yc = yb + (size_t)c*L->nblk*n;
+        yc = feed_y[c];
+        for (j = 0; j < n; j++) yc[j] = yb[(size_t)c*L->nblk*ns + j];
         if (T.check || (T.sample_every > 0 && ++T.sample_ctr >= T.sample_every)) {
           /* OD_CHECKASM for the candidate: always in check mode, and on every
              sample_every-th candidate otherwise (the sampled re-search that keeps a silently

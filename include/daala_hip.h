@@ -208,8 +208,7 @@ int od_hip_download_recon(od_hip_ctx *ctx, int slot, int pli, unsigned char *dst
  *    q[band]: per-band quantiser max(1, q0*pvq_qm_q4[idx] >> 4)
  *    (src/pvq_encoder.c:712); beta[band] from OD_PVQ_BETA (src/pvq.c:230).
  *    Output record layout: od_hip_pvq_band (one per block per band, blocks in
- *    raster order of the level), pulses y: [record][cand][n_band] int32 packed
- *    per band (see od_hip_pvq_layout). */
+ *    raster order of the level), pulses y as documented at od_hip_pvq_download. */
 typedef struct od_hip_pvq_band {
   double cg;          /* companded gain of the input, cg in pvq_theta */
   double g;           /* raw gain */
@@ -281,8 +280,13 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
  *      record r = band*nblk + block (blocks in raster order of the level)
  *      cg[r], ncand[r], qg[c*nrec + r], k[c*nrec + r], cos_dist[c*nrec + r]
  *                                                          c = candidate 0/1
- *      y of band b: y + 2*nblk*(off[b]-1) + (c*nblk + block)*(off[b+1]-off[b])
- *    level l holds the (32 >> l)-sized luma blocks. */
+ *      y of band b, 16-bit (|y| <= K <= 738):
+ *           y + 2*nblk*yo[b] + (c*nblk + block)*ns[b]
+ *           ns[b] = the band's size rounded up to even (one pad entry after the 15 pulses of
+ *           band 0), yo[0] = 0, yo[b] = off[b] for b >= 1
+ *    level l holds the (32 >> l)-sized luma blocks.  Per frame slot the device hands over ONE
+ *    block of records + pulses, one of gains and one of the four level planes (three
+ *    transfers), and takes one block of companded gains + search work lists. */
 typedef struct od_hip_enc_feed od_hip_enc_feed;
 
 typedef struct od_hip_feed_level {
@@ -298,7 +302,7 @@ typedef struct od_hip_feed_level {
   const int32_t *qg;        /* [2][nbands*nblk] gain index i; the search's g2 = qg*cg */
   const int32_t *k;         /* [2][nbands*nblk] */
   const double *cos_dist;   /* [2][nbands*nblk] return value of the search */
-  const int32_t *y;         /* pulses, see above */
+  const int16_t *y;         /* pulses, see above */
   /* The level's plane of the forward pyramid itself (od_hip_forward_pyramid): the fDCT of
      every n x n block of the lapped picture, i.e. what fdct_2d produces at
      src/encode.c:1139 (block-size RDO pass) and :1308 (od_compute_dcts) for luma.

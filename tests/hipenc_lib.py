@@ -10,6 +10,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from daala_amd.hipenc import *          # noqa: F401,F403
 from daala_amd.hipenc import FeedLevel, level_params, p32, p16, pu8, pf64, I32P
+
+
+def pulse_layout(off, nb):
+    """(yo, ns) of every band in the feed's 16-bit pulse array (include/daala_hip.h 4b)."""
+    return [0 if b == 0 else off[b] for b in range(nb)], [(off[b + 1] - off[b] + 1) & ~1 for b in range(nb)]
+
 from testlib import oracle
 
 
@@ -48,7 +54,16 @@ class OracleFeed:
             for i, x in enumerate(off):
                 v.off[i] = x
             v.cg, v.g, v.ncand, v.qg, v.k = pf64(a['cg']), pf64(a['g']), p32(a['ncand']), p32(a['qg']), p32(a['k'])
-            v.cos_dist, v.y = pf64(a['cos_dist']), p32(a['y'])
+            # the oracle writes 32-bit pulses, band b at 2*nblk*(off[b] - 1), runs of n_b; the feed
+            # carries 16-bit pulses, band b at 2*nblk*yo[b], runs of ns[b] (padded to even)
+            yo, ns = pulse_layout(off, nb)
+            y16 = np.zeros(2*nblk*ncoded, np.int16)
+            for b in range(nb):
+                nn = off[b + 1] - off[b]
+                src = a['y'][2*nblk*(off[b] - 1): 2*nblk*(off[b] - 1) + 2*nblk*nn].reshape(2*nblk, nn)
+                y16[2*nblk*yo[b]: 2*nblk*yo[b] + 2*nblk*ns[b]].reshape(2*nblk, ns[b])[:, :nn] = src
+            a['y'] = y16
+            v.cos_dist, v.y = pf64(a['cos_dist']), a['y'].ctypes.data_as(ctypes.POINTER(ctypes.c_int16))
             v.lev, v.lev_stride = p32(lev[l]), fw
             a['lev'] = lev[l]
             self.levels.append(v)

@@ -62,8 +62,8 @@ def test_device_feed_equals_oracle_feed(masking):
                                   g['cos_dist'][c*nrec:(c + 1)*nrec][live].view(np.int64))
         # pulses of live candidates
         for bnd in range(g['nbands']):
-            nn = g['off'][bnd + 1] - g['off'][bnd]
-            base = 2*g['nblk']*(g['off'][bnd] - 1)
+            nn = (g['off'][bnd + 1] - g['off'][bnd] + 1) & ~1          # runs padded to even
+            base = 2*g['nblk']*(0 if bnd == 0 else g['off'][bnd])
             for c in range(2):
                 live = a['ncand'][bnd*g['nblk']:(bnd + 1)*g['nblk']] > c
                 ya = a['y'][base + c*g['nblk']*nn: base + (c + 1)*g['nblk']*nn].reshape(-1, nn)
