@@ -80,7 +80,7 @@ def host_cpu_budget():
     return n
 
 
-def reference_packets(frames, nframes):
+def reference_packets(frames, nframes, masking=1):
     """The first `nframes` packets of the pure reference encoder (oracle/_ref/enc_probe.so,
     gcc -std=c89 -O2, one thread) and its speed: the CPU baseline of record and the
     bit-exactness pin."""
@@ -95,7 +95,7 @@ def reference_packets(frames, nframes):
     fnv = ctypes.c_uint()
     sec = ctypes.c_double()
     U8P = ctypes.POINTER(ctypes.c_uint8)
-    nbytes = lib.probe_encode_frames(PIC_W, PIC_H, nframes, 20, 7, 1, 1, buf.ctypes.data_as(U8P),
+    nbytes = lib.probe_encode_frames(PIC_W, PIC_H, nframes, 20, 7, masking, 1, buf.ctypes.data_as(U8P),
                                      ctypes.byref(fnv), ctypes.byref(sec),
                                      out.ctypes.data_as(U8P), out.size)
     if nbytes <= 0:
@@ -229,21 +229,28 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
         'k_forward_pyramid_chroma': FRAMES*s_c*13,
         'k_forward_known_luma': FRAMES*s_y*5,
         'k_forward_known_chroma': FRAMES*s_c*5,
-        'k_inverse_sb_luma': FRAMES*s_y*5,          # inverse+postfilter+clamp is 5 B/sample
-        'k_inverse_sb_chroma': FRAMES*s_c*5,        #   in total; split over two kernels here
-        'k_inverse_strips_luma': FRAMES*s_y*5,
-        'k_inverse_strips_chroma': FRAMES*s_c*5,
     }
+    # inverse + post-filter + clamp is 5 B/sample for the PAIR of kernels that does it (tile
+    # kernel + strip kernel): the pair is reported, not a share of the bytes per kernel
+    pair_bytes = {'k_inverse_pair_luma': (FRAMES*s_y*5, ('k_inverse_sb_luma', 'k_inverse_strips_luma')),
+                  'k_inverse_pair_chroma': (FRAMES*s_c*5, ('k_inverse_sb_chroma', 'k_inverse_strips_chroma'))}
     kernels = {}
     pvq_names = ['k_pvq_noref<15>', 'k_pvq_noref<8>', 'k_pvq_noref<32>', 'k_pvq_noref<128>']
     gain_names = ['k_pvq_gain<15>', 'k_pvq_gain<8>', 'k_pvq_gain<32>', 'k_pvq_gain<128>']
     pvq_phase = ctx.timing_get('pvq_phase')
-    for name in list(alg_bytes) + pvq_names + gain_names:
+    inv_names = [k for _, ks in pair_bytes.values() for k in ks]
+    for name in list(alg_bytes) + inv_names + pvq_names + gain_names:
         n, ms = ctx.timing_get(name)
         if n:
             kernels[name] = {'launches': n, 'avg_ms': ms/n}
             if name in alg_bytes:
                 kernels[name]['GBps'] = alg_bytes[name]/(ms/n*1e-3)/1e9
+    for pname, (nbytes, parts) in pair_bytes.items():
+        if all(k in kernels for k in parts):
+            t = sum(kernels[k]['avg_ms'] for k in parts)
+            kernels[pname] = {'launches': kernels[parts[0]]['launches'], 'avg_ms': t,
+                              'GBps': nbytes/(t*1e-3)/1e9, 'kernels': list(parts)}
+    alg_bytes.update({k: v[0] for k, v in pair_bytes.items()})
     out = {'Mpixels_per_s': round(FRAMES*PIC_W*PIC_H*steps/elapsed/1e6, 1),
            'ms_per_step': round(elapsed/steps*1e3, 3), 'steps': steps,
            'host_compand_stage_s_once': round(compand_s, 4),
@@ -251,7 +258,18 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
                    'pass + no-ref search pass of every band, forward known, inverse (no PCIe; the '
                    'host libm companding stage between the two PVQ passes is run once, '
                    'single-threaded, before the timed steps and reported beside them)'}
-    hb = {k: v for k, v in kernels.items() if k in alg_bytes}
+    # where the step's wall time goes: kernel spans (HIP events; the PVQ searches overlap on
+    # side streams, so their phase span counts, not their sum) and what is left - launch gaps:
+    # a step is ~110 launches issued from Python through ctypes, each bracketed by two event
+    # records while timing is on; on a host that is busy (the driver runs this section right
+    # after the 30-worker end-to-end part) the gaps grow, the kernel averages do not
+    span_ms = sum(v['avg_ms']*v['launches'] for k, v in kernels.items()
+                  if k not in pvq_names and k not in pair_bytes)/steps
+    nph, ph_ms = pvq_phase
+    span_ms += (ph_ms/steps) if nph else sum(kernels[k]['avg_ms']*kernels[k]['launches'] for k in pvq_names if k in kernels)/steps
+    out['kernel_spans_ms_per_step'] = round(span_ms, 3)
+    out['launch_gaps_ms_per_step'] = round(elapsed/steps*1e3 - span_ms, 3)
+    hb = {k: v for k, v in kernels.items() if k in alg_bytes and 'avg_ms' in v}
     dom = max(hb, key=lambda k: hb[k]['avg_ms']*hb[k]['launches'])
     ach = hb[dom]['GBps']
     traffic = measured_traffic(dom)
@@ -280,7 +298,8 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
         concurrent = nph > 0
         if concurrent:
             tot_ms = ph_ms
-        other_ms = sum(v['avg_ms']*v['launches'] for k, v in kernels.items() if k not in pvq_names)
+        other_ms = sum(v['avg_ms']*v['launches'] for k, v in kernels.items()
+                       if k not in pvq_names and k not in pair_bytes)
         out['pvq'] = {'bands_per_s': round(bands*FRAMES*steps/(tot_ms*1e-3), 1),
                       'bands_per_frame': bands,
                       'ms_per_step': round(tot_ms/steps, 3),
@@ -469,7 +488,6 @@ def main():
             'e2e': {'packet_bytes_per_step': int(nbytes), 'searches_from_device': int(st.dev_hits),
                     'searches_on_host': int(st.cpu_other + st.cpu_noref_luma),
                     'g2_mismatch_host_recomputed': int(st.g2_mismatch), 'lost_sync': int(st.lost_sync),
-                    'host_search_seconds_all_workers': round(st.search_cpu_s, 3),
                     'upload_phase_s': round(st.t_upload_s, 4), 'device_launch_phase_s': round(st.t_launch_s, 4),
                     'last_step_s': round(st.t_total_s, 4), 'session_setup_s': round(st.t_setup_s, 3)},
         }
@@ -503,6 +521,20 @@ def main():
                                  'host_workers': nw,
                                  'what': 'the same driver and host build with the device off (plain C '
                                          'search on every worker): what the GPU adds is value / this'}
+            # SURVEY 8d's second run: activity masking off (beta = 1 everywhere: no companding
+            # pow, cg = g/q0), same frames, same driver, bounded to two steps
+            pm = H.Params(PIC_W, PIC_H, 20, 7, 0, nw, 0, FRAMES)
+            with H.Session(pm, use_device=1, device=local_rank) as sm:
+                sm.encode(buf, FRAMES, out=out)
+                tm = time.perf_counter()
+                nm, pkm, stm = sm.encode(buf, FRAMES, out=out)
+                tm = time.perf_counter() - tm
+            refm = reference_packets(frames, 2, masking=0)
+            line['masking_off'] = {'Mpixels_per_s': round(FRAMES*PIC_W*PIC_H/tm/1e6, 3),
+                                   'first_2_packets_equal_pure_reference_build':
+                                       bool(nm > 0 and refm is not None and pkm[:2] == refm['packets']),
+                                   'reference_1thread_Mpixels_per_s': round(refm['Mpixels_per_s'], 4) if refm else None,
+                                   'what': 'the end-to-end step with activity masking off (SURVEY 8d), one timed step'}
             # decoder side of the seam on the packets just produced
             hdr = H.headers(prm)
             nd, pics, sec, dsec = H.decode(prm, hdr, packets, use_device=1, device=local_rank)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -68,8 +69,12 @@ struct DevBuf {
   }
 };
 
-// Scratch for the host-pointer entry points (sections 1, 2 of the header).
+// Scratch for the host-pointer entry points (sections 1, 2 of the header): one set per
+// process, so those entry points take g_scratch_mu for their whole round trip (they are
+// parity/drop-in paths, not the fast path; the context objects carry their own buffers).
 DevBuf g_in, g_out, g_aux0, g_aux1, g_aux2, g_aux3, g_aux4, g_aux5, g_aux6;
+std::recursive_mutex g_scratch_mu;
+#define SCRATCH_LOCK std::lock_guard<std::recursive_mutex> scratch_lock_(g_scratch_mu)
 
 template <int N, bool INV>
 int launch_dct_blocks(int32_t *out, const int32_t *in, int nblocks, hipStream_t s) {
@@ -101,6 +106,7 @@ int dct_blocks_host(int bs, bool inv, od_coeff *out, const od_coeff *in, int nbl
   if (int rc = ensure_device()) return rc;
   if (nblocks == 0) return 0;
   size_t n = 4u << bs, bytes = (size_t)nblocks*n*n*sizeof(int32_t);
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_out.reserve(bytes)) return rc;
   HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
@@ -385,6 +391,7 @@ int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in, i
   if (int rc = ensure_device()) return rc;
   if (nblocks == 0) return 0;
   size_t n = 4u << bs, bytes = (size_t)nblocks*n*n*sizeof(int32_t);
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_out.reserve(bytes)) return rc;
   HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
@@ -423,6 +430,7 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
   if (nblocks == 0) return 0;
   static_assert(sizeof(McBlock) == sizeof(od_hip_mc_block), "McBlock mirrors od_hip_mc_block");
   const size_t plane = (size_t)ref_stride*ref_h, dbytes = (size_t)dst_stride*dst_h;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(plane*nref)) return rc;
   if (int rc = g_aux0.reserve((size_t)nblocks*sizeof(McBlock))) return rc;
   if (int rc = g_out.reserve(dbytes)) return rc;
@@ -464,6 +472,7 @@ int od_hip_mc_sad_pairs(const unsigned char *src, int src_stride, int src_h, con
   if (npairs == 0) return 0;
   static_assert(sizeof(McPair) == sizeof(od_hip_mc_pair), "McPair mirrors od_hip_mc_pair");
   const size_t sb = (size_t)src_stride*src_h, rb = (size_t)ref_stride*ref_h;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(sb)) return rc;
   if (int rc = g_aux0.reserve(rb)) return rc;
   if (int rc = g_aux1.reserve((size_t)npairs*sizeof(McPair))) return rc;
@@ -479,6 +488,151 @@ int od_hip_mc_sad_pairs(const unsigned char *src, int src_stride, int src_h, con
   hipLaunchKernelGGL(k_mc_sad_pairs, dim3(npairs), dim3(64), 0, 0, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, g_out.p, (size_t)npairs*4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Resident motion-compensation object (one per host thread that predicts frames): own
+// stream, page-locked staging, the reference frames of every plane resident in HBM - a
+// reference image is uploaded when it changes, not once per predicted plane - block list and
+// prediction buffers.  od_hip_mc_predict_blocks above stays as the stateless parity entry.
+struct od_hip_mc {
+  int device = 0, nref = 0;
+  hipStream_t stream = nullptr;
+  struct Plane {
+    int ref_stride = 0, ref_h = 0, org_x = 0, org_y = 0;
+    size_t plane = 0;                 // bytes of one reference plane
+    uint8_t *d_refs = nullptr;        // [nref][ref_h][ref_stride]
+    uint8_t *h_ref = nullptr;         // pinned staging, one plane
+    uint8_t *d_dst = nullptr, *h_dst = nullptr;
+    size_t dst_cap = 0;
+  } pl[3];
+  McBlock *d_blocks = nullptr, *h_blocks = nullptr;
+  size_t blocks_cap = 0;
+};
+
+extern "C" {
+
+void od_hip_mc_destroy(od_hip_mc *m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  for (auto &p : m->pl) {
+    if (p.d_refs) (void)hipFree(p.d_refs);
+    if (p.h_ref) (void)hipHostFree(p.h_ref);
+    if (p.d_dst) (void)hipFree(p.d_dst);
+    if (p.h_dst) (void)hipHostFree(p.h_dst);
+  }
+  if (m->d_blocks) (void)hipFree(m->d_blocks);
+  if (m->h_blocks) (void)hipHostFree(m->h_blocks);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+od_hip_mc *od_hip_mc_create(int device, int nref) {
+  if (nref < 1 || nref > 8) { fail(OD_HIP_EINVAL, "bad reference count"); return nullptr; }
+  if (ensure_device()) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) { fail(OD_HIP_ENODEV, "hipSetDevice failed"); return nullptr; }
+  od_hip_mc *m = new od_hip_mc();
+  m->device = device;
+  m->nref = nref;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(OD_HIP_ENODEV, "stream creation failed");
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+
+int od_hip_mc_set_ref(od_hip_mc *m, int pli, int k, const unsigned char *plane, int ref_stride, int ref_h,
+                      int org_x, int org_y) {
+  if (!m || !plane) return fail(OD_HIP_EFAULT, "null pointer");
+  if (pli < 0 || pli > 2 || k < 0 || k >= m->nref || ref_stride < 1 || ref_h < 1) return fail(OD_HIP_EINVAL, "bad reference plane");
+  HIPCHK(hipSetDevice(m->device));
+  auto &P = m->pl[pli];
+  const size_t bytes = (size_t)ref_stride*ref_h;
+  if (P.plane != bytes || P.ref_stride != ref_stride) {
+    // geometry (re)defined: every reference of this plane has to be set again by the caller
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (P.d_refs) (void)hipFree(P.d_refs);
+    if (P.h_ref) (void)hipHostFree(P.h_ref);
+    P.d_refs = P.h_ref = nullptr;
+    HIPCHK(hipMalloc((void **)&P.d_refs, bytes*m->nref));
+    HIPCHK(hipHostMalloc((void **)&P.h_ref, bytes));
+    P.plane = bytes;
+    P.ref_stride = ref_stride;
+    P.ref_h = ref_h;
+  }
+  P.org_x = org_x;
+  P.org_y = org_y;
+  HIPCHK(hipStreamSynchronize(m->stream));          // the staging plane may still be in flight
+  memcpy(P.h_ref, plane, bytes);
+  HIPCHK(hipMemcpyAsync(P.d_refs + bytes*k, P.h_ref, bytes, hipMemcpyHostToDevice, m->stream));
+  return 0;
+}
+
+int od_hip_mc_predict(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nblocks, unsigned char *dst,
+                      int dst_stride, int dst_w, int dst_h) {
+  if (!m || !blocks || !dst) return fail(OD_HIP_EFAULT, "null pointer");
+  if (pli < 0 || pli > 2 || nblocks < 0 || dst_stride < 1 || dst_w < 1 || dst_w > dst_stride || dst_h < 1)
+    return fail(OD_HIP_EINVAL, "bad geometry");
+  auto &P = m->pl[pli];
+  if (!P.d_refs) return fail(OD_HIP_EINVAL, "no reference planes set for this plane");
+  // operand shapes are checked on the host before anything is launched
+  for (int b = 0; b < nblocks; b++) {
+    const od_hip_mc_block &q = blocks[b];
+    if (q.log_xblk_sz < 2 || q.log_xblk_sz > 6 || q.log_yblk_sz < 2 || q.log_yblk_sz > 6 || q.x < 0 || q.y < 0
+        || q.x + (1 << q.log_xblk_sz) > dst_w || q.y + (1 << q.log_yblk_sz) > dst_h
+        || q.oc < 0 || q.oc > 3 || q.s < 0 || q.s > 3)
+      return fail(OD_HIP_EINVAL, "bad prediction block");
+    for (int k = 0; k < 4; k++) if (q.ref[k] < 0 || q.ref[k] >= m->nref) return fail(OD_HIP_EINVAL, "bad reference index");
+  }
+  if (nblocks == 0) return 0;
+  HIPCHK(hipSetDevice(m->device));
+  const size_t dbytes = (size_t)dst_w*dst_h;        // dense picture area on the device
+  if (P.dst_cap < dbytes) {
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (P.d_dst) (void)hipFree(P.d_dst);
+    if (P.h_dst) (void)hipHostFree(P.h_dst);
+    P.d_dst = P.h_dst = nullptr;
+    P.dst_cap = 0;
+    HIPCHK(hipMalloc((void **)&P.d_dst, dbytes));
+    HIPCHK(hipHostMalloc((void **)&P.h_dst, dbytes));
+    P.dst_cap = dbytes;
+  }
+  if (m->blocks_cap < (size_t)nblocks) {
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->d_blocks) (void)hipFree(m->d_blocks);
+    if (m->h_blocks) (void)hipHostFree(m->h_blocks);
+    m->d_blocks = m->h_blocks = nullptr;
+    m->blocks_cap = 0;
+    const size_t cap = (size_t)nblocks*2;
+    HIPCHK(hipMalloc((void **)&m->d_blocks, cap*sizeof(McBlock)));
+    HIPCHK(hipHostMalloc((void **)&m->h_blocks, cap*sizeof(McBlock)));
+    m->blocks_cap = cap;
+  }
+  HIPCHK(hipStreamSynchronize(m->stream));          // the previous plane's list may still be read
+  memcpy(m->h_blocks, blocks, (size_t)nblocks*sizeof(McBlock));
+  HIPCHK(hipMemcpyAsync(m->d_blocks, m->h_blocks, (size_t)nblocks*sizeof(McBlock), hipMemcpyHostToDevice, m->stream));
+  McArgs a;
+  a.refs = P.d_refs;
+  a.ref_plane = P.plane;
+  a.ref_stride = P.ref_stride;
+  a.ref_h = P.ref_h;
+  a.org_x = P.org_x;
+  a.org_y = P.org_y;
+  a.blocks = m->d_blocks;
+  a.nblocks = nblocks;
+  a.dst = P.d_dst;
+  a.dst_stride = dst_w;
+  hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(MC_THREADS), 0, m->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(P.h_dst, P.d_dst, dbytes, hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  // the blocks tile the picture area; only that area of the caller's plane is written
+  for (int y = 0; y < dst_h; y++) memcpy(dst + (size_t)y*dst_stride, P.h_dst + (size_t)y*dst_w, dst_w);
   return 0;
 }
 
@@ -506,6 +660,7 @@ int od_hip_coding_order_blocks(int bs, int to_raster, od_coeff *inout_dst, const
   const int tabn[4] = {CODING_NCODED_4, CODING_NCODED_8, CODING_NCODED_16, CODING_NCODED_32};
   const int n = 4 << bs, nn = n*n, ncoded = tabn[bs];
   const size_t bytes = (size_t)nblocks*nn*4;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_out.reserve(bytes)) return rc;
   if (int rc = g_aux0.reserve((size_t)ncoded*2)) return rc;
@@ -529,6 +684,7 @@ int od_hip_filter4_vectors(int inverse, od_coeff *out, const od_coeff *in, int n
   if (int rc = ensure_device()) return rc;
   if (nvec == 0) return 0;
   size_t bytes = (size_t)nvec*4*sizeof(int32_t);
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_out.reserve(bytes)) return rc;
   HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
@@ -545,6 +701,7 @@ int od_hip_filter_vectors(int n, int inverse, od_coeff *out, const od_coeff *in,
   if (int rc = ensure_device()) return rc;
   if (nvec == 0) return 0;
   size_t bytes = (size_t)nvec*n*sizeof(int32_t);
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_out.reserve(bytes)) return rc;
   HIPCHK(hipMemcpy(g_in.p, in, bytes, hipMemcpyHostToDevice));
@@ -582,6 +739,7 @@ int od_hip_resample_luma(od_coeff *pred, const od_coeff *luma, size_t luma_len,
   if (int rc = ensure_device()) return rc;
   if (nblk == 0) return 0;
   size_t n = 4u << bs, obytes = (size_t)nblk*n*n*sizeof(int32_t);
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(luma_len*sizeof(int32_t))) return rc;
   if (int rc = g_out.reserve(obytes)) return rc;
   if (int rc = g_aux0.reserve((size_t)nblk*sizeof(int32_t))) return rc;
@@ -1356,6 +1514,7 @@ int od_hip_pvq_search_vectors(int n, int nvec, const double *x, const int32_t *k
   if (int rc = ensure_device()) return rc;
   if (nvec == 0) return 0;
   size_t nv = nvec;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(nv*n*8)) return rc;
   if (int rc = g_out.reserve(nv*n*4)) return rc;
   if (int rc = g_aux0.reserve(nv*4)) return rc;
@@ -1380,6 +1539,7 @@ int od_hip_pvq_synthesis_noref(int n, int nvec, const int32_t *y, const double *
   if (int rc = ensure_device()) return rc;
   if (nvec == 0) return 0;
   size_t nv = nvec;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(nv*n*4)) return rc;
   if (int rc = g_out.reserve(nv*n*4)) return rc;
   if (int rc = g_aux0.reserve(nv*n*2)) return rc;
@@ -1432,6 +1592,7 @@ int od_hip_pvq_theta_vectors(int n, int nvec, const od_coeff *x0, const od_coeff
   if (int rc = ensure_device()) return rc;
   if (nvec == 0) return 0;
   size_t nv = nvec;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(nv*n*4)) return rc;
   if (int rc = g_aux0.reserve(nv*n*4)) return rc;
   if (int rc = g_aux1.reserve((size_t)n*2)) return rc;
@@ -1564,6 +1725,7 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
   if (int rc = ensure_device()) return rc;
   if (nvec == 0) return 0;
   size_t nv = nvec;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(nv*n*4)) return rc;
   if (int rc = g_aux0.reserve(nv*n*4)) return rc;
   if (int rc = g_aux1.reserve(nv*8)) return rc;
@@ -1611,6 +1773,7 @@ int od_hip_hv_intra_pred_blocks(const od_coeff *d, int w, int h, const unsigned 
   if (int rc = ensure_device()) return rc;
   if (nblk == 0) return 0;
   size_t nb = nblk, bh = h/8;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve((size_t)w*h*4)) return rc;
   if (int rc = g_aux0.reserve(bh*bstride)) return rc;
   if (int rc = g_aux1.reserve(nb*4)) return rc;
@@ -1636,6 +1799,7 @@ int od_hip_compute_dist_blocks(int bs, int nblk, const od_coeff *x, const od_coe
   if (nblk == 0) return 0;
   size_t n = 4u << bs, bytes = (size_t)nblk*n*n*4;
   const size_t per = (n/8)*(n/8), nsub = (size_t)nblk*per;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_aux0.reserve(bytes)) return rc;
   if (int rc = g_aux1.reserve(64*8)) return rc;
@@ -1772,6 +1936,7 @@ int od_hip_libm_probe(int fn, int n, const double *x, const double *y, double *o
   if (int rc = ensure_device()) return rc;
   if (n == 0) return 0;
   size_t nb = (size_t)n*8;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(nb)) return rc;
   if (int rc = g_aux0.reserve(nb)) return rc;
   if (int rc = g_out.reserve(nb)) return rc;
@@ -1788,6 +1953,7 @@ int od_hip_calibrate_traffic(int mode, size_t bytes) {
   if (mode < 0 || mode > 2 || bytes < 1024) return fail(OD_HIP_EINVAL, "bad arguments");
   if (int rc = ensure_device()) return rc;
   bytes &= ~(size_t)1023;
+  SCRATCH_LOCK;
   if (int rc = g_in.reserve(bytes)) return rc;
   if (int rc = g_aux0.reserve(64)) return rc;
   HIPCHK(hipMemset(g_in.p, 1, bytes));

@@ -58,6 +58,7 @@ void od_state_mc_predict_cpu(od_state *state, od_img *img_dst);
 /* hip_enc_glue.c */
 int od_hipenc_device_thread(void);
 int od_hipenc_check_mode(void);
+void od_hipdec_thread_cleanup(void);
 int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
  int xstride, int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
  int dir[OD_DERING_NBLOCKS][OD_DERING_NBLOCKS], int pli, unsigned char *bskip,
@@ -83,6 +84,10 @@ typedef struct dec_tls {
   long md_check_fail;
   long idct_skipped;
   long haar_skipped;
+  int device;               /* HIP device of this thread's objects */
+  od_hip_mc *mc;            /* this thread's resident motion-compensation object */
+  const od_state *mc_state; /* the codec state its reference copies belong to */
+  unsigned char mc_dirty[OD_FRAME_MAX + 1];   /* reference image k changed since its upload */
   int failed;               /* a device stage of the current packet / frame failed: surfaced as an error code */
   int haar_frame;           /* the frame being decoded uses the Haar wavelet with a quantizer > 0: host path */
   int check;
@@ -417,6 +422,11 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
   int w;
   int h;
   int y;
+  /* every frame's reconstruction lands in state->ref_imgs[SELF] through this function: the
+     device copy of that reference image (mc_predict_device) is stale from here on */
+  if (state == D.mc_state && dst >= state->ref_imgs && dst <= state->ref_imgs + OD_FRAME_MAX) {
+    D.mc_dirty[dst - state->ref_imgs] = 1;
+  }
   if (D.failed && D.dec != NULL && state == &D.dec->state) {
     od_coeff_to_ref_plane_cpu(state, dst, pli, src, lossless_p);
     return;
@@ -590,6 +600,7 @@ static void *dworker(void *arg) {
   J = (djob *)arg;
   memset(&D, 0, sizeof(D));
   D.check = J->p->check;
+  D.device = J->device;
   dec = make_decoder(J);
   st = dec != NULL ? &((od_dec_ctx *)dec)->state : NULL;
   if (dec != NULL && J->use_device) {
@@ -712,6 +723,7 @@ static void *dworker(void *arg) {
     if (D.pinned[3 + pli]) od_hip_host_unregister(D.stage[pli]);
     free(D.stage[pli]);
   }
+  od_hipdec_thread_cleanup();
   if (D.ctx != NULL) od_hip_ctx_destroy(D.ctx);
   for (pli = 0; pli < 3; pli++) free(D.rec[pli]);
   if (dec != NULL) daala_decode_free(dec);
@@ -810,21 +822,52 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
   mc_list L;
   int pli;
   int rc;
+  int k;
+  int dev;
   rc = 0;
   memset(&L, 0, sizeof(L));
   if (state->full_precision_references) return -1;
+  if (D.mc == NULL) {
+    dev = D.device;
+    D.mc = od_hip_mc_create(dev, OD_FRAME_MAX + 1);
+    if (D.mc == NULL) return -1;
+    D.mc_state = NULL;
+  }
+  if (D.mc_state != state) {
+    D.mc_state = state;
+    memset(D.mc_dirty, 1, sizeof(D.mc_dirty));
+  }
+  /* the image being predicted into is this frame's SELF: rewritten, and never read as a
+     reference of this frame */
+  if (img_dst >= state->ref_imgs && img_dst <= state->ref_imgs + OD_FRAME_MAX) {
+    D.mc_dirty[img_dst - state->ref_imgs] = 1;
+  }
+  /* reference images that changed since their upload (src/state.c:236-300: OD_BUFFER_PADDING
+     >> dec samples of padding on every side of the frame) */
+  for (k = 0; k <= OD_FRAME_MAX && rc == 0; k++) {
+    int used;
+    int t;
+    used = 0;
+    for (t = 0; t < OD_FRAME_MAX + 1; t++) used |= state->ref_imgi[t] == k && t != OD_FRAME_SELF;
+    if (!used || !D.mc_dirty[k] || state->ref_imgs + k == img_dst) continue;
+    for (pli = 0; pli < img_dst->nplanes && rc == 0; pli++) {
+      const od_img_plane *rp;
+      int px;
+      int py;
+      rp = state->ref_imgs[k].planes + pli;
+      px = OD_BUFFER_PADDING >> rp->xdec;
+      py = OD_BUFFER_PADDING >> rp->ydec;
+      rc = od_hip_mc_set_ref(D.mc, pli, k, rp->data - (ptrdiff_t)py*rp->ystride - px, rp->ystride,
+       (state->frame_height + 2*OD_BUFFER_PADDING) >> rp->ydec, px, py);
+    }
+    if (rc == 0) D.mc_dirty[k] = 0;
+  }
   for (pli = 0; pli < img_dst->nplanes && rc == 0; pli++) {
-    const unsigned char *refs[OD_FRAME_MAX + 1];
     od_img_plane *dp;
     int xdec;
     int ydec;
-    int px;
-    int py;
-    int stride;
-    int rh;
     int vx;
     int vy;
-    int k;
     dp = img_dst->planes + pli;
     xdec = dp->xdec;
     ydec = dp->ydec;
@@ -832,31 +875,33 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
       rc = -1;
       break;
     }
-    /* the reference frames' plane buffers (od_state_ref_imgs_init, src/state.c:236-300):
-       OD_BUFFER_PADDING >> dec samples of padding on every side of the frame */
-    px = OD_BUFFER_PADDING >> xdec;
-    py = OD_BUFFER_PADDING >> ydec;
-    stride = state->ref_imgs[0].planes[pli].ystride;
-    rh = (state->frame_height + 2*OD_BUFFER_PADDING) >> ydec;
-    for (k = 0; k <= OD_FRAME_MAX; k++) {
-      refs[k] = state->ref_imgs[k].planes[pli].data - (ptrdiff_t)py*stride - px;
-    }
     L.n = 0;
     for (vy = 0; vy < state->nvmvbs && rc == 0; vy += OD_MVB_DELTA0) {
       for (vx = 0; vx < state->nhmvbs && rc == 0; vx += OD_MVB_DELTA0) {
         rc = mc_collect(state, &L, pli, xdec, ydec, vx, vy, OD_LOG_MVB_DELTA0);
       }
     }
+    /* a block may name any image the grid refers to: all of those were refreshed above */
     if (rc == 0) {
-      rc = od_hip_mc_predict_blocks(OD_FRAME_MAX + 1, refs, stride, rh, px, py, L.b, L.n,
-       dp->data, dp->ystride, state->frame_height >> ydec);
+      rc = od_hip_mc_predict(D.mc, pli, L.b, L.n, dp->data, dp->ystride, state->frame_width >> xdec,
+       state->frame_height >> ydec);
     }
   }
   free(L.b);
   return rc;
 }
 
+/* encoder workers: the device their prediction object lives on */
+void od_hipdec_set_device(int device) {
+  D.device = device;
+}
 
+/* per-thread clean-up (worker exit) */
+void od_hipdec_thread_cleanup(void) {
+  if (D.mc != NULL) od_hip_mc_destroy(D.mc);
+  D.mc = NULL;
+  D.mc_state = NULL;
+}
 
 void od_state_mc_predict(od_state *state, od_img *img_dst) {
   if ((D.ctx != NULL || od_hipenc_device_thread()) && !D.failed) {

@@ -341,6 +341,8 @@ void od_encode_rollback(daala_enc_ctx *enc, const od_rollback_buffer *rbuf) {
 void od_haar_cpu(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln);
 void od_hipdec_haar_notify(void);        /* hip_dec_glue.c */
 int od_hipdec_take_failure(void);
+void od_hipdec_thread_cleanup(void);
+void od_hipdec_set_device(int device);
 
 void od_haar(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln) {
   /* decoder threads: a Haar frame with a quantizer > 0 takes the host path (hip_dec_glue.c) */
@@ -436,6 +438,10 @@ static daala_enc_ctx *make_encoder(const od_hipenc_params *p, int w, int h) {
      it); the reference CLI always sets 1 (examples/encoder_example.c:675,900). */
   v = 1;
   daala_encode_ctl(enc, OD_SET_DERING, &v, sizeof(v));
+  /* Test hook: the stream syntax allows Haar-wavelet frames with a quantizer > 0 (the flag of
+     src/encode.c:3022), which the reference encoder only writes when built with
+     OD_USE_HAAR_WAVELET; the decoder glue's handling of such frames needs one. */
+  if (getenv("HIPENC_TEST_HAAR") != NULL) enc->use_haar_wavelet = 1;
   return enc;
 }
 
@@ -721,6 +727,7 @@ static void *worker(void *arg) {
   pthread_mutex_lock(&S->mu);
   pin_worker(S->next_worker_id++);
   pthread_mutex_unlock(&S->mu);
+  od_hipdec_set_device(S->device);
   T.check = S->p.check;
   T.time_cpu = S->time_cpu;
   T.host_pvq = S->host_pvq;
@@ -835,6 +842,7 @@ static void *worker(void *arg) {
   free(T.dist[2]);
   if (enc != NULL) daala_encode_free(enc);
   od_hipenc_mc_cache_free();             /* this thread's prediction cache (hip_mc_host.c) */
+  od_hipdec_thread_cleanup();            /* its resident motion-compensation object (hip_dec_glue.c) */
   return NULL;
 }
 

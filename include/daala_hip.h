@@ -439,6 +439,21 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
  int ref_h, int org_x, int org_y, const od_hip_mc_block *blocks, int nblocks,
  unsigned char *dst, int dst_stride, int dst_h);
 
+/* The same with the reference frames RESIDENT on the device: one object per host thread that
+ * predicts frames (own stream and staging, safe beside any other object).
+ *   od_hip_mc_set_ref   uploads reference image k of plane pli (geometry as refs[k] above);
+ *                       call it when that image has changed - not per predicted plane;
+ *   od_hip_mc_predict   predicts the blocks of plane pli from the resident references into
+ *                       dst: dst_w x dst_h samples are written (the blocks tile that area),
+ *                       rows dst_stride bytes apart; nothing else of dst is touched. */
+typedef struct od_hip_mc od_hip_mc;
+od_hip_mc *od_hip_mc_create(int device, int nref);
+void od_hip_mc_destroy(od_hip_mc *mc);
+int od_hip_mc_set_ref(od_hip_mc *mc, int pli, int k, const unsigned char *plane, int ref_stride,
+ int ref_h, int org_x, int org_y);
+int od_hip_mc_predict(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int nblocks,
+ unsigned char *dst, int dst_stride, int dst_w, int dst_h);
+
 /* F3: the encoder's SAD / SATD table od_enc_opt_vtbl (src/encint.h:61-82; C entries
  * od_mc_compute_sad8_NxN_c src/mcenc.c:1349-1372, od_mc_compute_satd8_NxN_c :1584-1660) for a
  * list of block pairs: out[i] = SAD or SATD between the 2^log_blk_sz square block at (sx, sy)
