@@ -624,3 +624,89 @@ def od_compute_dist_blocks(bs, x, y, mag2, activity_masking):
     _chk(lib.od_hip_compute_dist_blocks(bs, x.shape[0], _p32(x), _p32(y), mag2.ctypes.data_as(F64P),
                                         int(activity_masking), out.ctypes.data_as(F64P)))
     return out
+
+
+class PFeedLevel(ctypes.Structure):
+    """od_hip_pfeed_level (include/daala_hip.h section 4d)."""
+    _fields_ = [('n', ctypes.c_int32), ('nbands', ctypes.c_int32), ('nblk', ctypes.c_int32),
+                ('nbx', ctypes.c_int32), ('off', ctypes.c_int32*11), ('nslots', ctypes.c_int32),
+                ('nref_slots', ctypes.c_int32), ('pad', ctypes.c_int32),
+                ('g', F64P), ('gr', F64P), ('corr', F64P), ('isnull', I32P), ('cg', F64P), ('cgr', F64P),
+                ('theta', F64P), ('flags', I32P), ('cos_dist', F64P), ('k', I32P), ('y', I16P)]
+
+
+class PFeed:
+    """od_hip_pfeed_*: the complete pvq_theta candidate lists of one inter frame (all planes,
+    all levels) from its padded input planes and its motion-compensated prediction."""
+
+    def __init__(self, pic_w, pic_h, fw, fh, nplanes=3, xdec=(0, 1, 1), device=0):
+        self.lib = load()
+        g = Geometry()
+        g.pic_width, g.pic_height, g.frame_width, g.frame_height = pic_w, pic_h, fw, fh
+        g.nplanes = nplanes
+        for i, d in enumerate(xdec):
+            g.xdec[i] = d
+        g.nslots = 2
+        self.lib.od_hip_pfeed_create.restype = ctypes.c_void_p
+        self.lib.od_hip_pfeed_create.argtypes = [c_int, ctypes.POINTER(Geometry)]
+        self.h = self.lib.od_hip_pfeed_create(device, ctypes.byref(g))
+        if not self.h:
+            raise HipError(self.lib.od_hip_last_error().decode())
+        self.nplanes, self.xdec = nplanes, tuple(xdec)
+        for name in ('od_hip_pfeed_destroy', 'od_hip_pfeed_set_level', 'od_hip_pfeed_gains',
+                     'od_hip_pfeed_nrec', 'od_hip_pfeed_host_stage', 'od_hip_pfeed_search',
+                     'od_hip_pfeed_view'):
+            getattr(self.lib, name).argtypes = None
+        self.lib.od_hip_pfeed_destroy.argtypes = [ctypes.c_void_p]
+        self.lib.od_hip_pfeed_set_level.argtypes = [ctypes.c_void_p, c_int, c_int, I16P, I32P, F64P]
+        self.lib.od_hip_pfeed_gains.argtypes = [ctypes.c_void_p, ctypes.POINTER(U8P), I32P,
+                                                ctypes.POINTER(U8P), I32P]
+        self.lib.od_hip_pfeed_nrec.argtypes = [ctypes.c_void_p, c_int, c_int]
+        self.lib.od_hip_pfeed_host_stage.argtypes = [ctypes.c_void_p, c_int, c_int, ctypes.c_long, ctypes.c_long]
+        self.lib.od_hip_pfeed_search.argtypes = [ctypes.c_void_p]
+        self.lib.od_hip_pfeed_view.argtypes = [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(PFeedLevel)]
+
+    def nlevels(self, pli):
+        return 4 - self.xdec[pli]
+
+    def set_level(self, pli, level, qm, q, beta):
+        qm = np.ascontiguousarray(qm, dtype=np.int16)
+        q = np.ascontiguousarray(list(q) + [1]*(11 - len(q)), dtype=np.int32)
+        beta = np.ascontiguousarray(list(beta) + [1.]*(11 - len(beta)), dtype=np.float64)
+        _chk(self.lib.od_hip_pfeed_set_level(self.h, pli, level, qm.ctypes.data_as(I16P), _p32(q),
+                                             beta.ctypes.data_as(F64P)))
+
+    def run(self, planes_in, planes_pred):
+        def pack(planes):
+            pl = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+            return pl, (U8P*len(pl))(*[p.ctypes.data_as(U8P) for p in pl]), \
+                np.ascontiguousarray([p.shape[1] for p in pl], dtype=np.int32)
+        a, pa, sa = pack(planes_in)
+        b, pb, sb = pack(planes_pred)
+        _chk(self.lib.od_hip_pfeed_gains(self.h, pa, _p32(sa), pb, _p32(sb)))
+        for pli in range(self.nplanes):
+            for level in range(self.nlevels(pli)):
+                n = self.lib.od_hip_pfeed_nrec(self.h, pli, level)
+                _chk(self.lib.od_hip_pfeed_host_stage(self.h, pli, level, 0, n))
+        _chk(self.lib.od_hip_pfeed_search(self.h))
+
+    def view(self, pli, level):
+        v = PFeedLevel()
+        _chk(self.lib.od_hip_pfeed_view(self.h, pli, level, ctypes.byref(v)))
+        nrec = v.nbands*v.nblk
+        ncoded = min(v.n*v.n, 512)
+        arr = np.ctypeslib.as_array
+        return {'n': v.n, 'nbands': v.nbands, 'nblk': v.nblk, 'nbx': v.nbx, 'off': list(v.off)[:v.nbands + 1],
+                'nslots': v.nslots, 'nref_slots': v.nref_slots,
+                'g': arr(v.g, (nrec,)).copy(), 'gr': arr(v.gr, (nrec,)).copy(),
+                'corr': arr(v.corr, (nrec,)).copy(), 'isnull': arr(v.isnull, (nrec,)).copy(),
+                'cg': arr(v.cg, (nrec,)).copy(), 'cgr': arr(v.cgr, (nrec,)).copy(),
+                'theta': arr(v.theta, (nrec,)).copy(), 'flags': arr(v.flags, (nrec,)).copy(),
+                'cos_dist': arr(v.cos_dist, (v.nslots*nrec,)).copy().reshape(v.nslots, nrec),
+                'k': arr(v.k, (v.nslots*nrec,)).copy().reshape(v.nslots, nrec),
+                'y': arr(v.y, (v.nslots*v.nblk*ncoded,)).copy()}
+
+    def close(self):
+        if self.h:
+            self.lib.od_hip_pfeed_destroy(self.h)
+            self.h = None

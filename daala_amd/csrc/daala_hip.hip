@@ -15,6 +15,7 @@
 #include "coding_order_tables.h"
 #include "pvq_kernels.hpp"
 #include "pvq_theta_kernels.hpp"
+#include "pvq_pfeed_kernels.hpp"
 #include "mc_kernels.hpp"
 #include "xform_kernels.hpp"
 #include "xform_rt_kernels.hpp"
@@ -2023,4 +2024,5 @@ int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches, double
 }  // extern "C"
 
 #include "enc_feed.hpp"
+#include "pfeed.hpp"
 #include "comm.hpp"

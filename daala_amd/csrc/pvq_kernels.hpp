@@ -334,17 +334,21 @@ __device__ __forceinline__ void pvq_tree_greedy(double &a, double &b, double &t,
 // in ONE batch (LDS copy of the table, or one batch of independent global loads beyond it),
 // the scans carry the unsquared sum and the new yy of the winner (they ARE the reference's
 // next xy and yy: same operands, same operation), and no branch is left inside a scan.
-template <int N>
+// PAD: the band may be one coefficient short of N (the with-reference searches of pvq_theta
+// run on n - 1 dimensions, src/pvq_encoder.c:404,426): with `padlast` the last coefficient of the
+// band's last lane is a pad - its |x| is 0, so every sum is unchanged - that no scan may select.
+template <int N, bool PAD = false>
 __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int lane, int k,
                                                 double g2, const double *__restrict__ rsq,
                                                 const double *rsqL,
                                                 int (&y)[PvqGeom<N>::NL], int &npulse_greedy,
-                                                int &npulse_rdo) {
+                                                int &npulse_rdo, bool padlast = false) {
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL;
   static_assert(G*NL == N, "every lane of a band owns NL coefficients (no padding elements in the scans)");
   const int base = (lane/G)*G;                  // first lane of my band
+  const bool padl = PAD && padlast && g == G - 1;   // this lane's element NL - 1 is the pad
   const double lambda = PVQ_LAMBDA/(1e-30 + g2);
-  const double delta_rate = 3./N;
+  const double delta_rate = 3./(N - ((PAD && padlast) ? 1 : 0));   // 3./n of the searched vector
   double xy = 0, yy = 0;
   int i = 0;
   int ymax = 0;                                 // largest pulse count of this lane's chunk
@@ -387,7 +391,7 @@ __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int l
       const double t = xy + v.x[j];
       const double b = yy + (double)(2*y[j] + 1);
       const double a = t*t;
-      if (a*bb > ba*b) { ba = a; bb = b; bt = t; bpos = j; }
+      if (a*bb > ba*b && !(PAD && j == NL - 1 && padl)) { ba = a; bb = b; bt = t; bpos = j; }
     }
     int wl = bpos, wg = 0;            // winner: local index and owning lane of the group
     double nxy = bt, nyy = bb;
@@ -414,7 +418,7 @@ __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int l
           const bool before = g < wg || (g == wg && j < wl);
           const bool self = g == wg && j == wl;
           // before: p1 > p2 required; after: !(p2 > p1)
-          ok = ok && (self || (before ? p1 > p2 : !(p2 > p1)));
+          ok = ok && (self || (PAD && j == NL - 1 && padl) || (before ? p1 > p2 : !(p2 > p1)));
         }
       }
       if (__any(run && !ok)) {
@@ -430,7 +434,7 @@ __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int l
                 double a = xy + v.x[j];
                 const double b = yy + (2*y[j] + 1);
                 a *= a;
-                if ((r == 0 && j == 0) || a*ib > ia*b) { ia = a; ib = b; ip = j; ig = r; }
+                if ((r == 0 && j == 0) || (a*ib > ia*b && !(PAD && j == NL - 1 && padl))) { ia = a; ib = b; ip = j; ig = r; }
               }
             }
           }
@@ -490,7 +494,7 @@ __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int l
         const int ix = iy + 2*y[j] + 1;
         const double t = xy + v.x[j];
         const double c = 2*t*v.norm_1*rsqL[ix] - lam*(g*NL + j)*delta_rate;
-        if (c > bc) { bc = c; bt = t; bpos = j; bix = ix; }
+        if (c > bc && !(PAD && j == NL - 1 && padl)) { bc = c; bt = t; bpos = j; bix = ix; }
       }
     }
     else if (N >= 32 && !__any(ymax > 3)) {
@@ -512,7 +516,7 @@ __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int l
         const double rs = yj == 0 ? q0 : yj == 1 ? q1 : yj == 2 ? q2 : q3;
         const double t = xy + v.x[j];
         const double c = 2*t*v.norm_1*rs - lam*(g*NL + j)*delta_rate;
-        if (j == 0 || c > bc) { bc = c; bt = t; bpos = j; bix = iy + 2*yj + 1; }
+        if (j == 0 || (c > bc && !(PAD && j == NL - 1 && padl))) { bc = c; bt = t; bpos = j; bix = iy + 2*yj + 1; }
       }
     }
     else {
@@ -546,7 +550,7 @@ __device__ __forceinline__ double pvq_search_v4(const PvqVec<N> &v, int g, int l
             asm volatile("" : "+v"(ix));       // opaque: no "bix = table[bpos]" rewrite through scratch
             const double t = xy + v.x[j0 + j];
             const double c = 2*t*v.norm_1*rs[j] - lam*(g*NL + j0 + j)*delta_rate;
-            if (j0 + j == 0 || c > bc) { bc = c; bt = t; bpos = j0 + j; bix = ix; }
+            if (j0 + j == 0 || (c > bc && !(PAD && j0 + j == NL - 1 && padl))) { bc = c; bt = t; bpos = j0 + j; bix = ix; }
           }
         }
       }
@@ -617,12 +621,13 @@ __device__ __forceinline__ void pvq_wave_lds_sync() {
 // round 3 (profiles/r03_pvq_stamps.txt) showed four, each 2-6 k cycles, against 5-15 k cycles
 // of search in a short-band wave.
 // pe: this lane's work-list entry as loaded (lane < BPW), or anything for other lanes.
-template <int N, typename ENTRY>
+template <int N, typename ENTRY, bool TWO = false>
 __device__ __forceinline__ void pvq_gather(const PvqLevelArgs &a, int f, int o0, int lane, int g, int inst,
                                            int nslot_here, ENTRY entry_of_lane, int32_t *Pe, int32_t *Yst,
                                            int32_t *Org, bool &live, long &blk, const double *cg_band,
                                            double &cg, int32_t (&cf)[PvqGeom<N>::NL],
-                                           int (&qi)[PvqGeom<N>::NL]) {
+                                           int (&qi)[PvqGeom<N>::NL], const int32_t *plane2 = nullptr,
+                                           int32_t *cf2 = nullptr) {
   constexpr int G = PvqGeom<N>::G, NL = PvqGeom<N>::NL, BPW = PvqGeom<N>::BPW;
   constexpr int CH = NL + 1;                       // padded chunk stride in LDS
   constexpr int LDSN = (G*CH) | 1;                 // odd per-band stride
@@ -647,16 +652,18 @@ __device__ __forceinline__ void pvq_gather(const PvqLevelArgs &a, int f, int o0,
     if (lane + 64*q < N) Ro[lane + 64*q] = (rt[q] >> lg)*a.w + (rt[q] & (a.n - 1));
   }
   pvq_wave_lds_sync();
-  // round trip 2: the coefficients
+  // round trip 2: the coefficients (of both planes when there are two)
   const int32_t *plane = a.lev + (size_t)f*a.lev_fstride;
   const int total = nslot_here*N;
-  int32_t val[NL];
+  int32_t val[NL], val2[TWO ? NL : 1];
 #pragma unroll
   for (int it = 0; it < NL; it++) {
     const int e = lane + 64*it;
     const int ec = e < total ? e : 0;
     const int b = ec/N, jj = ec - b*N;
-    val[it] = plane[(size_t)Org[b] + Ro[jj]];
+    const size_t o = (size_t)Org[b] + Ro[jj];
+    val[it] = plane[o];
+    if (TWO) val2[it] = plane2[o];
   }
   const int32_t en = Pe[inst];
   live = en >= 0;
@@ -674,7 +681,19 @@ __device__ __forceinline__ void pvq_gather(const PvqLevelArgs &a, int f, int o0,
     cf[j] = live ? Yst[inst*LDSN + g*CH + j] : 0;
     qi[j] = live ? qi[j] : 0;
   }
-  pvq_wave_lds_sync();                             // Yst is reused for the pulses
+  pvq_wave_lds_sync();                             // Yst is reused (second plane, pulses)
+  if (TWO) {
+#pragma unroll
+    for (int it = 0; it < NL; it++) {
+      const int e = lane + 64*it;
+      const int b = e/N, jj = e - b*N;
+      if (e < total) Yst[b*LDSN + (jj/NL)*CH + jj%NL] = val2[it];
+    }
+    pvq_wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NL; j++) cf2[j] = live ? Yst[inst*LDSN + g*CH + j] : 0;
+    pvq_wave_lds_sync();
+  }
 }
 
 // Two launches per level.  k_pvq_gain computes the exact uncompanded gain g = sqrt(acc) of

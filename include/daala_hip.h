@@ -332,6 +332,53 @@ int od_hip_enc_feed_haar_view(od_hip_enc_feed *feed, int slot, const od_coeff *p
  int strides[3]);
 
 /* ---------------------------------------------------------------------------
+ * 4d. P-frame feed.  On an inter frame the reference of every band is the transform of the
+ *    motion-compensated prediction (od_encode_compute_pred, src/encode.c:749-755) - no H/V
+ *    intra prediction, no CfL - so both inputs of pvq_theta (src/pvq_encoder.c:311) are known
+ *    for every block size of every plane before the first symbol is coded: the device
+ *    enumerates the COMPLETE candidate list of every band - the with-reference (gain, theta)
+ *    candidates of :399-448 in the reference's loop order (slots 0 .. nref_slots - 1) and the
+ *    no-reference ones of :452-481 (the last two slots) - and the host prices them.  Two device
+ *    passes around the host's libm (pow, acos, sin are this process's):
+ *      od_hip_pfeed_gains       uploads the padded input planes and the prediction, forward
+ *                               pyramids of both, g / gr / correlation sum of every band;
+ *      od_hip_pfeed_host_stage  cg, cgr, theta, sin(theta), which searches run - any thread,
+ *                               disjoint record ranges concurrently;
+ *      od_hip_pfeed_search      every candidate's Householder reflection + codeword search.
+ *    One object holds one frame.  View layout: record r = band*nblk + block;
+ *      cos_dist[c*nrec + r], k[c*nrec + r] (K of slot c, -1: the reference's loops do not reach
+ *      that slot; the host re-derives the loops and must find the same K);
+ *      y of band b, slot c: y + nslots*nblk*yo[b] + (c*nblk + block)*ns[b], 16-bit, yo / ns as
+ *      in section 4b; with-reference codewords have n - 1 entries (src/pvq_encoder.c:426).
+ *    Blocks of superblocks that contain padding must not be taken from the feed: the encoder
+ *    overwrites the padded part of its input with the prediction's (src/encode.c:2443-2457). */
+typedef struct od_hip_pfeed od_hip_pfeed;
+typedef struct od_hip_pfeed_level {
+  int32_t n, nbands, nblk, nbx;
+  int32_t off[11];
+  int32_t nslots, nref_slots, pad;
+  const double *g, *gr;       /* [nrec] raw gains of input and reference (src/pvq.c:456-464) */
+  const double *corr;         /* [nrec] normalised, clamped correlation (:380-381) */
+  const int32_t *isnull;      /* [nrec] the reference vector is all zero */
+  const double *cg, *cgr;     /* [nrec] od_gain_compand of g, gr (host libm) */
+  const double *theta;        /* [nrec] acos(corr) where the theta search runs */
+  const int32_t *flags;       /* [nrec] bit 0: theta search ran, bit 1: no-reference search ran */
+  const double *cos_dist;     /* [nslots][nrec] */
+  const int32_t *k;           /* [nslots][nrec] */
+  const int16_t *y;
+} od_hip_pfeed_level;
+od_hip_pfeed *od_hip_pfeed_create(int device, const od_hip_geometry *geo);
+void od_hip_pfeed_destroy(od_hip_pfeed *pf);
+int od_hip_pfeed_set_level(od_hip_pfeed *pf, int pli, int level, const int16_t *qm, const int32_t *q,
+ const double *beta);
+int od_hip_pfeed_gains(od_hip_pfeed *pf, const unsigned char *const planes_in[], const int stride_in[],
+ const unsigned char *const planes_pred[], const int stride_pred[]);
+int od_hip_pfeed_nrec(od_hip_pfeed *pf, int pli, int level);
+int od_hip_pfeed_host_stage(od_hip_pfeed *pf, int pli, int level, long rec0, long rec1);
+int od_hip_pfeed_search(od_hip_pfeed *pf);
+int od_hip_pfeed_view(od_hip_pfeed *pf, int pli, int level, od_hip_pfeed_level *v);
+
+/* ---------------------------------------------------------------------------
  * 4c. Encoder-side deringing: od_dering() (src/filter.c:1835) of EVERY 32x32 superblock of
  *    one frame in one pass - what the encoder's filter on/off loop (src/encode.c:2552-2685)
  *    asks for superblock by superblock.  in[pli]: the unfiltered post-filter planes

@@ -708,3 +708,107 @@ def test_sad_satd_pairs_equal_oracle_and_golden():
     assert B.od_mc_sad_pairs(src, rf, []).size == 0
     with pytest.raises(Exception):
         B.od_mc_sad_pairs(src, rf, [(W - 4, 0, 0, 0, 3, 0)])
+
+
+def test_pframe_feed_complete_candidate_lists_vs_oracle(hip):
+    """The P-frame feed (include/daala_hip.h 4d): for an input frame and a prediction, every band
+    of every block of every level of every plane gets pvq_theta's COMPLETE candidate list on the
+    device (is_keyframe = 0: with-reference (gain, theta) candidates in the reference's loop
+    order + no-reference ones).  Against the oracle's pvq_theta on the oracle's own pyramids:
+    gains, companded gains, correlation, theta, which searches run, and per slot K, cosine
+    distance and pulses - every field bit-exact."""
+    from testlib import ThetaOut
+    o = oracle()
+    o.orc_pvq_theta_candidates.argtypes = [ctypes.POINTER(ctypes.c_int32)]*2 + [
+        c_int, c_int, ctypes.c_double, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int16),
+        ctypes.POINTER(ThetaOut), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    prm = golden('encoder_params.npz')
+    tag = 'q20_m1'
+    pic_w, pic_h, fw, fh = 128, 96, 128, 96
+    rng = np.random.default_rng(5)
+    src = [synth_plane(fw + 8, fh + 8, 21), synth_plane(fw//2 + 8, fh//2 + 8, 21, 1), synth_plane(fw//2 + 8, fh//2 + 8, 22, 1)]
+    inp = [np.ascontiguousarray(p[4:4 + (fh >> (i > 0)), 4:4 + (fw >> (i > 0))]) for i, p in enumerate(src)]
+    # a "prediction": the frame displaced by a pixel plus a little noise; one flat region (null-ish reference)
+    pred = []
+    for i, p in enumerate(src):
+        h, w = fh >> (i > 0), fw >> (i > 0)
+        q = p[3:3 + h, 5:5 + w].astype(np.int32) + rng.integers(-3, 4, size=(h, w))
+        q[:h//4, :w//4] = 128
+        pred.append(np.clip(q, 0, 255).astype(np.uint8))
+    pf = hip.PFeed(pic_w, pic_h, fw, fh)
+    par = {}
+    for pli in range(3):
+        for level in range(pf.nlevels(pli)):
+            n = (32 >> (pli > 0)) >> level
+            bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+            off, q, beta, qm = level_params(prm, tag, pli, bs, int(pli > 0))
+            par[pli, level] = (n, off, q, beta, qm)
+            pf.set_level(pli, level, qm, q, beta)
+    pf.run(inp, pred)
+    checked = nsearch = nnoref = 0
+    for pli in range(3):
+        dec = int(pli > 0)
+        w, h = fw >> dec, fh >> dec
+        nlev = pf.nlevels(pli)
+        pyr = []
+        for planes in (inp, pred):
+            lev = [np.zeros((h, w), np.int32) for _ in range(nlev)]
+            arr = (ctypes.POINTER(ctypes.c_int32)*nlev)(*[p32(a) for a in lev])
+            c = np.zeros((h, w), np.int32)
+            o.orc_forward_pyramid_plane(p32(c), arr, nlev, pu8(planes[pli]), w, fw//32, fh//32, dec, pic_w, pic_h)
+            pyr.append(lev)
+        for level in range(nlev):
+            n, off, q, beta, qm = par[pli, level]
+            v = pf.view(pli, level)
+            nb, nblk, nbx = v['nbands'], v['nblk'], v['nbx']
+            assert v['nslots'] == 14 and v['nref_slots'] == 12
+            ncoded = min(n*n, 512)
+            for blk in range(nblk):
+                bx, by = blk % nbx, blk//nbx
+                cx = np.zeros(n*n, np.int32)
+                cr = np.zeros(n*n, np.int32)
+                o.orc_raster_to_coding_order(p32(cx), n, p32(pyr[0][level][by*n:, bx*n:][:n, :n].copy()), n)
+                o.orc_raster_to_coding_order(p32(cr), n, p32(pyr[1][level][by*n:, bx*n:][:n, :n].copy()), n)
+                for b in range(nb):
+                    nn = off[b + 1] - off[b]
+                    ns = (nn + 1) & ~1
+                    yo = 0 if b == 0 else off[b]
+                    r = b*nblk + blk
+                    t = ThetaOut()
+                    yr = np.zeros((12, nn), np.int32)
+                    yn = np.zeros((2, nn), np.int32)
+                    o.orc_pvq_theta_candidates(p32(np.ascontiguousarray(cx[off[b]:off[b + 1]])),
+                                               p32(np.ascontiguousarray(cr[off[b]:off[b + 1]])), nn, int(q[b]),
+                                               float(beta[b]), 1, 0, pli,
+                                               p16(np.ascontiguousarray(qm[off[b]:off[b + 1]])),
+                                               ctypes.byref(t), p32(yr), p32(yn))
+                    assert v['g'][r] == t.g and v['gr'][r] == t.gr, (pli, level, blk, b)
+                    assert v['cg'][r] == t.cg and v['cgr'][r] == t.cgr
+                    assert v['corr'][r] == t.corr
+                    assert (v['flags'][r] & 1) == t.theta_searched and ((v['flags'][r] >> 1) & 1) == t.noref_searched
+                    if t.theta_searched:
+                        assert v['theta'][r] == t.theta
+                    ybase = 14*nblk*yo
+                    for c in range(12):
+                        k = v['k'][c, r]
+                        if c < t.nref:
+                            assert k == t.ref_k[c], (pli, level, blk, b, c, k, t.ref_k[c])
+                            assert v['cos_dist'][c, r] == t.ref_cos_dist[c], (pli, level, blk, b, c)
+                            yy = v['y'][ybase + (c*nblk + blk)*ns: ybase + (c*nblk + blk)*ns + nn - 1]
+                            assert np.array_equal(yy, yr[c, :nn - 1]), (pli, level, blk, b, c)
+                            nsearch += 1
+                        else:
+                            assert k == -1
+                    for c in range(2):
+                        k = v['k'][12 + c, r]
+                        if c < t.nnoref:
+                            assert k == t.nr_k[c]
+                            assert v['cos_dist'][12 + c, r] == t.nr_cos_dist[c]
+                            yy = v['y'][ybase + ((12 + c)*nblk + blk)*ns: ybase + ((12 + c)*nblk + blk)*ns + nn]
+                            assert np.array_equal(yy, yn[c])
+                            nnoref += 1
+                        else:
+                            assert k == -1
+                    checked += 1
+    pf.close()
+    assert checked > 2000 and nsearch > 3000 and nnoref > 500, (checked, nsearch, nnoref)
