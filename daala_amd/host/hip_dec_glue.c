@@ -58,6 +58,7 @@ void od_state_mc_predict_cpu(od_state *state, od_img *img_dst);
 /* hip_enc_glue.c */
 int od_hipenc_device_thread(void);
 int od_hipenc_check_mode(void);
+int od_hipenc_pframe_feed(od_state *state, od_img *pred);
 void od_hipdec_thread_cleanup(void);
 int od_hipenc_dering_hook(od_state *state, int16_t *y, int ystride, int16_t *x,
  int xstride, int ln, int sbx, int sby, int nhsb, int nvsb, int q, int xdec,
@@ -912,6 +913,8 @@ void od_state_mc_predict(od_state *state, od_img *img_dst) {
         D.md_valid = md_pyramid(state, img_dst) == 0;
         if (!D.md_valid) D.failed = 1;      /* surfaced by daala_decode_packet_in, no silent host path */
       }
+      /* encoder threads: the frame's prediction exists - the P-frame feed can run */
+      if (D.ctx == NULL && od_hipenc_device_thread() && od_hipenc_pframe_feed(state, img_dst) < 0) D.failed = 1;
       if (D.check || od_hipenc_check_mode()) {
         /* OD_CHECKASM: the reference's own prediction of the same frame; its result stays */
         unsigned char *keep[3];

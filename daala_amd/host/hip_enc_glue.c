@@ -229,6 +229,134 @@ int od_hipenc_dist_hook(daala_enc_ctx *enc, const od_coeff *x, const od_coeff *y
   return 1;
 }
 
+/* ------------------------------------------------------------------------ */
+/* P-frame feed (include/daala_hip.h section 4d).  Called by the od_state_mc_predict binding
+   (hip_dec_glue.c) on an encoder thread right after the frame's prediction exists: from here
+   on both inputs of every pvq_theta call of the frame - the input's and the prediction's
+   transforms at every block size - are fixed, so the device enumerates every candidate of
+   every band while this thread (and a few helpers, for the libm stage) waits; the block-size
+   RDO pass and the final pass then only price. */
+typedef struct pf_stage_job {
+  od_hip_pfeed *pf;
+  int part;
+  int nparts;
+  int rc;
+} pf_stage_job;
+
+static void *pf_stage_thread(void *arg) {
+  pf_stage_job *j;
+  int pli;
+  int level;
+  j = (pf_stage_job *)arg;
+  j->rc = 0;
+  for (pli = 0; pli < 3; pli++) {
+    for (level = 0; level < (pli ? 3 : 4); level++) {
+      long n;
+      long a;
+      long b;
+      n = od_hip_pfeed_nrec(j->pf, pli, level);
+      if (n < 0) {
+        j->rc = (int)n;
+        return NULL;
+      }
+      a = n*j->part/j->nparts;
+      b = n*(j->part + 1)/j->nparts;
+      if (b > a && od_hip_pfeed_host_stage(j->pf, pli, level, a, b) != 0) j->rc = -1;
+    }
+  }
+  return NULL;
+}
+
+static int pf_helpers = 6;        /* HIPENC_PF_THREADS: threads of the feed's libm stage */
+
+int od_hipenc_pframe_feed(od_state *state, od_img *pred) {
+  daala_enc_ctx *enc;
+  const unsigned char *pin[3];
+  const unsigned char *ppr[3];
+  int sin_[3];
+  int spr[3];
+  int pli;
+  int level;
+  double t0;
+  enc = T.enc;
+  T.pf_valid = 0;
+  if (T.pf == NULL || enc == NULL || state != &enc->state || !T.host_pvq
+   || state->frame_type != OD_P_FRAME || state->info.nplanes != 3
+   || enc->use_haar_wavelet || enc->quality[0] == 0) {
+    return 0;
+  }
+  t0 = now_s();
+  for (pli = 0; pli < 3; pli++) {
+    const od_img_plane *ip;
+    int dec;
+    ip = &enc->input_img[enc->curr_frame].planes[pli];
+    dec = pli > 0;
+    if (ip->xstride != 1 || pred->planes[pli].xstride != 1) return 0;
+    pin[pli] = ip->data;
+    sin_[pli] = ip->ystride;
+    ppr[pli] = pred->planes[pli].data;
+    spr[pli] = pred->planes[pli].ystride;
+    for (level = 0; level < (dec ? 3 : 4); level++) {
+      int32_t q[11];
+      double beta[11];
+      int bs;
+      int nb;
+      int b;
+      bs = (dec ? 2 : 3) - level;
+      nb = OD_BAND_OFFSETS[bs][0];
+      for (b = 0; b < 11; b++) {
+        q[b] = 1;
+        beta[b] = 1;
+      }
+      for (b = 0; b < nb; b++) {
+        /* src/pvq_encoder.c:712, src/encode.c:1187 */
+        q[b] = OD_MAXI(1, OD_MAXI(1, state->quantizer[pli])*state->pvq_qm_q4[pli][od_qm_get_index(bs, b + 1)] >> 4);
+        beta[b] = OD_PVQ_BETA[enc->use_activity_masking][pli][bs][b];
+      }
+      if (od_hip_pfeed_set_level(T.pf, pli, level, state->qm + od_qm_offset(bs, dec), q, beta) != 0) return -1;
+    }
+  }
+  if (od_hip_pfeed_gains(T.pf, pin, sin_, ppr, spr) != 0) return -1;
+  {
+    pthread_t th[16];
+    pf_stage_job jobs[16];
+    int n;
+    int i;
+    int bad;
+    n = pf_helpers < 1 ? 1 : pf_helpers > 16 ? 16 : pf_helpers;
+    for (i = 0; i < n; i++) {
+      jobs[i].pf = T.pf;
+      jobs[i].part = i;
+      jobs[i].nparts = n;
+      jobs[i].rc = 0;
+    }
+    for (i = 1; i < n; i++) {
+      if (pthread_create(&th[i], NULL, pf_stage_thread, &jobs[i]) != 0) {
+        /* no thread: this one does that part too */
+        th[i] = 0;
+        pf_stage_thread(&jobs[i]);
+      }
+    }
+    pf_stage_thread(&jobs[0]);
+    bad = jobs[0].rc;
+    for (i = 1; i < n; i++) {
+      if (th[i] != 0) pthread_join(th[i], NULL);
+      bad |= jobs[i].rc;
+    }
+    if (bad) return -1;
+  }
+  if (od_hip_pfeed_search(T.pf) != 0) return -1;
+  for (pli = 0; pli < 3; pli++) {
+    for (level = 0; level < (pli ? 3 : 4); level++) {
+      if (od_hip_pfeed_view(T.pf, pli, level, &T.pfv[pli][level]) != 0) return -1;
+    }
+  }
+  T.pf_valid = 1;
+  T.st.pfeed_frames++;
+  T.st.t_pfeed_s += now_s() - t0;
+  return 1;
+}
+
 #define FDCT_MIN_BS_DEFAULT (1)     /* 4x4 blocks: four cache misses cost more than the transform */
 
 /* fdct_2d entries of the worker's vtable (struct od_state_opt_vtbl, src/state.h:106).
@@ -565,6 +693,7 @@ struct od_hipenc {
   int host_pvq;         /* keyframe od_pvq_encode: 1 hip_pvq_host.c (default), 0 the reference's */
   int time_cpu;         /* per-call timers around the C searches (HIPENC_TIME=1) */
   int sample_every;     /* HIPENC_SAMPLE: re-search every n-th feed candidate (default 256, 0 off) */
+  int pfeed_on;         /* HIPENC_PFEED (default 1): inter frames take the P-frame feed */
   long job_seq;         /* number of jobs submitted so far */
   job *J;               /* the job being worked on, or NULL */
   double t_setup_s;
@@ -587,6 +716,8 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->dering_check_fail += b->dering_check_fail;
   a->dist_dev += b->dist_dev;
   a->dist_check_fail += b->dist_check_fail;
+  a->pfeed_frames += b->pfeed_frames;
+  a->t_pfeed_s += b->t_pfeed_s;
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
@@ -638,6 +769,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   T.dr_valid = 0;
   T.dist_valid = 0;
   T.dist_sb = -1;
+  T.pf_valid = 0;
   od_hipenc_mc_cache_flush();          /* reference frames change between frames */
   (void)od_hipdec_take_failure();
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
@@ -661,6 +793,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   T.lev = NULL;
   T.haar[0] = T.haar[1] = T.haar[2] = NULL;
   T.enc = NULL;
+  T.pf_valid = 0;
   return 0;
 }
 
@@ -733,6 +866,18 @@ static void *worker(void *arg) {
   T.host_pvq = S->host_pvq;
   T.sample_every = S->sample_every;
   enc = worker_encoder(S);
+  if (enc != NULL && S->ctx != NULL && S->p.keyframe_rate > 1 && S->pfeed_on) {
+    od_hip_geometry g;
+    memset(&g, 0, sizeof(g));
+    g.pic_width = S->p.pic_width;
+    g.pic_height = S->p.pic_height;
+    g.frame_width = enc->state.frame_width;
+    g.frame_height = enc->state.frame_height;
+    g.nplanes = 3;
+    g.xdec[1] = g.xdec[2] = 1;
+    g.nslots = 2;
+    T.pf = od_hip_pfeed_create(S->device, &g);      /* NULL: inter frames are searched on the host */
+  }
   if (enc != NULL && S->ctx != NULL) {
     int xdec[3] = {0, 1, 1};
     int pli;
@@ -833,6 +978,8 @@ static void *worker(void *arg) {
     pthread_cond_broadcast(&S->cv);
   }
   pthread_mutex_unlock(&S->mu);
+  if (T.pf != NULL) od_hip_pfeed_destroy(T.pf);
+  T.pf = NULL;
   if (T.dr != NULL) od_hip_dering_destroy(T.dr);
   free(T.dr_out[0]);
   free(T.dr_out[1]);
@@ -893,6 +1040,10 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     S->time_cpu = e != NULL && atoi(e) != 0;
     e = getenv("HIPENC_FDCT_MIN_BS");
     if (e != NULL) fdct_min_bs = atoi(e);
+    e = getenv("HIPENC_PFEED");
+    S->pfeed_on = e == NULL || atoi(e) != 0;
+    e = getenv("HIPENC_PF_THREADS");
+    if (e != NULL) pf_helpers = atoi(e);
   }
   S->use_device = use_device;
   S->device = device;

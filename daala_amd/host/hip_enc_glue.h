@@ -45,6 +45,8 @@ typedef struct od_hipenc_stats {
   int64_t dering_check_fail; /* check mode: device block != C od_dering (must be 0) */
   int64_t dist_dev;        /* od_compute_dist calls of the deringing on/off loop answered from the device pass */
   int64_t dist_check_fail; /* check mode: device distortion != the reference's od_compute_dist (must be 0) */
+  int64_t pfeed_frames;    /* inter frames whose bands took the complete candidate lists of the P-frame feed */
+  double t_pfeed_s;        /* seconds the coding thread waited for P-frame feeds (device passes + libm stage) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* upload done -> device batch enqueued (includes t_compand_s), wall */

@@ -28,6 +28,17 @@ typedef struct glue_tls {
   int dist_sb;                    /* superblock whose two od_compute_dist calls come next, or -1 */
   int dist_calls;
   int dr_error;
+  /* the block being coded by od_pvq_encode: which feed records its bands read (hip_pvq_host.c) */
+  const od_hip_feed_level *cur_L;   /* keyframe feed of the block's level, or NULL */
+  const od_hip_pfeed_level *cur_P;  /* P-frame feed of the block's (plane, level), or NULL */
+  int cur_blk;
+  int cur_band;                   /* next band pvq_theta is called for */
+  int cur_bs;
+  int in_pure;                    /* inside the untouched reference od_pvq_encode (check mode) */
+  /* P-frame feed of the inter frame being coded */
+  od_hip_pfeed *pf;
+  int pf_valid;
+  od_hip_pfeed_level pfv[3][4];
   od_hipenc_stats st;
 } glue_tls;
 

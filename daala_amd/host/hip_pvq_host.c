@@ -1,7 +1,9 @@
-/* hip_pvq_host.c - host side of SURVEY rows A16/A19: od_pvq_encode() and pvq_theta()
- * restated (keyframes and inter frames) so that they CONSUME the device feed where there is
- * one (keyframe luma) instead of redoing the device's work, plus a rate-only form of
- * od_pvq_rate() and one search context per band for the searches that stay here.
+/* hip_pvq_host.c - host side of SURVEY rows A16/A19: the band decision pvq_theta() as a
+ * CONSUMER of the device feeds - keyframe luma: the no-reference candidates (section 4b of
+ * include/daala_hip.h); inter frames: the complete candidate list of every band (4d) - plus a
+ * rate-only form of od_pvq_rate() and one search context per band for what stays here.
+ * od_pvq_encode() itself is the reference's function, compiled from its source by the build
+ * recipe with its pvq_theta / checkpoint call sites bound here (Makefile: pvq_encoder.o).
  *
  * What the reference does per band (src/pvq_encoder.c:311-511) and what happens here:
  *   gain of x (:360, n multiply-adds + pow)   -> read from the feed (g exact from the
@@ -325,360 +327,508 @@ static double pvq_rate_with_codeword(double rate, int qg, int icgr, int theta, i
 }
 
 /* ------------------------------------------------------------------------ */
-static int neg_interleave(int x, int ref) {       /* src/pvq_encoder.c:236-240 */
-  if (x < ref) return -2*(x - ref) - 1;
-  else if (x < 2*ref) return 2*(x - ref);
-  else return x - 1;
+/* The band decision.  One band of one block = a set of CANDIDATES - the null / skip case, the
+   with-reference (gain i, angle j) pairs of src/pvq_encoder.c:406-417, the no-reference gains
+   of :457 - each with a distortion and a rate; the cheapest wins (:435 '<', :469 '<=').  What
+   differs between the sources of a band is only where a candidate's codeword and cosine
+   distance come from:
+     keyframe feed (4b)   no-reference candidates of keyframe luma
+     P-frame feed (4d)    every candidate of every band of an inter frame
+     this file            a search on the host (hip_pvq_search.c) for whatever no feed covers
+   so the function below is written around a small candidate record and one pricing step,
+   not around the reference's control flow.  Arithmetic that decides anything keeps the
+   reference's operand order (cited line by line); libm calls are this process's. */
+
+typedef struct band_src {
+  const od_hip_feed_level *L;     /* keyframe feed of the block's level, or NULL */
+  const od_hip_pfeed_level *P;    /* P-frame feed of the block's (plane, level), or NULL */
+  size_t rec;                     /* band*nblk + block */
+  size_t nrec;
+  int band;
+  int blk;
+} band_src;
+
+typedef struct band_best {
+  double cost;
+  double dist;
+  double qtheta;
+  int qg;
+  int k;
+  int itheta;
+  int max_theta;
+  int noref;
+  const od_coeff *y;              /* winning codeword, or NULL: none (gain 0) */
+} band_best;
+
+/* widen a run of the feeds' 16-bit pulses */
+static inline void widen(od_coeff *dst, const int16_t *src, int n) {
+  int j;
+  for (j = 0; j < n; j++) dst[j] = src[j];
 }
 
-/* pvq_theta (src/pvq_encoder.c:311-511).  L/band/blk: the feed records of this band
-   (keyframe luma with a device feed), or L == NULL. */
-static int hip_pvq_theta(od_coeff *out, const od_coeff *x0, const od_coeff *r0, int n,
- int q0, od_coeff *y, int *itheta, int *max_theta, int *vk, double beta,
- double *skip_diff, int robust, int is_keyframe, int pli, const od_adapt_ctx *adapt,
- int bs, const int16_t *qm, const int16_t *qm_inv, const od_hip_feed_level *L, int band,
- int blk) {
-  double g;
-  double gr;
+/* src/pvq_encoder.c:236-240 */
+static inline int interleave_gain(int x, int ref) {
+  if (x < ref) return -2*(x - ref) - 1;
+  if (x < 2*ref) return 2*(x - ref);
+  return x - 1;
+}
+
+/* the codeword cache of one band: equal codewords have equal rates while the adaptation
+   state stands still (it does within a band) */
+typedef struct cw_cache {
+  od_coeff y[OD_HIP_SEARCH_KCACHE][128];
+  double rate[OD_HIP_SEARCH_KCACHE];
+  int k[OD_HIP_SEARCH_KCACHE];
+  int n;
+} cw_cache;
+
+static double cached_codeword_rate(cw_cache *C, const od_adapt_ctx *adapt, const od_coeff *y, int k,
+ int n, int bs) {
+  double cw;
+  int e;
+  if (k <= 0) return 0;
+  for (e = 0; e < C->n; e++) {
+    if (C->k[e] == k && memcmp(C->y[e], y, sizeof(od_coeff)*(n - 1)) == 0) return C->rate[e];
+  }
+  cw = pvq_codeword_rate(adapt, y, k, n, 0, bs);
+  if (C->n < OD_HIP_SEARCH_KCACHE && n - 1 <= 128) {
+    C->k[C->n] = k;
+    C->rate[C->n] = cw;
+    memcpy(C->y[C->n], y, sizeof(od_coeff)*(n - 1));
+    C->n++;
+  }
+  return cw;
+}
+
+/* x = the input reflected by the reference's Householder vector with the reference's axis
+   dropped (src/pvq_encoder.c:402-404), r = that vector: what the with-reference searches and
+   the synthesis work on */
+static void reflect(double *x, double *r, const od_coeff *x0, const od_coeff *r0, const int16_t *qm,
+ int n, double gr, int *m, int *s) {
+  int i;
+  for (i = 0; i < n; i++) {
+    x[i] = x0[i]*qm[i]*OD_QM_SCALE_1;
+    r[i] = r0[i]*qm[i]*OD_QM_SCALE_1;
+  }
+  *m = od_compute_householder(r, n, gr, s);
+  od_apply_householder(x, r, n);
+  for (i = *m; i < n - 1; i++) x[i] = x[i + 1];
+}
+
+/* timing of the host searches (HIPENC_TIME=1) */
+static inline double timed_search(od_hip_search *sc, int k, od_coeff *y, double g2, int cls) {
+  double t0;
+  double r;
+  if (!T.time_cpu) return od_hip_search_run(sc, k, y, g2);
+  t0 = od_hipenc_now();
+  r = od_hip_search_run(sc, k, y, g2);
+  t0 = od_hipenc_now() - t0;
+  T.st.search_cpu_s += t0;
+  T.st.search_class_s[cls] += t0;
+  return r;
+}
+
+/* pvq_theta (src/pvq_encoder.c:311-511), same interface; the feed context of the block being
+   coded comes from the calling thread's state (set by od_pvq_encode below). */
+int od_ref_pvq_theta(od_coeff *out, od_coeff *x0, od_coeff *r0, int n, int q0, od_coeff *y,
+ int *itheta, int *max_theta, int *vk, double beta, double *skip_diff, int robust,
+ int is_keyframe, int pli, const od_adapt_ctx *adapt, int bs, const int16_t *qm,
+ const int16_t *qm_inv);
+
+int pvq_theta(od_coeff *out, od_coeff *x0, od_coeff *r0, int n, int q0, od_coeff *y,
+ int *itheta, int *max_theta, int *vk, double beta, double *skip_diff, int robust,
+ int is_keyframe, int pli, const od_adapt_ctx *adapt, int bs, const int16_t *qm,
+ const int16_t *qm_inv) {
+  const double lambda = OD_PVQ_LAMBDA;
+  const double gain_weight = 1.4;
+  band_src S;
+  band_best B;
+  od_coeff y_tmp[MAXN];
+  od_coeff y_keep[MAXN];          /* the incumbent's codeword when it came from y_tmp */
   double x[MAXN];
   double r[MAXN];
-  od_coeff y_tmp[MAXN];
-  od_coeff feed_y[2][MAXN];       /* the feed's 16-bit pulses of the two candidates, widened */
-  const od_coeff *y_best;
-  int i;
-  int k;
+  double g;
+  double gr;
   double cg;
   double cgr;
-  int icgr;
-  int qg;
-  double best_cost;
-  double best_dist;
-  double dist;
-  int s;
-  int m;
-  double theta;
   double corr;
-  int best_k;
-  double best_qtheta;
+  double theta;
   double gain_offset;
-  int noref;
-  double lambda;
   double skip_dist;
-  int cfl_enabled;
-  int skip;
-  double gain_weight;
+  int icgr;
+  int theta_search;
+  int noref_search;
+  int have_xr;                    /* x[] / r[] hold the scaled input and reference */
   int r_null;
-  int feed_ok;
-  size_t rec;
-  size_t nrec;
-  lambda = OD_PVQ_LAMBDA;
-  gain_weight = 1.4;
-  rec = 0;
-  nrec = 0;
-  feed_ok = 0;
-  r_null = od_vector_is_null(r0, n);
-  if (L != NULL) {
-    rec = (size_t)band*L->nblk + blk;
-    nrec = (size_t)L->nbands*L->nblk;
-    /* :360 - g: the device's sqrt of the exact sum; cg: od_gain_compand of that g, computed
-       by THIS process's libm between the two device passes (od_hip_enc_feed_compand), i.e.
-       the value od_pvq_compute_gain returns here */
-    g = L->g[rec];
-    cg = L->cg[rec];
-    feed_ok = 1;
+  int cfl;
+  int nodesync;
+  int i;
+  int m;
+  int s;
+  if (!T.host_pvq) {
+    return od_ref_pvq_theta(out, x0, r0, n, q0, y, itheta, max_theta, vk, beta, skip_diff, robust,
+     is_keyframe, pli, adapt, bs, qm, qm_inv);
+  }
+  /* ---- which feed covers this band */
+  memset(&S, 0, sizeof(S));
+  S.band = T.cur_band++;
+  S.blk = T.cur_blk;
+  if (T.cur_L != NULL) {
+    S.L = T.cur_L;
+    S.rec = (size_t)S.band*S.L->nblk + S.blk;
+    S.nrec = (size_t)S.L->nbands*S.L->nblk;
+  }
+  else if (T.cur_P != NULL) {
+    S.P = T.cur_P;
+    S.rec = (size_t)S.band*S.P->nblk + S.blk;
+    S.nrec = (size_t)S.P->nbands*S.P->nblk;
+  }
+  nodesync = robust || is_keyframe;
+  cfl = is_keyframe && pli != 0 && !OD_DISABLE_CFL;
+  have_xr = 0;
+  m = 0;
+  s = 1;
+  theta = 0;
+  /* ---- gains, correlation (:353-381) */
+  if (S.P != NULL) {
+    /* all of it from the feed: exact sums from the device, pow / acos by this process's libm
+       in the feed's host stage */
+    g = S.P->g[S.rec];
+    gr = S.P->gr[S.rec];
+    cg = S.P->cg[S.rec];
+    cgr = S.P->cgr[S.rec];
+    corr = S.P->corr[S.rec];
+    r_null = S.P->isnull[S.rec];
+    theta_search = S.P->flags[S.rec] & 1;
+    noref_search = (S.P->flags[S.rec] >> 1) & 1;
+    if (theta_search) theta = S.P->theta[S.rec];
     if (T.check) {
       double gc;
-      double cgc;
-      cgc = od_pvq_compute_gain((od_coeff *)x0, n, q0, &gc, beta, qm);
-      if (gc != g || cgc != cg) {
+      double grc;
+      if (od_pvq_compute_gain(x0, n, q0, &gc, beta, qm) != cg || gc != g
+       || od_pvq_compute_gain(r0, n, q0, &grc, beta, qm) != cgr || grc != gr) {
         T.st.g2_mismatch++;
         T.st.check_fail++;
       }
     }
   }
-  else cg = od_pvq_compute_gain((od_coeff *)x0, n, q0, &g, beta, qm);
-  corr = 0;
-  if (!r_null) {
-    /* :353-361 */
-    for (i = 0; i < n; i++) {
-      x[i] = x0[i]*qm[i]*OD_QM_SCALE_1;
-      r[i] = r0[i]*qm[i]*OD_QM_SCALE_1;
-      corr += x[i]*r[i];
-    }
-    cgr = od_pvq_compute_gain((od_coeff *)r0, n, q0, &gr, beta, qm);
-  }
   else {
-    /* a null reference: corr is a sum of zeros, gr = sqrt(0) and od_gain_compand(0) = 0 */
+    r_null = od_vector_is_null(r0, n);
+    if (S.L != NULL) {
+      /* g: the device's sqrt of the exact sum; cg: od_gain_compand of that g by THIS process's
+         libm between the two device passes (od_hip_enc_feed_compand) */
+      g = S.L->g[S.rec];
+      cg = S.L->cg[S.rec];
+      if (T.check) {
+        double gc;
+        if (od_pvq_compute_gain(x0, n, q0, &gc, beta, qm) != cg || gc != g) {
+          T.st.g2_mismatch++;
+          T.st.check_fail++;
+        }
+      }
+    }
+    else cg = od_pvq_compute_gain(x0, n, q0, &g, beta, qm);
+    corr = 0;
     gr = 0;
     cgr = 0;
+    if (!r_null) {
+      for (i = 0; i < n; i++) {
+        x[i] = x0[i]*qm[i]*OD_QM_SCALE_1;
+        r[i] = r0[i]*qm[i]*OD_QM_SCALE_1;
+        corr += x[i]*r[i];
+      }
+      have_xr = 1;
+      cgr = od_pvq_compute_gain(r0, n, q0, &gr, beta, qm);
+    }
+    /* a null reference: corr is a sum of zeros, gr = sqrt(0) and od_gain_compand(0) = 0 */
+    corr = corr/(1e-100 + g*gr);
+    corr = OD_MAXF(OD_MINF(corr, 1.), -1.);
+    theta_search = n <= OD_MAX_PVQ_SIZE && !r_null && corr > 0;
+    noref_search = -1;            /* decided below, once cg is final */
   }
-  cfl_enabled = is_keyframe && pli != 0 && !OD_DISABLE_CFL;
-  if (cfl_enabled) cgr = 1;
+  if (cfl) cgr = 1;
   icgr = (int)floor(.5 + cgr);
   gain_offset = cgr - icgr;
-  /* null case: gain 0, no pulse; its rate is 0 (:368-372) */
-  qg = 0;
-  dist = gain_weight*cg*cg;
-  best_dist = dist;
-  best_cost = dist + lambda*0.;
-  noref = 1;
-  best_k = 0;
-  *itheta = -1;
-  *max_theta = 0;
-  OD_CLEAR(y, n);
-  y_best = NULL;
-  best_qtheta = 0;
-  m = 0;
-  s = 1;
-  corr = corr/(1e-100 + g*gr);
-  corr = OD_MAXF(OD_MINF(corr, 1.), -1.);
-  if (is_keyframe) skip_dist = gain_weight*cg*cg;
-  else skip_dist = gain_weight*(cg - cgr)*(cg - cgr) + cgr*cg*(2 - 2*corr);
-  if (!is_keyframe) {
-    /* noref with gain 0 is not allowed on inter frames, skip is (:385-398); the rate of
-       (qg = 0, theta = 0, no codeword) is 0 */
-    double scgr;
-    scgr = OD_MAXF(0, gain_offset);
-    if (icgr == 0) {
-      best_dist = gain_weight*(cg - scgr)*(cg - scgr) + scgr*cg*(2 - 2*corr);
-    }
-    best_cost = best_dist + lambda*0.;
-    best_qtheta = 0;
-    *itheta = 0;
-    *max_theta = 0;
-    noref = 0;
+  if (noref_search < 0) {
+    noref_search = n <= OD_MAX_PVQ_SIZE && ((is_keyframe && pli == 0) || corr < .5 || cg < 2.);
   }
-  if (n <= OD_MAX_PVQ_SIZE && !r_null && corr > 0) {
-    /* :399-448, the reference's arithmetic: its input depends on the reconstruction of the
-       neighbours (or of luma), so there is nothing the device could have prepared */
+  /* ---- the incumbent every candidate has to beat: gain 0, no pulse, rate 0 (:368-398) */
+  B.qg = 0;
+  B.k = 0;
+  B.qtheta = 0;
+  B.y = NULL;
+  B.dist = gain_weight*cg*cg;
+  B.cost = B.dist + lambda*0.;
+  if (is_keyframe) {
+    B.noref = 1;
+    B.itheta = -1;
+    B.max_theta = 0;
+    skip_dist = gain_weight*cg*cg;
+  }
+  else {
+    /* an inter band cannot be "no reference, gain 0"; it can be skipped */
+    double scgr;
+    skip_dist = gain_weight*(cg - cgr)*(cg - cgr) + cgr*cg*(2 - 2*corr);
+    scgr = OD_MAXF(0, gain_offset);
+    if (icgr == 0) B.dist = gain_weight*(cg - scgr)*(cg - scgr) + scgr*cg*(2 - 2*corr);
+    B.cost = B.dist + lambda*0.;
+    B.noref = 0;
+    B.itheta = 0;
+    B.max_theta = 0;
+  }
+  /* ---- with-reference candidates (:399-448) */
+  if (theta_search) {
     od_hip_search sc;
-    /* codewords already priced in this band: (k, y) -> codeword rate */
-    od_coeff seen_y[OD_HIP_SEARCH_KCACHE][128];
-    double seen_rate[OD_HIP_SEARCH_KCACHE];
-    int seen_k[OD_HIP_SEARCH_KCACHE];
-    int nseen;
-    nseen = 0;
-    theta = acos(corr);
-    m = od_compute_householder(r, n, gr, &s);
-    od_apply_householder(x, r, n);
-    for (i = m; i < n - 1; i++) x[i] = x[i + 1];
-    od_hip_search_begin(&sc, x, n - 1);
-    for (i = OD_MAXI(1, (int)floor(cg - gain_offset) - 1);
-     i <= (int)ceil(cg - gain_offset); i++) {
-      int j;
+    cw_cache cache;
+    int slot;
+    int searching;                /* host searches: the reflected vector is set up */
+    const int16_t *py;
+    int ns;
+    cache.n = 0;
+    slot = 0;
+    searching = 0;
+    py = NULL;
+    ns = (n + 1) & ~1;
+    if (S.P != NULL) py = S.P->y + (size_t)S.P->nslots*S.P->nblk*(S.band == 0 ? 0 : S.P->off[S.band]);
+    else {
+      theta = acos(corr);
+      m = od_compute_householder(r, n, gr, &s);
+      od_apply_householder(x, r, n);
+      for (i = m; i < n - 1; i++) x[i] = x[i + 1];
+      od_hip_search_begin(&sc, x, n - 1);
+      searching = 1;
+      have_xr = 2;                /* r[] is now the Householder vector, x[] is consumed */
+    }
+    for (i = OD_MAXI(1, (int)floor(cg - gain_offset) - 1); i <= (int)ceil(cg - gain_offset); i++) {
       double qcg;
       int ts;
+      int j;
       qcg = i + gain_offset;
       ts = od_pvq_compute_max_theta(qcg, beta);
       for (j = OD_MAXI(0, (int)floor(.5 + theta*2/M_PI*ts) - 2);
-       j <= OD_MINI(ts - 1, (int)ceil(theta*2/M_PI*ts)); j++) {
-        double cos_dist;
-        double cost;
-        double dist_theta;
+       j <= OD_MINI(ts - 1, (int)ceil(theta*2/M_PI*ts)); j++, slot++) {
         double qtheta;
-        double t0;
+        double cos_dist;
+        double dist;
+        double cost;
+        const od_coeff *yc;
+        int k;
         qtheta = od_pvq_compute_theta(j, ts);
-        k = od_pvq_compute_k(qcg, j, qtheta, 0, n, beta, robust || is_keyframe);
-        t0 = T.time_cpu ? od_hipenc_now() : 0;
-        cos_dist = od_hip_search_run(&sc, k, y_tmp, qcg*cg*sin(theta)*sin(qtheta));
-        if (T.time_cpu) {
-          double dt;
-          dt = od_hipenc_now() - t0;
-          T.st.search_cpu_s += dt;
-          T.st.search_class_s[(pli != 0)*2 + 1] += dt;
-        }
-        T.st.cpu_other++;
-        dist_theta = 2 - 2*cos(theta - qtheta)
-         + sin(theta)*sin(qtheta)*(2 - 2*cos_dist);
-        dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*dist_theta;
-        /* The codeword's bits are >= 0 and floating-point + and * are monotonic, so the
-           cost is at least the cost with the codeword bits left out (k = 0 below: only the
-           theta/gain terms of od_pvq_rate, which can be negative).  A candidate that cannot
-           beat the incumbent even so is not priced. */
-        if (!(dist + lambda*od_hip_pvq_rate(i, icgr, j, ts, adapt, NULL, 0, n, is_keyframe, pli, bs)
-         < best_cost)) continue;
-        {
-          double cw;
-          int e;
-          cw = 0;
-          if (k > 0) {
-            for (e = 0; e < nseen; e++) {
-              if (seen_k[e] == k && memcmp(seen_y[e], y_tmp, sizeof(od_coeff)*(n - 1)) == 0) break;
+        k = od_pvq_compute_k(qcg, j, qtheta, 0, n, beta, nodesync);
+        if (py != NULL && slot < S.P->nref_slots && S.P->k[(size_t)slot*S.nrec + S.rec] == k) {
+          /* the feed's slot for this (i, j): K re-derived here must be the feed's */
+          cos_dist = S.P->cos_dist[(size_t)slot*S.nrec + S.rec];
+          widen(y_tmp, py + ((size_t)slot*S.P->nblk + S.blk)*ns, n - 1);
+          T.st.dev_hits++;
+          if (T.check || (T.sample_every > 0 && ++T.sample_ctr >= T.sample_every)) {
+            /* the sampled re-search that keeps a silently wrong feed from going unnoticed */
+            od_coeff yv[MAXN];
+            double cv;
+            T.sample_ctr = 0;
+            T.st.resampled++;
+            if (!searching) {
+              reflect(x, r, x0, r0, qm, n, gr, &m, &s);
+              od_hip_search_begin(&sc, x, n - 1);
+              searching = 1;
+              have_xr = 2;
             }
-            if (e < nseen) cw = seen_rate[e];
-            else {
-              cw = pvq_codeword_rate(adapt, y_tmp, k, n, 0, bs);
-              if (nseen < OD_HIP_SEARCH_KCACHE && n - 1 <= 128) {
-                seen_k[nseen] = k;
-                seen_rate[nseen] = cw;
-                memcpy(seen_y[nseen], y_tmp, sizeof(od_coeff)*(n - 1));
-                nseen++;
-              }
+            cv = od_hip_search_run(&sc, k, yv, qcg*cg*sin(theta)*sin(qtheta));
+            if (cv != cos_dist || memcmp(yv, y_tmp, sizeof(od_coeff)*(n - 1)) != 0) T.st.check_fail++;
+          }
+        }
+        else {
+          if (py != NULL) {
+            /* the feed does not hold this candidate (resolution beyond its table, a slot it
+               does not reach): searched here */
+            T.st.lost_sync++;
+            if (!searching) {
+              reflect(x, r, x0, r0, qm, n, gr, &m, &s);
+              od_hip_search_begin(&sc, x, n - 1);
+              searching = 1;
+              have_xr = 2;
             }
           }
-          cost = dist + lambda*pvq_rate_with_codeword(cw, i, icgr, j, ts, is_keyframe, pli);
+          cos_dist = timed_search(&sc, k, y_tmp, qcg*cg*sin(theta)*sin(qtheta), (pli != 0)*2 + 1);
+          T.st.cpu_other++;
         }
-        if (cost < best_cost) {
-          best_cost = cost;
-          best_dist = dist;
-          qg = i;
-          best_k = k;
-          best_qtheta = qtheta;
-          *itheta = j;
-          *max_theta = ts;
-          noref = 0;
-          OD_COPY(y, y_tmp, n - 1);
+        /* :428-431 */
+        {
+          double dist_theta;
+          dist_theta = 2 - 2*cos(theta - qtheta) + sin(theta)*sin(qtheta)*(2 - 2*cos_dist);
+          dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*dist_theta;
+        }
+        /* The codeword's bits are >= 0 and + and * are monotonic, so the cost is at least the
+           cost with the codeword bits left out (only the theta / gain terms of od_pvq_rate, which
+           can be negative).  A candidate that cannot beat the incumbent even so is not priced. */
+        if (!(dist + lambda*pvq_rate_with_codeword(0, i, icgr, j, ts, is_keyframe, pli) < B.cost)) continue;
+        yc = y_tmp;
+        cost = dist + lambda*pvq_rate_with_codeword(cached_codeword_rate(&cache, adapt, yc, k, n, bs), i, icgr,
+         j, ts, is_keyframe, pli);
+        if (cost < B.cost) {
+          B.cost = cost;
+          B.dist = dist;
+          B.qg = i;
+          B.k = k;
+          B.qtheta = qtheta;
+          B.itheta = j;
+          B.max_theta = ts;
+          B.noref = 0;
+          OD_COPY(y_keep, yc, n - 1);
+          B.y = y_keep;
         }
       }
     }
   }
-  if (n <= OD_MAX_PVQ_SIZE && ((is_keyframe && pli == 0) || corr < .5 || cg < 2.)) {
-    /* :452-481 */
+  /* ---- no-reference candidates (:452-481) */
+  if (noref_search) {
+    od_hip_search sc;
+    const int16_t *py;
+    int ns;
+    int base_slot;
     int c;
-    int from_feed;
-    from_feed = 0;
-    if (feed_ok) {
+    int fed;                      /* candidates come from a feed */
+    int searching;
+    ns = (n + 1) & ~1;
+    py = NULL;
+    base_slot = 0;
+    fed = 0;
+    searching = 0;
+    if (S.L != NULL) {
       /* the candidates the device enumerated must be the ones this loop visits: gains
-         max(1, floor(cg)) .. ceil(cg), K recomputed here (the independent value that
-         exposes a feed that is corrupt or out of step) */
+         max(1, floor(cg)) .. ceil(cg), K recomputed here (the independent value that exposes
+         a feed that is corrupt or out of step) */
       int nc;
       nc = 0;
       for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++) nc++;
-      from_feed = nc == L->ncand[rec] && nc <= 2;
-      for (c = 0; from_feed && c < nc; c++) {
+      fed = nc == S.L->ncand[S.rec] && nc <= 2;
+      py = S.L->y + (size_t)2*S.L->nblk*(S.band == 0 ? 0 : S.L->off[S.band]);
+      for (c = 0; fed && c < nc; c++) {
         const int16_t *yc;
         double cd;
         int sum;
         int j;
         i = OD_MAXI(1, (int)floor(cg)) + c;
-        if (L->qg[c*nrec + rec] != i
-         || L->k[c*nrec + rec] != od_pvq_compute_k(i, -1, -1, 1, n, beta, robust || is_keyframe)) from_feed = 0;
+        if (S.L->qg[c*S.nrec + S.rec] != i
+         || S.L->k[c*S.nrec + S.rec] != od_pvq_compute_k(i, -1, -1, 1, n, beta, nodesync)) fed = 0;
         /* a codeword of the search has exactly K pulses and a cosine in [0, 1]: cheap
-           integrity checks of the two fields that are taken on trust.  16-bit pulses, band b
-           at 2*nblk*yo[b] in runs of ns[b] (include/daala_hip.h section 4b). */
-        yc = L->y + (size_t)2*L->nblk*(band == 0 ? 0 : L->off[band]) + ((size_t)c*L->nblk + blk)*((n + 1) & ~1);
+           integrity checks of the two fields that are taken on trust */
+        yc = py + ((size_t)c*S.L->nblk + S.blk)*ns;
         sum = 0;
         for (j = 0; j < n; j++) sum += abs(yc[j]);
-        cd = L->cos_dist[c*nrec + rec];
-        if (sum != L->k[c*nrec + rec] || !(cd >= 0 && cd <= 1.0000001)) from_feed = 0;
+        cd = S.L->cos_dist[c*S.nrec + S.rec];
+        if (sum != S.L->k[c*S.nrec + S.rec] || !(cd >= 0 && cd <= 1.0000001)) fed = 0;
       }
-      if (!from_feed) T.st.lost_sync++;
+      if (!fed) T.st.lost_sync++;
     }
-    if (from_feed) {
-      const int16_t *yb;
-      int ns;
-      ns = (n + 1) & ~1;
-      yb = L->y + (size_t)2*L->nblk*(band == 0 ? 0 : L->off[band]) + (size_t)blk*ns;
-      c = 0;
-      for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++, c++) {
-        double cos_dist;
-        double cost;
-        double qcg;
-        od_coeff *yc;
-        int j;
-        qcg = i;
-        k = L->k[c*nrec + rec];
-        cos_dist = L->cos_dist[c*nrec + rec];
-        yc = feed_y[c];
-        for (j = 0; j < n; j++) yc[j] = yb[(size_t)c*L->nblk*ns + j];
+    else if (S.P != NULL) {
+      fed = 1;
+      base_slot = S.P->nref_slots;
+      py = S.P->y + (size_t)S.P->nslots*S.P->nblk*(S.band == 0 ? 0 : S.P->off[S.band]);
+    }
+    c = 0;
+    for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++, c++) {
+      double qcg;
+      double cos_dist;
+      double dist;
+      double cost;
+      int k;
+      int from_feed;
+      qcg = i;
+      k = od_pvq_compute_k(qcg, -1, -1, 1, n, beta, nodesync);
+      from_feed = 0;
+      if (fed && S.L != NULL) {
+        from_feed = 1;
+        cos_dist = S.L->cos_dist[c*S.nrec + S.rec];
+        widen(y_tmp, py + ((size_t)c*S.L->nblk + S.blk)*ns, n);
+      }
+      else if (fed && c < 2 && S.P->k[(size_t)(base_slot + c)*S.nrec + S.rec] == k) {
+        from_feed = 1;
+        cos_dist = S.P->cos_dist[(size_t)(base_slot + c)*S.nrec + S.rec];
+        widen(y_tmp, py + ((size_t)(base_slot + c)*S.P->nblk + S.blk)*ns, n);
+      }
+      if (from_feed) {
+        T.st.dev_hits++;
         if (T.check || (T.sample_every > 0 && ++T.sample_ctr >= T.sample_every)) {
-          /* OD_CHECKASM for the candidate: always in check mode, and on every
-             sample_every-th candidate otherwise (the sampled re-search that keeps a silently
-             wrong feed from going unnoticed; HIPENC_SAMPLE, default 1 in 256) */
+          /* OD_CHECKASM for the candidate: always in check mode, and on every sample_every-th
+             candidate otherwise (HIPENC_SAMPLE, default 1 in 256) */
           double x1[MAXN];
+          od_coeff yv[MAXN];
           double rc;
           int j;
           T.sample_ctr = 0;
           T.st.resampled++;
           for (j = 0; j < n; j++) x1[j] = x0[j]*qm[j]*OD_QM_SCALE_1;
-          rc = od_ref_pvq_search_rdo_double_cpu(x1, n, k, y_tmp, qcg*cg);
-          if (rc != cos_dist || memcmp(y_tmp, yc, sizeof(od_coeff)*n) != 0) T.st.check_fail++;
-        }
-        T.st.dev_hits++;
-        dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
-        if (!(dist <= best_cost)) continue;         /* no-reference rate = codeword bits >= 0 */
-        cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, yc, k, n, is_keyframe, pli, bs);
-        if (cost <= best_cost) {
-          best_cost = cost;
-          best_dist = dist;
-          qg = i;
-          noref = 1;
-          best_k = k;
-          *itheta = -1;
-          *max_theta = 0;
-          y_best = yc;
+          rc = od_ref_pvq_search_rdo_double_cpu(x1, n, k, yv, qcg*cg);
+          if (rc != cos_dist || memcmp(yv, y_tmp, sizeof(od_coeff)*n) != 0) T.st.check_fail++;
         }
       }
+      else {
+        if (!searching) {
+          double x1[MAXN];
+          int j;
+          for (j = 0; j < n; j++) x1[j] = x0[j]*qm[j]*OD_QM_SCALE_1;
+          od_hip_search_begin(&sc, x1, n);
+          searching = 1;
+          if (fed) T.st.lost_sync++;
+        }
+        cos_dist = timed_search(&sc, k, y_tmp, qcg*cg, (pli != 0)*2);
+        if (S.L != NULL) T.st.cpu_noref_luma++;
+        else T.st.cpu_other++;
+      }
+      dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
+      if (!(dist <= B.cost)) continue;            /* no-reference rate = codeword bits >= 0 */
+      cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, y_tmp, k, n, is_keyframe, pli, bs);
+      if (cost <= B.cost) {
+        B.cost = cost;
+        B.dist = dist;
+        B.qg = i;
+        B.noref = 1;
+        B.k = k;
+        B.itheta = -1;
+        B.max_theta = 0;
+        OD_COPY(y_keep, y_tmp, n);
+        B.y = y_keep;
+      }
+    }
+  }
+  /* ---- hand the winner over and synthesise like the decoder would (:483-503) */
+  if (B.y != NULL) OD_COPY(y, B.y, B.noref ? n : n - 1);
+  else OD_CLEAR(y, n);
+  *itheta = B.itheta;
+  *max_theta = B.max_theta;
+  *vk = B.k;
+  {
+    int skip;
+    skip = 0;
+    if (B.noref) {
+      if (B.qg == 0) skip = OD_PVQ_SKIP_ZERO;
     }
     else {
-      double x1[MAXN];
-      od_hip_search sc;
-      for (i = 0; i < n; i++) x1[i] = x0[i]*qm[i]*OD_QM_SCALE_1;
-      od_hip_search_begin(&sc, x1, n);
-      for (i = OD_MAXI(1, (int)floor(cg)); i <= ceil(cg); i++) {
-        double cos_dist;
-        double cost;
-        double qcg;
-        double t0;
-        qcg = i;
-        k = od_pvq_compute_k(qcg, -1, -1, 1, n, beta, robust || is_keyframe);
-        t0 = T.time_cpu ? od_hipenc_now() : 0;
-        cos_dist = od_hip_search_run(&sc, k, y_tmp, qcg*cg);
-        if (T.time_cpu) {
-          double dt;
-          dt = od_hipenc_now() - t0;
-          T.st.search_cpu_s += dt;
-          T.st.search_class_s[(pli != 0)*2] += dt;
-        }
-        if (L != NULL) T.st.cpu_noref_luma++;
-        else T.st.cpu_other++;
-        dist = gain_weight*(qcg - cg)*(qcg - cg) + qcg*cg*(2 - 2*cos_dist);
-        if (!(dist <= best_cost)) continue;
-        cost = dist + lambda*od_hip_pvq_rate(i, 0, -1, 0, adapt, y_tmp, k, n, is_keyframe, pli, bs);
-        if (cost <= best_cost) {
-          best_cost = cost;
-          best_dist = dist;
-          qg = i;
-          noref = 1;
-          best_k = k;
-          *itheta = -1;
-          *max_theta = 0;
-          y_best = NULL;
-          OD_COPY(y, y_tmp, n);
-        }
+      if (!is_keyframe && B.qg == 0) skip = icgr ? OD_PVQ_SKIP_ZERO : OD_PVQ_SKIP_COPY;
+      if (B.qg == icgr && B.itheta == 0 && !cfl) skip = OD_PVQ_SKIP_COPY;
+    }
+    if (skip == OD_PVQ_SKIP_COPY) OD_COPY(out, r0, n);
+    else if (skip) OD_CLEAR(out, n);
+    else {
+      if (!B.noref && have_xr != 2) {
+        /* the Householder vector of the reference (the searches ran on the device) */
+        for (i = 0; i < n; i++) r[i] = r0[i]*qm[i]*OD_QM_SCALE_1;
+        m = od_compute_householder(r, n, gr, &s);
       }
+      g = od_gain_expand(B.qg + (B.noref ? 0 : gain_offset), q0, beta);
+      od_pvq_synthesis_partial(out, y, r, n, B.noref, g, B.qtheta, m, s, qm_inv);
     }
   }
-  if (y_best != NULL) OD_COPY(y, y_best, n);
-  k = best_k;
-  theta = best_qtheta;
-  skip = 0;
-  if (noref) {
-    if (qg == 0) skip = OD_PVQ_SKIP_ZERO;
-  }
-  else {
-    if (!is_keyframe && qg == 0) skip = (icgr ? OD_PVQ_SKIP_ZERO : OD_PVQ_SKIP_COPY);
-    if (qg == icgr && *itheta == 0 && !cfl_enabled) skip = OD_PVQ_SKIP_COPY;
-  }
-  /* Synthesize like the decoder would (:493-503). */
-  if (skip) {
-    if (skip == OD_PVQ_SKIP_COPY) OD_COPY(out, r0, n);
-    else OD_CLEAR(out, n);
-  }
-  else {
-    if (noref) gain_offset = 0;
-    g = od_gain_expand(qg + gain_offset, q0, beta);
-    od_pvq_synthesis_partial(out, y, r, n, noref, g, theta, m, s, qm_inv);
-  }
-  *vk = k;
-  *skip_diff += skip_dist - best_dist;
-  if (is_keyframe) return noref ? qg : neg_interleave(qg, icgr);
-  return noref ? qg - 1 : neg_interleave(qg + 1, icgr + 1);
+  *skip_diff += skip_dist - B.dist;
+  if (is_keyframe) return B.noref ? B.qg : interleave_gain(B.qg, icgr);
+  return B.noref ? B.qg - 1 : interleave_gain(B.qg + 1, icgr + 1);
 }
 
 /* ------------------------------------------------------------------------ */
-/* What od_pvq_encode's coding section (src/pvq_encoder.c:718-776) can modify: the
-   range coder and these members of the adaptation context. */
+/* od_encode_checkpoint / od_encode_rollback as od_pvq_encode calls them (src/pvq_encoder.c:718,
+   :796; bound by the build recipe for that one source): between the two the function can only
+   modify the range coder and a handful of members of the adaptation context - 2 KB instead of
+   the 19.7 KB of the whole context.  The subset lives in the caller's od_rollback_buffer. */
 typedef struct pvq_ckpt {
   od_ec_enc ec;
   od_pvq_codeword_ctx cw;
@@ -691,9 +841,24 @@ typedef struct pvq_ckpt {
   uint16_t q_cdf[4*4][4];
 } pvq_ckpt;
 
-static void pvq_save(pvq_ckpt *c, daala_enc_ctx *enc, int pli, int bs, int nb, int gt0) {
-  od_adapt_ctx *a;
+void od_hip_pvq_checkpoint(const daala_enc_ctx *enc, od_rollback_buffer *rbuf) {
+  const od_adapt_ctx *a;
+  pvq_ckpt *c;
+  int pli;
+  int bs;
+  int nb;
+  int gt0;
+  _Static_assert(sizeof(pvq_ckpt) <= sizeof(od_rollback_buffer), "the subset fits the caller's buffer");
+  if (!T.host_pvq || T.in_pure) {
+    od_encode_checkpoint(enc, rbuf);
+    return;
+  }
   a = &enc->state.adapt;
+  c = (pvq_ckpt *)rbuf;
+  pli = T.pli;
+  bs = T.cur_bs;
+  nb = OD_BAND_OFFSETS[bs][0];
+  gt0 = (pli != 0)*OD_NBSIZES*PVQ_MAX_PARTITIONS + bs*PVQ_MAX_PARTITIONS;
   od_ec_enc_checkpoint(&c->ec, &enc->ec);
   c->cw = a->pvq.pvq_codeword_ctx;
   memcpy(c->model, a->pvq.pvq_param_model, sizeof(c->model));
@@ -705,9 +870,23 @@ static void pvq_save(pvq_ckpt *c, daala_enc_ctx *enc, int pli, int bs, int nb, i
   if (bs == OD_NBSIZES - 1 && pli == 0) memcpy(c->q_cdf, a->q_cdf, sizeof(c->q_cdf));
 }
 
-static void pvq_restore(const pvq_ckpt *c, daala_enc_ctx *enc, int pli, int bs, int nb, int gt0) {
+void od_hip_pvq_rollback(daala_enc_ctx *enc, const od_rollback_buffer *rbuf) {
   od_adapt_ctx *a;
+  const pvq_ckpt *c;
+  int pli;
+  int bs;
+  int nb;
+  int gt0;
+  if (!T.host_pvq || T.in_pure) {
+    od_encode_rollback(enc, rbuf);
+    return;
+  }
   a = &enc->state.adapt;
+  c = (const pvq_ckpt *)rbuf;
+  pli = T.pli;
+  bs = T.cur_bs;
+  nb = OD_BAND_OFFSETS[bs][0];
+  gt0 = (pli != 0)*OD_NBSIZES*PVQ_MAX_PARTITIONS + bs*PVQ_MAX_PARTITIONS;
   od_ec_enc_rollback(&enc->ec, &c->ec);
   a->pvq.pvq_codeword_ctx = c->cw;
   memcpy(a->pvq.pvq_param_model, c->model, sizeof(c->model));
@@ -719,188 +898,9 @@ static void pvq_restore(const pvq_ckpt *c, daala_enc_ctx *enc, int pli, int bs, 
   if (bs == OD_NBSIZES - 1 && pli == 0) memcpy(a->q_cdf, c->q_cdf, sizeof(c->q_cdf));
 }
 
-/* od_pvq_encode (src/pvq_encoder.c:645-815) for keyframes */
-static int pvq_encode_block(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
- od_coeff *out, int q0, int pli, int bs, const double *beta, int robust, int is_keyframe,
- int q_scaling, int bx, int by, const int16_t *qm, const int16_t *qm_inv) {
-  int theta[PVQ_MAX_PARTITIONS];
-  int max_theta[PVQ_MAX_PARTITIONS];
-  int qg[PVQ_MAX_PARTITIONS];
-  int k[PVQ_MAX_PARTITIONS];
-  od_coeff y[OD_BSIZE_MAX*OD_BSIZE_MAX];
-  int size[PVQ_MAX_PARTITIONS];
-  int *exg;
-  int *ext;
-  int nb_bands;
-  int nb0;
-  int i;
-  const int *off;
-  generic_encoder *model;
-  double skip_diff;
-  int tell;
-  uint16_t *skip_cdf;
-  pvq_ckpt buf;
-  int flip;
-  int cfl_encoded;
-  int skip_rest;
-  int skip_dir;
-  int gt0;
-  int dc_quant;
-  int skip_theta_value;
-  double dc_rate;
-  const unsigned char *pvq_qm;
-  const od_hip_feed_level *L;
-  int blk;
-  od_adapt_ctx *adapt;
-  adapt = &enc->state.adapt;
-  pvq_qm = &enc->state.pvq_qm_q4[pli][0];
-  exg = &adapt->pvq.pvq_exg[pli][bs][0];
-  ext = adapt->pvq.pvq_ext + bs*PVQ_MAX_PARTITIONS;
-  skip_cdf = adapt->skip_cdf[2*bs + (pli != 0)];
-  model = adapt->pvq.pvq_param_model;
-  nb_bands = OD_BAND_OFFSETS[bs][0];
-  nb0 = nb_bands;
-  off = &OD_BAND_OFFSETS[bs][1];
-  gt0 = (pli != 0)*OD_NBSIZES*PVQ_MAX_PARTITIONS + bs*PVQ_MAX_PARTITIONS;
-  dc_quant = OD_MAXI(1, q0*pvq_qm[od_qm_get_index(bs, 0)] >> 4);
-  for (i = 0; i < nb_bands; i++) size[i] = off[i + 1] - off[i];
-  skip_diff = 0;
-  flip = 0;
-  /* chroma of a keyframe is predicted from luma: negate the reference when the first
-     band points away from it (:697-709) */
-  if (pli != 0 && is_keyframe) {
-    double xy;
-    xy = 0;
-    for (i = off[0]; i < off[1]; i++) {
-      xy += ref[i]*qm[i]*OD_QM_SCALE_1*(double)in[i]*qm[i]*OD_QM_SCALE_1;
-    }
-    if (xy < 0) {
-      flip = 1;
-      for (i = off[0]; i < off[nb_bands]; i++) ref[i] = -ref[i];
-    }
-  }
-  /* the feed records of this block: keyframe luma, level 3 - bs, bx/by in 4x4 units */
-  L = NULL;
-  blk = 0;
-  if (T.lev != NULL && pli == 0 && is_keyframe) {
-    L = &T.lev[3 - bs];
-    blk = (by >> bs)*L->nbx + (bx >> bs);
-    if (L->g == NULL || blk < 0 || blk >= L->nblk || L->nbands != nb_bands) L = NULL;
-    else {
-      /* the records of one block sit nblk entries apart (band-major, the device's
-         coalesced layout): start pulling them in before the first band needs them */
-      size_t nrec;
-      nrec = (size_t)L->nbands*L->nblk;
-      for (i = 0; i < nb_bands; i++) {
-        size_t rec;
-        rec = (size_t)i*L->nblk + blk;
-        __builtin_prefetch(L->g + rec);
-        __builtin_prefetch(L->cg + rec);
-        __builtin_prefetch(L->ncand + rec);
-        __builtin_prefetch(L->k + rec);
-        __builtin_prefetch(L->qg + rec);
-        __builtin_prefetch(L->cos_dist + rec);
-        __builtin_prefetch(L->k + nrec + rec);
-        __builtin_prefetch(L->qg + nrec + rec);
-        __builtin_prefetch(L->cos_dist + nrec + rec);
-      }
-    }
-  }
-  for (i = 0; i < nb_bands; i++) {
-    int q;
-    q = OD_MAXI(1, q0*pvq_qm[od_qm_get_index(bs, i + 1)] >> 4);
-    qg[i] = hip_pvq_theta(out + off[i], in + off[i], ref + off[i], size[i], q, y + off[i],
-     &theta[i], &max_theta[i], &k[i], beta[i], &skip_diff, robust, is_keyframe, pli, adapt,
-     bs, qm + off[i], qm_inv + off[i], L, i, blk);
-  }
-  pvq_save(&buf, enc, pli, bs, nb0, gt0);
-  if (is_keyframe) out[0] = 0;
-  else {
-    dc_rate = -OD_LOG2((double)(skip_cdf[1] - skip_cdf[0])/(double)skip_cdf[0]);
-    out[0] = od_rdo_quant(in[0] - ref[0], dc_quant, dc_rate);
-  }
-  tell = od_ec_enc_tell_frac(&enc->ec);
-  /* Code as if we're not skipping. */
-  od_encode_cdf_adapt(&enc->ec, out[0] != 0, skip_cdf, 4 + (pli == 0 && bs > 0),
-   adapt->skip_increment);
-#if OD_SIGNAL_Q_SCALING
-  if (bs == OD_NBSIZES - 1 && pli == 0) {
-    od_encode_quantizer_scaling(enc, q_scaling, bx >> (OD_NBSIZES - 1), by >> (OD_NBSIZES - 1), 0);
-  }
-#endif
-  cfl_encoded = 0;
-  skip_rest = 1;
-  skip_theta_value = is_keyframe ? -1 : 0;
-  for (i = 1; i < nb_bands; i++) {
-    if (theta[i] != skip_theta_value || qg[i]) skip_rest = 0;
-  }
-  skip_dir = 0;
-  if (nb_bands > 1) {
-    for (i = 0; i < 3; i++) {
-      int j;
-      int tmp;
-      tmp = 1;
-      for (j = i + 1; j < nb_bands; j += 3) {
-        if (theta[j] != skip_theta_value || qg[j]) tmp = 0;
-      }
-      skip_dir |= tmp << i;
-    }
-  }
-  if (theta[0] == skip_theta_value && qg[0] == 0 && skip_rest) nb_bands = 0;
-  for (i = 0; i < nb_bands; i++) {
-    if (i == 0 || (!skip_rest && !(skip_dir & (1 << ((i - 1)%3))))) {
-      od_ref_pvq_encode_partition(&enc->ec, qg[i], theta[i], max_theta[i], y + off[i], size[i],
-       k[i], model, adapt, exg + i, ext + i, robust || is_keyframe, gt0 + i, is_keyframe,
-       i == 0 && (i < nb_bands - 1), skip_rest, bs);
-    }
-    if (i == 0 && !skip_rest && bs > 0) {
-      od_encode_cdf_adapt(&enc->ec, skip_dir,
-       &adapt->pvq.pvq_skip_dir_cdf[(pli != 0) + 2*(bs - 1)][0], 7,
-       adapt->pvq.pvq_skip_dir_increment);
-    }
-    if (pli != 0 && is_keyframe && theta[i] != -1 && !cfl_encoded) {
-      od_ec_enc_bits(&enc->ec, flip, 1);
-      cfl_encoded = 1;
-    }
-  }
-  tell = od_ec_enc_tell_frac(&enc->ec) - tell;
-  /* the rate of skipping the AC instead (:778-787) */
-  {
-    double skip_rate;
-    int skip_flag;
-    skip_flag = 2 + (out[0] != 0);
-    skip_rate = -OD_LOG2((skip_cdf[skip_flag] - skip_cdf[skip_flag - 1])/
-     (double)skip_cdf[3 + (pli == 0 && bs > 0)]);
-    tell -= (int)floor(.5 + 8*skip_rate);
-  }
-  if (nb_bands == 0 || skip_diff <= OD_PVQ_LAMBDA/8*tell) {
-    /* skip: everything back as it was (:788-813) */
-    if (is_keyframe) out[0] = 0;
-    else {
-      dc_rate = -OD_LOG2((double)(skip_cdf[3] - skip_cdf[2])/(double)(skip_cdf[2] - skip_cdf[1]));
-      out[0] = od_rdo_quant(in[0] - ref[0], dc_quant, dc_rate);
-    }
-    pvq_restore(&buf, enc, pli, bs, nb0, gt0);
-    od_encode_cdf_adapt(&enc->ec, 2 + (out[0] != 0), skip_cdf, 4 + (pli == 0 && bs > 0),
-     adapt->skip_increment);
-#if OD_SIGNAL_Q_SCALING
-    if (bs == OD_NBSIZES - 1 && pli == 0) {
-      int skip;
-      skip = out[0] == 0;
-      if (skip) q_scaling = 0;
-      od_encode_quantizer_scaling(enc, q_scaling, bx >> (OD_NBSIZES - 1), by >> (OD_NBSIZES - 1),
-       skip);
-    }
-#endif
-    if (is_keyframe) for (i = 1; i < 1 << (2*bs + 4); i++) out[i] = 0;
-    else for (i = 1; i < 1 << (2*bs + 4); i++) out[i] = ref[i];
-    if (out[0] == 0) return 1;
-  }
-  return 0;
-}
-
 /* ------------------------------------------------------------------------ */
-/* check mode: the reference's od_pvq_encode on the same inputs and state */
+/* check mode: the reference's od_pvq_encode, untouched (od_pvq_encode_pure: a second compile
+   of src/pvq_encoder.c with nothing bound), on the same inputs and state */
 typedef struct ec_sig {
   od_ec_window low;
   uint16_t rng;
@@ -922,6 +922,56 @@ static void ec_signature(ec_sig *s, const od_ec_enc *ec) {
   s->nend_bits = ec->nend_bits;
 }
 
+int od_pvq_encode_pure(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out, int q0, int pli,
+ int bs, const double *beta, int robust, int is_keyframe, int q_scaling, int bx, int by,
+ const int16_t *qm, const int16_t *qm_inv);
+
+/* the feed context of one block: which records its bands read */
+static void set_block_context(daala_enc_ctx *enc, int pli, int bs, int is_keyframe, int bx, int by) {
+  T.cur_band = 0;
+  T.cur_bs = bs;
+  T.cur_L = NULL;
+  T.cur_P = NULL;
+  T.cur_blk = 0;
+  if (is_keyframe && pli == 0 && T.lev != NULL) {
+    const od_hip_feed_level *L;
+    int blk;
+    L = &T.lev[3 - bs];
+    blk = (by >> bs)*L->nbx + (bx >> bs);
+    if (L->g != NULL && blk >= 0 && blk < L->nblk && L->nbands == OD_BAND_OFFSETS[bs][0]) {
+      T.cur_L = L;
+      T.cur_blk = blk;
+    }
+  }
+  else if (!is_keyframe && T.pf_valid && pli >= 0 && pli < 3) {
+    const od_hip_pfeed_level *P;
+    int level;
+    int dec;
+    int blk;
+    dec = pli > 0;
+    level = (dec ? 2 : 3) - bs;
+    if (level >= 0 && level < (dec ? 3 : 4)) {
+      int sbx;
+      int sby;
+      P = &T.pfv[pli][level];
+      blk = (by >> bs)*P->nbx + (bx >> bs);
+      /* superblocks that contain padding are not in the feed: there the encoder's input is
+         the prediction's, not the picture's (src/encode.c:2443-2457) */
+      sbx = (bx << 2) >> (5 - dec);
+      sby = (by << 2) >> (5 - dec);
+      if (P->g != NULL && blk >= 0 && blk < P->nblk && P->nbands == OD_BAND_OFFSETS[bs][0]
+       && (sbx + 1)*32 <= enc->state.info.pic_width && (sby + 1)*32 <= enc->state.info.pic_height) {
+        T.cur_P = P;
+        T.cur_blk = blk;
+      }
+    }
+  }
+}
+
+int od_pvq_encode_cpu(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in, od_coeff *out, int q0, int pli,
+ int bs, const double *beta, int robust, int is_keyframe, int q_scaling, int bx, int by,
+ const int16_t *qm, const int16_t *qm_inv);
+
 int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
  od_coeff *out, int q0, int pli, int bs, const double *beta, int robust,
  int is_keyframe, int q_scaling, int bx, int by, const int16_t *qm,
@@ -929,9 +979,10 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
   int n2;
   int ret;
   n2 = 1 << (2*bs + 4);
+  T.pli = pli;
   if (T.check) {
-    /* OD_CHECKASM for the block: ours first, then the reference's own od_pvq_encode from
-       the same state; the reference's result is the one that stays */
+    /* OD_CHECKASM for the block: ours first, then the untouched reference function from the same
+       state; the reference's result is the one that stays */
     od_rollback_buffer *rb;
     od_adapt_ctx *mine;
     od_coeff *ref0;
@@ -944,7 +995,6 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     unsigned char sbq;
     int sbi;
     int ret2;
-    const od_hip_feed_level *lev;
     rb = (od_rollback_buffer *)malloc(sizeof(*rb));
     mine = (od_adapt_ctx *)malloc(sizeof(*mine));
     ref0 = (od_coeff *)malloc(sizeof(od_coeff)*n2*3);
@@ -955,7 +1005,8 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     offs0 = enc->ec.offs;
     sbi = (by >> (OD_NBSIZES - 1))*enc->state.nhsb + (bx >> (OD_NBSIZES - 1));
     sbq = enc->state.sb_q_scaling[sbi];
-    ret = pvq_encode_block(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
+    set_block_context(enc, pli, bs, is_keyframe, bx, by);
+    ret = od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
      qm, qm_inv);
     memcpy(out1, out, sizeof(od_coeff)*n2);
     memcpy(ref1, ref, sizeof(od_coeff)*n2);
@@ -966,11 +1017,10 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     od_encode_rollback_cpu(enc, rb);
     memcpy(ref, ref0, sizeof(od_coeff)*n2);
     enc->state.sb_q_scaling[sbi] = sbq;
-    lev = T.lev;
-    T.lev = NULL;                 /* the reference runs its own C search */
-    ret2 = od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe,
+    T.in_pure = 1;
+    ret2 = od_pvq_encode_pure(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe,
      q_scaling, bx, by, qm, qm_inv);
-    T.lev = lev;
+    T.in_pure = 0;
     ec_signature(&s2, &enc->ec);
     if (ret != ret2 || memcmp(out1 + 1, out + 1, sizeof(od_coeff)*(n2 - 1)) != 0
      || out1[0] != out[0] || memcmp(ref1, ref, sizeof(od_coeff)*n2) != 0
@@ -985,7 +1035,8 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     free(rb);
     return ret2;
   }
-  ret = pvq_encode_block(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
+  set_block_context(enc, pli, bs, is_keyframe, bx, by);
+  ret = od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
    qm, qm_inv);
   return ret;
 }

@@ -20,3 +20,12 @@ double od_ref_pvq_rate(int qg, int icgr, int theta, int ts, const od_adapt_ctx *
  const od_coeff *y0, int k, int n, int is_keyframe, int pli, int bs) {
   return od_pvq_rate(qg, icgr, theta, ts, adapt, y0, k, n, is_keyframe, pli, bs);
 }
+
+/* the reference's own band decision, for HIPENC_HOST_PVQ=0 */
+int od_ref_pvq_theta(od_coeff *out, od_coeff *x0, od_coeff *r0, int n, int q0, od_coeff *y,
+ int *itheta, int *max_theta, int *vk, double beta, double *skip_diff, int robust,
+ int is_keyframe, int pli, const od_adapt_ctx *adapt, int bs, const int16_t *qm,
+ const int16_t *qm_inv) {
+  return pvq_theta_cpu(out, x0, r0, n, q0, y, itheta, max_theta, vk, beta, skip_diff, robust,
+   is_keyframe, pli, adapt, bs, qm, qm_inv);
+}

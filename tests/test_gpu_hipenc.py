@@ -313,6 +313,34 @@ def test_inter_stream_encoded_through_the_seam():
     n, pk, st = H.encode(prm, buf, nf, use_device=1)
     assert n > 0 and pk == want
     assert st.pvq_check_fail == 0 and st.check_fail == 0
+    # the P frames' bands took the complete candidate lists of the P-frame feed (4d): in check
+    # mode every candidate taken from it was searched again on the host and compared
+    assert st.pfeed_frames == 3 and st.resampled > 1000
+
+
+def test_inter_stream_1080p_pframe_feed_packets_identical():
+    """configs[3] at its own size: 1920x1080, I P P (keyframe rate 30), the P frames' pvq_theta
+    candidates - with-reference and no-reference, every band of every block size of every plane
+    outside the padded superblock row - from the device's P-frame feed.  Packets identical to
+    the pure reference encoder's; fewer than a tenth of the P frames' searches left on the host."""
+    from test_hipenc_cpu import inter_stream
+    w, h, nf = 1920, 1080, 3
+    want, rec = inter_stream(w, h, nf, keyrate=30)
+    base = [synth_plane(w + 64, h + 64, 31), synth_plane(w//2 + 32, h//2 + 32, 32, 1),
+            synth_plane(w//2 + 32, h//2 + 32, 33, 1)]
+    frames = [[base[0][2*f:2*f + h, 3*f:3*f + w], base[1][f:f + h//2, (3*f)//2:(3*f)//2 + w//2],
+               base[2][f:f + h//2, (3*f)//2:(3*f)//2 + w//2]] for f in range(nf)]
+    buf = H.pack_frames(frames, w, h)
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0, 30)
+    n1, pk1, st1 = H.encode(prm, buf, 1, use_device=1)            # the keyframe alone: its host searches
+    n, pk, st = H.encode(prm, buf, nf, use_device=1)
+    assert n > 0 and pk == want
+    assert st.pfeed_frames == 2 and st.lost_sync == st1.lost_sync
+    host_p = (st.cpu_other + st.cpu_noref_luma) - (st1.cpu_other + st1.cpu_noref_luma)
+    dev_p = st.dev_hits - st1.dev_hits
+    print('1080p I P P: P-frame searches from the feed %d, on the host %d; feed wait %.3f s; total %.2f s'
+          % (dev_p, host_p, st.t_pfeed_s, st.t_total_s))
+    assert host_p < 0.1*(host_p + dev_p)
 
 
 def test_haar_frames_with_a_quantizer_decode_on_the_host_path(monkeypatch):
