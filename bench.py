@@ -104,6 +104,36 @@ def reference_packets(frames, nframes, masking=1):
             'packets': H.split_packets(out, nframes), 'packet_bytes': int(nbytes)}
 
 
+def inter_sample(H, frames, device, nframes=3):
+    so = os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so')
+    if not os.path.exists(so):
+        return None
+    lib = ctypes.CDLL(so)
+    lib.probe_encode_frames.restype = ctypes.c_long
+    buf = H.pack_frames(frames[:nframes], PIC_W, PIC_H)
+    out = np.zeros(max(1 << 22, buf.size), np.uint8)
+    fnv, sec = ctypes.c_uint(), ctypes.c_double()
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    nb = lib.probe_encode_frames(PIC_W, PIC_H, nframes, 20, 7, 1, 30, buf.ctypes.data_as(U8P),
+                                 ctypes.byref(fnv), ctypes.byref(sec), out.ctypes.data_as(U8P), out.size)
+    want = H.split_packets(out, nframes) if nb > 0 else None
+    prm = H.Params(PIC_W, PIC_H, 20, 7, 1, 1, 0, 0, 30)
+    with H.Session(prm, use_device=1, device=device) as ses:
+        ses.encode(buf, nframes)                          # warm-up: contexts, pinned buffers
+        t = time.perf_counter()
+        n, pk, st = ses.encode(buf, nframes)
+        t = time.perf_counter() - t
+    host = st.cpu_other + st.cpu_noref_luma
+    return {'frames': 'I P P, 1920x1080, keyframe rate 30', 'seconds': round(t, 3),
+            'Mpixels_per_s': round(nframes*PIC_W*PIC_H/t/1e6, 3),
+            'reference_1thread_seconds': round(sec.value, 2),
+            'x_single_thread_reference': round(sec.value/t, 2),
+            'packets_equal_pure_reference_build': bool(n > 0 and want is not None and pk == want),
+            'pfeed_frames': int(st.pfeed_frames), 'pfeed_wait_s': round(st.t_pfeed_s, 4),
+            'searches_from_device': int(st.dev_hits), 'searches_on_host': int(host),
+            'host_workers': 1}
+
+
 KERNEL_SYMBOL = {     # bench kernel label -> substring of the device kernel name
     'k_forward_pyramid_luma': 'k_forward_rt<32, 4, false>',
     'k_forward_pyramid_chroma': 'k_forward_rt<16, 3, false>',
@@ -373,6 +403,84 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
     return out, roofline
 
 
+def strong_step_setup(H, b, local_rank, rank, world, nframes, rehearse, dist):
+    """BASELINE configs[2]: ONE 3840x2160 frame at a time sharded by superblock rows over the
+    ranks - every rank runs the forward pyramid, the gains pass, its libm stage and the searches
+    of ITS strip of every frame of the step from the replicated input; the strips travel to rank
+    0 (od_hip_gather_strips: one packed RCCL message per owner over xGMI; in a gloo rehearsal on
+    one GPU the same packed buffers through host memory) and rank 0's host workers code the
+    frames from the gathered feed.  Returns a step() closure and its description."""
+    w, h = 3840, 2160
+    fw, fh = 3840, 2176
+    from testlib import synth_plane
+    base = [synth_plane(fw, fh, 101), synth_plane(fw//2, fh//2, 101, 1), synth_plane(fw//2, fh//2, 102, 1)]
+    frames = [[np.ascontiguousarray(np.roll(p, (3*f, 5*f), axis=(0, 1)))[:h >> (i > 0), :w >> (i > 0)]
+               for i, p in enumerate(base)] for f in range(nframes)]
+    buf = H.pack_frames(frames, w, h)
+    budget = host_cpu_budget()
+    nw = nframes if (os.cpu_count() or 1) >= 2*budget else max(1, min(nframes, budget//world))
+    prm = H.Params(w, h, 20, 7, 1, nw, 0, 0)
+    fb = w*h + 2*(w//2)*(h//2)
+    padded = [H.pad_frame(prm, buf[f*fb:(f + 1)*fb]) for f in range(nframes)]
+    ctx = b.DaalaHip(w, h, fw, fh, nplanes=3, xdec=(0, 1, 1), nslots=nframes, device=local_rank)
+    ctx.enc_feed_create(*H.level_params(prm))
+    nvsb = fh//32
+    rows = [nvsb*r//world for r in range(world + 1)]
+    comm = None
+    if world > 1 and not rehearse:
+        import torch
+        uid = [b.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = b.Comm(local_rank, world, rank, uid[0])
+
+    class View:
+        pass
+
+    def step():
+        for f in range(nframes):
+            ctx.upload_planes(f, padded[f])
+        ctx.set_strip(rows[rank], rows[rank + 1])
+        ctx.enc_feed_phases(0, nframes)
+        ctx.sync()
+        for f in range(nframes):
+            if comm is not None:
+                ctx.gather_strips(comm, f, rows)
+            elif world > 1:
+                import torch
+                blob = ctx.strip_export(f, rows[rank], rows[rank + 1])
+                got = [None]*world if rank == 0 else None
+                dist.gather_object(blob.tobytes(), got, dst=0)
+                if rank == 0:
+                    for r in range(1, world):
+                        ctx.strip_import(f, rows[r], rows[r + 1], np.frombuffer(got[r], np.uint8))
+        ctx.set_strip(0, nvsb)
+        if rank != 0:
+            return 0, None
+        ctx.enc_feed_refresh(0, nframes)
+        views = []
+        for f in range(nframes):
+            v = View()
+            v.levels = ctx.enc_feed_views_raw(f)
+            views.append(v)
+        n, pk, st = H.encode(prm, buf, nframes, views=views)
+        if n < 0:
+            raise SystemExit('sharded encode failed: %d' % n)
+        return n, pk
+
+    def close():
+        if comm is not None:
+            comm.close()
+        ctx.close()
+
+    what = {'workload': '3840x2160 4:2:0 synthetic frames (BASELINE configs[2]), %d intra frames per step, each frame '
+                        'sharded by superblock rows over %d rank(s), strips gathered to rank 0 %s, rank 0 codes'
+                        % (nframes, world, 'through host memory (gloo rehearsal)' if rehearse else
+                           'with one packed RCCL message per owner'),
+            'frames_per_step': nframes, 'host_workers_on_rank0': nw, 'host_cpu_quota': budget,
+            'sb_rows_per_rank': [rows[r + 1] - rows[r] for r in range(world)]}
+    return step, close, what, (w, h, buf)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -382,6 +490,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--device-steps', type=int, default=10, help='steps of the device-only section')
     ap.add_argument('--skip-pvq', action='store_true', help='profiling aid: device section without PVQ')
+    ap.add_argument('--strong', action='store_true',
+                    help='configs[2]: one 4K frame at a time sharded by superblock rows over the ranks '
+                         '(strong scaling); the default N > 1 mode codes independent streams (weak)')
+    ap.add_argument('--strong-frames', type=int, default=4)
     ap.add_argument('--device-only', action='store_true',
                     help='profiling aid: only the device-only section (INVALID as a bench result)')
     args = ap.parse_args()
@@ -423,6 +535,51 @@ def main():
         return
     if not H.have_hipenc():
         raise SystemExit('daala_amd/host/build/libdaala_hipenc.so is missing (make -C daala_amd/host)')
+
+    if args.strong:
+        step, close, what, (sw, sh, sbuf) = strong_step_setup(H, b, local_rank, rank, world, args.strong_frames,
+                                                              rehearse, dist)
+        for _ in range(args.warmup):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            nb, pk = step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            # bit-exactness: the first frame against the pure reference build
+            ok = None
+            so = os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so')
+            if os.path.exists(so) and not args.no_cpu_baseline:
+                lib2 = ctypes.CDLL(so)
+                lib2.probe_encode_frames.restype = ctypes.c_long
+                U8P = ctypes.POINTER(ctypes.c_uint8)
+                o2 = np.zeros(1 << 23, np.uint8)
+                fnv, sec = ctypes.c_uint(), ctypes.c_double()
+                n2 = lib2.probe_encode_frames(sw, sh, 1, 20, 7, 1, 1, sbuf.ctypes.data_as(U8P), ctypes.byref(fnv),
+                                              ctypes.byref(sec), o2.ctypes.data_as(U8P), o2.size)
+                ok = bool(n2 > 0 and H.split_packets(o2, 1)[0] == pk[0])
+            px = args.strong_frames*sw*sh*args.steps
+            print(json.dumps({
+                'metric': 'encode Mpixels/s (intra, bit-exact)', 'value': round(px/elapsed/1e6, 3),
+                'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(elapsed/args.steps*1e3, 3), 'higher_is_better': True, 'scaling': 'strong',
+                'vs_baseline': None, 'dtype': 'int32+f64', 'data': 'synthetic', 'config': what,
+                'bit_exact': {'first_packet_equals_pure_reference_build': ok},
+                'note': 'the serial entropy/RDO stage of every frame runs on rank 0 alone: what the other ranks '
+                        'take over is the device feed of their superblock rows (a few ms of a step)'}))
+        close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     frames = make_frames(FRAMES, seed0=1 + rank)
     buf = H.pack_frames(frames, PIC_W, PIC_H)
@@ -535,6 +692,14 @@ def main():
                                        bool(nm > 0 and refm is not None and pkm[:2] == refm['packets']),
                                    'reference_1thread_Mpixels_per_s': round(refm['Mpixels_per_s'], 4) if refm else None,
                                    'what': 'the end-to-end step with activity masking off (SURVEY 8d), one timed step'}
+            # BASELINE configs[3], bounded: 1080p inter (I P P of a GOP, keyframe rate 30) through a
+            # one-worker session - P frames: device OBMC prediction, P-frame feed (complete
+            # pvq_theta candidate lists from the device), device deringing - beside the pure
+            # reference encoder on the same frames, one thread each
+            try:
+                line['inter'] = inter_sample(H, frames, local_rank)
+            except Exception as e:                       # an extra key must not take the headline down
+                line['inter'] = {'error': repr(e)}
             # decoder side of the seam on the packets just produced
             hdr = H.headers(prm)
             nd, pics, sec, dsec = H.decode(prm, hdr, packets, use_device=1, device=local_rank)

@@ -431,6 +431,23 @@ class DaalaHip(object):
         self.lib.od_hip_gather_strips.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_int, I32P, c_int]
         _chk(self.lib.od_hip_gather_strips(self.ctx, comm.h, slot, _p32(rows), int(with_pvq)))
 
+    def strip_export(self, slot, r0, r1, with_pvq=True):
+        """The packed results of superblock rows [r0, r1) as one host buffer."""
+        self.lib.od_hip_strip_bytes.restype = ctypes.c_long
+        self.lib.od_hip_strip_bytes.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, c_int]
+        n = self.lib.od_hip_strip_bytes(self.ctx, slot, r0, r1, int(with_pvq))
+        if n < 0:
+            raise HipError(self.lib.od_hip_last_error().decode())
+        buf = np.zeros(max(n, 1), np.uint8)
+        self.lib.od_hip_strip_export.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, c_int, U8P, ctypes.c_long]
+        _chk(self.lib.od_hip_strip_export(self.ctx, slot, r0, r1, int(with_pvq), buf.ctypes.data_as(U8P), n))
+        return buf[:n]
+
+    def strip_import(self, slot, r0, r1, blob, with_pvq=True):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.lib.od_hip_strip_import.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, c_int, U8P, ctypes.c_long]
+        _chk(self.lib.od_hip_strip_import(self.ctx, slot, r0, r1, int(with_pvq), blob.ctypes.data_as(U8P), blob.size))
+
     def pvq_stats(self, enable):
         """Device work counters of the searches (greedy element steps, RDO element steps,
         candidates); enable=1 restarts them, 0 reads and stops."""
@@ -483,6 +500,30 @@ class DaalaHip(object):
             b_l = np.ascontiguousarray(beta[l], dtype=np.float64)
             _chk(lib.od_hip_enc_feed_set_level(self.feed, l, qm_l.ctypes.data_as(I16P), _p32(q_l),
                                                b_l.ctypes.data_as(F64P)))
+
+    def enc_feed_phases(self, slot0=0, nslots=None):
+        """od_hip_enc_feed_gains -> _compand per slot -> _search (what enc_feed_run does), as
+        separate calls so that a strip set with set_strip() is honoured by every phase."""
+        n = nslots or self.nslots - slot0
+        lib = self.lib
+        for f in (lib.od_hip_enc_feed_gains, lib.od_hip_enc_feed_search, lib.od_hip_enc_feed_refresh):
+            f.argtypes = [ctypes.c_void_p, c_int, c_int]
+        lib.od_hip_enc_feed_compand.argtypes = [ctypes.c_void_p, c_int]
+        _chk(lib.od_hip_enc_feed_gains(self.feed, slot0, n))
+        for s in range(slot0, slot0 + n):
+            _chk(lib.od_hip_enc_feed_compand(self.feed, s))
+        _chk(lib.od_hip_enc_feed_search(self.feed, slot0, n))
+
+    def enc_feed_refresh(self, slot0=0, nslots=None):
+        self.lib.od_hip_enc_feed_refresh.argtypes = [ctypes.c_void_p, c_int, c_int]
+        _chk(self.lib.od_hip_enc_feed_refresh(self.feed, slot0, nslots or self.nslots - slot0))
+
+    def enc_feed_views_raw(self, slot):
+        """The four od_hip_feed_level structs of a slot (pointers into the feed's pinned host
+        mirrors, valid until the slot is reused) - what od_hipenc_encode_frames takes as views."""
+        lev = (FeedLevel*4)()
+        _chk(self.lib.od_hip_enc_feed_view(self.feed, slot, lev))
+        return lev
 
     def enc_feed_run(self, slot0=0, nslots=None):
         _chk(self.lib.od_hip_enc_feed_run(self.feed, slot0, nslots or self.nslots - slot0))

@@ -156,12 +156,18 @@ int od_hip_enc_feed_compand(od_hip_enc_feed *f, int slot) {
     const double *g = (const double *)(f->h_g + (size_t)slot*A.g_slot + Y.o_g);
     double *cg = (double *)(f->h_in + (size_t)slot*A.in_slot + Y.o_cg);
     int32_t *perm = (int32_t *)(f->h_in + (size_t)slot*A.in_slot + Y.o_perm);
+    // the strip of the context (od_hip_set_strip; the whole frame by default): its blocks'
+    // gains are companded and its work list ordered - the search launch walks the list
+    // positions of the strip's blocks only
+    const int per_sb = 32/Y.n;
+    const long nbx = ctx->pw[0]/Y.n;
+    const long first = (long)ctx->strip0*per_sb*nbx, count = (long)(ctx->strip1 - ctx->strip0)*per_sb*nbx;
     for (int b = 0; b < Y.nb; b++) {
       const int q0 = L.q[b];
       const double beta = L.beta[b];
-      const size_t o = (size_t)b*Y.nblk;
-      for (int i = 0; i < Y.nblk; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
-      pvq_block_order(cg + o, 0, Y.nblk, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
+      const size_t o = (size_t)b*Y.nblk + first;
+      for (long i = 0; i < count; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
+      pvq_block_order(cg + o, first, count, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
     }
   }
   HIPCHK(hipMemcpyAsync(A.in + (size_t)slot*A.in_slot, f->h_in + (size_t)slot*A.in_slot, A.in_slot,
@@ -193,6 +199,31 @@ int od_hip_enc_feed_search(od_hip_enc_feed *f, int slot0, int nslots) {
                           hipMemcpyDeviceToHost, f->copy));
     HIPCHK(hipEventRecord(f->ready[s], f->copy));
     f->pending[s] = 1;
+  }
+  return 0;
+}
+
+// After od_hip_gather_strips on the coding rank: the slots' device buffers now hold the whole
+// frame (the other ranks' strips arrived device to device), so the host mirrors are fetched
+// again - level planes, gains, companded gains, records - and the slots' events re-armed.
+int od_hip_enc_feed_refresh(od_hip_enc_feed *f, int slot0, int nslots) {
+  if (!f) return fail(OD_HIP_EFAULT, "null feed");
+  od_hip_ctx *ctx = f->ctx;
+  if (int rc = check_slots(ctx, slot0, nslots)) return rc;
+  const PvqArena &A = ctx->arena[0];
+  const size_t pl = (size_t)ctx->nlev[0]*ctx->psz[0];
+  HIPCHK(hipEventRecord(f->computed, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
+  for (int s = slot0; s < slot0 + nslots; s++) {
+    HIPCHK(hipMemcpyAsync(f->h_planes + (size_t)s*pl, ctx->lev[0] + (size_t)s*pl, pl*sizeof(od_coeff),
+                          hipMemcpyDeviceToHost, f->copy));
+    HIPCHK(hipMemcpyAsync(f->h_g + (size_t)s*A.g_slot, A.g + (size_t)s*A.g_slot, A.g_slot, hipMemcpyDeviceToHost, f->copy));
+    HIPCHK(hipMemcpyAsync(f->h_in + (size_t)s*A.in_slot, A.in + (size_t)s*A.in_slot, A.in_slot, hipMemcpyDeviceToHost, f->copy));
+    HIPCHK(hipMemcpyAsync(f->h_out + (size_t)s*A.out_slot, A.out + (size_t)s*A.out_slot, A.out_slot,
+                          hipMemcpyDeviceToHost, f->copy));
+    HIPCHK(hipEventRecord(f->ready[s], f->copy));
+    f->pending[s] = 1;
+    f->lossless[s] = 0;
   }
   return 0;
 }

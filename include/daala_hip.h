@@ -322,6 +322,9 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_compand(od_hip_enc_feed *feed, int slot);
 int od_hip_enc_feed_search(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_view(od_hip_enc_feed *feed, int slot, od_hip_feed_level lev[4]);
+/* On the coding rank of a superblock-row sharded frame, after od_hip_gather_strips: fetches
+ * the slots' host mirrors again (the other ranks' strips arrived device to device). */
+int od_hip_enc_feed_refresh(od_hip_enc_feed *feed, int slot0, int nslots);
 /* Lossless frames (quantizer 0): the encoder codes the Haar wavelet of every whole
  * superblock (od_haar, src/encode.c:1305; no lapping, DCT or PVQ).  _run_lossless =
  * od_hip_forward_haar of the slots + the three coefficient planes to pinned host memory;
@@ -452,9 +455,13 @@ int od_hip_pvq_synthesis_vectors(int n, int nvec, const int32_t *y, const od_coe
  *       nothing from its neighbours.  (0, nvsb) - the default - is the whole frame.
  *   od_hip_comm_unique_id / od_hip_comm_create   an RCCL communicator over the ranks (the
  *       128-byte id travels by whatever the launcher offers, e.g. torch.distributed);
- *   od_hip_gather_strips   device-to-device gather over xGMI: afterwards every rank's slot
- *       holds the complete pyramid (and PVQ records), sb_rows[r] .. sb_rows[r + 1] being
- *       rank r's strip.  The only collective of the path; nothing crosses the host. */
+ *   od_hip_gather_strips   device-to-device gather over xGMI to the CODING rank (rank 0):
+ *       afterwards rank 0's slot holds the complete pyramid (and PVQ records), sb_rows[r] ..
+ *       sb_rows[r + 1] being rank r's strip.  Every owner packs its strip into one buffer
+ *       (one kernel), sends it with ONE ncclSend, rank 0 posts one ncclRecv per owner in one
+ *       group and unpacks; the only collective of the path, nothing crosses the host.
+ *   od_hip_strip_bytes / _export / _import   the same packed strip through host memory, for
+ *       launchers whose ranks have no RCCL between them (a gloo rehearsal on one GPU). */
 typedef struct od_hip_comm od_hip_comm;
 int od_hip_set_strip(od_hip_ctx *ctx, int sb_row0, int sb_row1);
 int od_hip_comm_unique_id(unsigned char id[128]);
@@ -462,6 +469,11 @@ od_hip_comm *od_hip_comm_create(int device, int world, int rank, const unsigned 
 void od_hip_comm_destroy(od_hip_comm *comm);
 int od_hip_gather_strips(od_hip_ctx *ctx, od_hip_comm *comm, int slot, const int *sb_rows,
  int with_pvq);
+long od_hip_strip_bytes(od_hip_ctx *ctx, int slot, int sb_row0, int sb_row1, int with_pvq);
+int od_hip_strip_export(od_hip_ctx *ctx, int slot, int sb_row0, int sb_row1, int with_pvq,
+ void *host, long cap);
+int od_hip_strip_import(od_hip_ctx *ctx, int slot, int sb_row0, int sb_row1, int with_pvq,
+ const void *host, long bytes);
 
 /* F3 (inter frames, first kernel): overlapped block motion compensation of a list of
  * prediction blocks = the leaves od_state_mc_predict (src/state.c:993) visits through

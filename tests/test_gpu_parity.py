@@ -673,6 +673,24 @@ def test_superblock_row_strips_in_c_equal_the_full_frame(hip):
             assert np.array_equal(yf, yp)
             for f in ('cg', 'g', 'cos_dist', 'dist', 'qg', 'k', 'ncand'):
                 assert np.array_equal(bf[f], bp[f]), (pli, level, f)
+    # the packed strip (what travels to the coding rank as ONE message per owner): a context that
+    # computed rows 0..3 imports the strip of rows 3..7 another context computed
+    a = run([(0, 3)])
+    b = run([(3, 7)])
+    blob = b.strip_export(0, 3, 7)
+    assert blob.size > 0
+    a.strip_import(0, 3, 7, blob)
+    for pli in range(3):
+        for level in range(full.nlevels(pli)):
+            assert np.array_equal(full.download_level(0, pli, level), a.download_level(0, pli, level))
+    for pli in (0, 1):
+        for level in range(full.nlevels(pli)):
+            (bf, yf), (bp, yp) = full.pvq_download(0, pli, level), a.pvq_download(0, pli, level)
+            assert np.array_equal(yf, yp)
+            for f in ('cg', 'g', 'cos_dist', 'qg', 'k', 'ncand'):
+                assert np.array_equal(bf[f], bp[f]), (pli, level, f)
+    a.close()
+    b.close()
     full.close()
     part.close()
 
