@@ -456,42 +456,6 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
   return 0;
 }
 
-// SAD / SATD of a list of block pairs (mc_kernels.hpp; od_enc_opt_vtbl, src/encint.h:61-82).
-int od_hip_mc_sad_pairs(const unsigned char *src, int src_stride, int src_h, const unsigned char *ref,
-                        int ref_stride, int ref_h, const od_hip_mc_pair *pairs, int npairs,
-                        int32_t *out) {
-  if (!src || !ref || !pairs || !out) return fail(OD_HIP_EFAULT, "null pointer");
-  if (src_stride < 1 || src_h < 1 || ref_stride < 1 || ref_h < 1 || npairs < 0) return fail(OD_HIP_EINVAL, "bad geometry");
-  for (int i = 0; i < npairs; i++) {
-    const od_hip_mc_pair &m = pairs[i];
-    if (m.log_blk_sz < 2 || m.log_blk_sz > 6) return fail(OD_HIP_EINVAL, "bad block size");
-    const int n = 1 << m.log_blk_sz;
-    if (m.sx < 0 || m.sy < 0 || m.sx + n > src_stride || m.sy + n > src_h || m.rx < 0 || m.ry < 0
-        || m.rx + n > ref_stride || m.ry + n > ref_h) return fail(OD_HIP_EINVAL, "block outside its plane");
-  }
-  if (int rc = ensure_device()) return rc;
-  if (npairs == 0) return 0;
-  static_assert(sizeof(McPair) == sizeof(od_hip_mc_pair), "McPair mirrors od_hip_mc_pair");
-  const size_t sb = (size_t)src_stride*src_h, rb = (size_t)ref_stride*ref_h;
-  SCRATCH_LOCK;
-  if (int rc = g_in.reserve(sb)) return rc;
-  if (int rc = g_aux0.reserve(rb)) return rc;
-  if (int rc = g_aux1.reserve((size_t)npairs*sizeof(McPair))) return rc;
-  if (int rc = g_out.reserve((size_t)npairs*4)) return rc;
-  HIPCHK(hipMemcpy(g_in.p, src, sb, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g_aux0.p, ref, rb, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g_aux1.p, pairs, (size_t)npairs*sizeof(McPair), hipMemcpyHostToDevice));
-  McPairArgs a;
-  a.src = (const uint8_t *)g_in.p; a.sstride = src_stride;
-  a.ref = (const uint8_t *)g_aux0.p; a.rstride = ref_stride;
-  a.pairs = (const McPair *)g_aux1.p; a.npairs = npairs;
-  a.out = (int32_t *)g_out.p;
-  hipLaunchKernelGGL(k_mc_sad_pairs, dim3(npairs), dim3(64), 0, 0, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(out, g_out.p, (size_t)npairs*4, hipMemcpyDeviceToHost));
-  return 0;
-}
-
 }  // extern "C"
 
 // ---------------------------------------------------------------------------

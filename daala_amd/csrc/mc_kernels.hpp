@@ -161,104 +161,3 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
     }
   }
 }
-
-// ---------------------------------------------------------------------------------
-// SAD / SATD of block pairs: the encoder's od_enc_opt_vtbl (src/encint.h:61-82) - what
-// od_mv_est's candidate evaluation calls per block (od_mc_compute_sad8_c src/mcenc.c:1333,
-// od_mc_compute_satd8 :1464, od_mc_compute_sum_8x8_satd8 :1520) - for a LIST of (source block,
-// candidate block) pairs.  SATD: 4x4 blocks one 4x4 Hadamard, larger blocks the sum of the
-// 8x8 Hadamards of their 8x8 sub-blocks, each (sum|.| + n/2) >> log2(n); the absolute sum of
-// a Hadamard transform does not depend on the order of its butterflies, so the in-register
-// network below gives the reference's number.  One thread per 8x8 (or 4x4) sub-block.
-struct McPair {            // == od_hip_mc_pair
-  int32_t sx, sy;          // block position in the source plane
-  int32_t rx, ry;          // candidate position in the reference plane
-  int32_t log_blk_sz;      // 2 .. 6
-  int32_t satd;            // 0: SAD, 1: SATD
-};
-
-struct McPairArgs {
-  const uint8_t *src;
-  int sstride;
-  const uint8_t *ref;
-  int rstride;
-  const McPair *pairs;
-  int npairs;
-  int32_t *out;            // [npairs], zeroed by the host
-};
-
-template <int N>
-__device__ __forceinline__ void hadamard_rows(int32_t (&v)[N*N]) {
-  // N-point Hadamard of every row (N = 4 or 8), in place
-#pragma unroll
-  for (int r = 0; r < N; r++) {
-#pragma unroll
-    for (int h = 1; h < N; h <<= 1) {
-#pragma unroll
-      for (int i = 0; i < N; i++) {
-        if ((i & h) == 0) {
-          const int32_t a = v[r*N + i], b = v[r*N + i + h];
-          v[r*N + i] = a + b;
-          v[r*N + i + h] = a - b;
-        }
-      }
-    }
-  }
-}
-
-template <int N>
-__device__ __forceinline__ int32_t satd_sub(const uint8_t *s, int ss, const uint8_t *r, int rs) {
-  int32_t v[N*N];
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-#pragma unroll
-    for (int j = 0; j < N; j++) v[i*N + j] = (int32_t)s[i*ss + j] - (int32_t)r[i*rs + j];
-  }
-  hadamard_rows<N>(v);
-  // columns: transpose in registers (compile-time indices), transform rows again
-  int32_t t[N*N];
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-#pragma unroll
-    for (int j = 0; j < N; j++) t[j*N + i] = v[i*N + j];
-  }
-  hadamard_rows<N>(t);
-  int32_t sum = 0;
-#pragma unroll
-  for (int i = 0; i < N*N; i++) sum += t[i] < 0 ? -t[i] : t[i];
-  constexpr int LN = N == 4 ? 2 : 3;
-  return (sum + (1 << LN >> 1)) >> LN;
-}
-
-__global__ __launch_bounds__(64) void k_mc_sad_pairs(McPairArgs a) {
-  const int p = blockIdx.x;
-  if (p >= a.npairs) return;
-  const McPair m = a.pairs[p];
-  const int n = 1 << m.log_blk_sz;
-  const uint8_t *s = a.src + (size_t)m.sy*a.sstride + m.sx;
-  const uint8_t *r = a.ref + (size_t)m.ry*a.rstride + m.rx;
-  int32_t acc = 0;
-  if (m.satd) {
-    if (n == 4) {
-      if (threadIdx.x == 0) acc = satd_sub<4>(s, a.sstride, r, a.rstride);
-    }
-    else {
-      const int nb = n >> 3;                          // 8x8 sub-blocks per side (<= 8)
-      if ((int)threadIdx.x < nb*nb) {
-        const int bi = threadIdx.x/nb, bj = threadIdx.x%nb;
-        acc = satd_sub<8>(s + (size_t)(8*bi)*a.sstride + 8*bj, a.sstride,
-                          r + (size_t)(8*bi)*a.rstride + 8*bj, a.rstride);
-      }
-    }
-  }
-  else {
-    for (int e = threadIdx.x; e < n*n; e += 64) {
-      const int i = e >> m.log_blk_sz, j = e & (n - 1);
-      const int d = (int)r[(size_t)i*a.rstride + j] - (int)s[(size_t)i*a.sstride + j];
-      acc += d < 0 ? -d : d;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (threadIdx.x == 0) a.out[p] = acc;
-}

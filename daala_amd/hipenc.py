@@ -59,6 +59,8 @@ class Stats(ctypes.Structure):
                 ('dering_dev_sbs', ctypes.c_int64), ('dering_check_fail', ctypes.c_int64),
                 ('dist_dev', ctypes.c_int64), ('dist_check_fail', ctypes.c_int64),
                 ('pfeed_frames', ctypes.c_int64), ('t_pfeed_s', ctypes.c_double),
+                ('rate_s', ctypes.c_double), ('rate_state_free_s', ctypes.c_double),
+                ('rate_calls', ctypes.c_int64), ('frame_cpu_s', ctypes.c_double), ('pre_mc_s', ctypes.c_double),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_compand_s', ctypes.c_double),

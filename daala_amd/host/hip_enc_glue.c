@@ -280,6 +280,7 @@ int od_hipenc_pframe_feed(od_state *state, od_img *pred) {
   double t0;
   enc = T.enc;
   T.pf_valid = 0;
+  if (T.time_cpu && enc != NULL && state == &enc->state) T.st.pre_mc_s += now_s() - T.t_frame0;
   if (T.pf == NULL || enc == NULL || state != &enc->state || !T.host_pvq
    || state->frame_type != OD_P_FRAME || state->info.nplanes != 3
    || enc->use_haar_wavelet || enc->quality[0] == 0) {
@@ -718,6 +719,11 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->dist_check_fail += b->dist_check_fail;
   a->pfeed_frames += b->pfeed_frames;
   a->t_pfeed_s += b->t_pfeed_s;
+  a->rate_s += b->rate_s;
+  a->rate_state_free_s += b->rate_state_free_s;
+  a->rate_calls += b->rate_calls;
+  a->frame_cpu_s += b->frame_cpu_s;
+  a->pre_mc_s += b->pre_mc_s;
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
@@ -772,6 +778,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   T.pf_valid = 0;
   od_hipenc_mc_cache_flush();          /* reference frames change between frames */
   (void)od_hipdec_take_failure();
+  T.t_frame0 = now_s();
   if (daala_encode_img_in(enc, &img, 0, 0, &left) < 0) return -2;
   if (T.dr_error) return -4;
   /* od_state_mc_predict's device pass (hip_dec_glue.c) failed for this frame */
@@ -790,6 +797,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
     memcpy(q + 4, dp.packet, dp.bytes);
     J->pkt_len[f] += 4 + dp.bytes;
   }
+  if (T.time_cpu) T.st.frame_cpu_s += now_s() - T.t_frame0;
   T.lev = NULL;
   T.haar[0] = T.haar[1] = T.haar[2] = NULL;
   T.enc = NULL;

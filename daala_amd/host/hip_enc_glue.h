@@ -47,6 +47,12 @@ typedef struct od_hipenc_stats {
   int64_t dist_check_fail; /* check mode: device distortion != the reference's od_compute_dist (must be 0) */
   int64_t pfeed_frames;    /* inter frames whose bands took the complete candidate lists of the P-frame feed */
   double t_pfeed_s;        /* seconds the coding thread waited for P-frame feeds (device passes + libm stage) */
+  /* HIPENC_TIME=1 only (0 otherwise): host time classes, summed over workers */
+  double rate_s;           /* inside the rate-only pricing of codewords */
+  double rate_state_free_s; /* a state-free skeleton of the same pricing run beside it (see hip_pvq_host.c) */
+  int64_t rate_calls;
+  double frame_cpu_s;      /* inside daala_encode_img_in + packet_out, all frames */
+  double pre_mc_s;         /* P frames: frame start -> od_state_mc_predict (input copy + od_mv_est) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* upload done -> device batch enqueued (includes t_compand_s), wall */

@@ -38,6 +38,7 @@ typedef struct glue_tls {
   /* P-frame feed of the inter frame being coded */
   od_hip_pfeed *pf;
   int pf_valid;
+  double t_frame0;                /* start of the frame being coded (timers) */
   od_hip_pfeed_level pfv[3][4];
   od_hipenc_stats st;
 } glue_tls;

@@ -258,7 +258,47 @@ static void rc_laplace_vector(hip_rc *c, const od_coeff *y, int n, int k,
 /* The codeword's share of od_pvq_rate (src/pvq_encoder.c:257-276): trial coding of y into
    a fresh range coder.  It depends on (y, k, n, noref, bs) and the adaptation state only, so
    within one band - where the state does not move - equal codewords have equal rates. */
+static double pvq_codeword_rate_untimed(const od_adapt_ctx *adapt, const od_coeff *y0, int k, int n,
+ int noref, int bs);
+
+/* What of a codeword's pricing does not depend on the adaptation state (HIPENC_TIME=1 runs it
+   beside every pricing and times both: the measured answer to "could the device pre-digest the
+   candidates' rate").  The symbols a codeword turns into - magnitudes, the running pulse
+   budget, where the delta coder takes over - are state free; every symbol's alphabet, shift
+   and CDF row (ex = f(exp_q8, kn, i), decay = f(ex)) and the rng recurrence are not. */
+static volatile int rate_skeleton_sink;
+static void rate_skeleton(const od_coeff *y, int n, int k) {
+  int kn;
+  int i;
+  int acc;
+  kn = k;
+  acc = 0;
+  for (i = 0; i < n && kn > 0; i++) {
+    int x;
+    x = abs(y[i]);
+    acc += (x != 0) + (kn <= 1);
+    kn -= x;
+  }
+  rate_skeleton_sink = acc;
+}
+
 static double pvq_codeword_rate(const od_adapt_ctx *adapt, const od_coeff *y0, int k, int n,
+ int noref, int bs) {
+  double t0;
+  double t1;
+  double r;
+  if (!T.time_cpu) return pvq_codeword_rate_untimed(adapt, y0, k, n, noref, bs);
+  t0 = od_hipenc_now();
+  r = pvq_codeword_rate_untimed(adapt, y0, k, n, noref, bs);
+  t1 = od_hipenc_now();
+  rate_skeleton(y0, n - !noref, k);
+  T.st.rate_s += t1 - t0;
+  T.st.rate_state_free_s += od_hipenc_now() - t1;
+  T.st.rate_calls++;
+  return r;
+}
+
+static double pvq_codeword_rate_untimed(const od_adapt_ctx *adapt, const od_coeff *y0, int k, int n,
  int noref, int bs) {
   const od_pvq_codeword_ctx *cd;
   hip_rc c;

@@ -513,22 +513,6 @@ int od_hip_mc_set_ref(od_hip_mc *mc, int pli, int k, const unsigned char *plane,
 int od_hip_mc_predict(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int nblocks,
  unsigned char *dst, int dst_stride, int dst_w, int dst_h);
 
-/* F3: the encoder's SAD / SATD table od_enc_opt_vtbl (src/encint.h:61-82; C entries
- * od_mc_compute_sad8_NxN_c src/mcenc.c:1349-1372, od_mc_compute_satd8_NxN_c :1584-1660) for a
- * list of block pairs: out[i] = SAD or SATD between the 2^log_blk_sz square block at (sx, sy)
- * of the source plane and the one at (rx, ry) of the reference plane (a prediction or a
- * reference frame), 8-bit samples.  Building block for a batched candidate evaluation; the
- * reference's motion search itself (src/mcenc.c:6390) decides candidate by candidate and stays
- * host code. */
-typedef struct od_hip_mc_pair {
-  int32_t sx, sy, rx, ry;
-  int32_t log_blk_sz;
-  int32_t satd;
-} od_hip_mc_pair;
-int od_hip_mc_sad_pairs(const unsigned char *src, int src_stride, int src_h,
- const unsigned char *ref, int ref_stride, int ref_h, const od_hip_mc_pair *pairs, int npairs,
- int32_t *out);
-
 /* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
  * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks
  * (n = 4 << bs).  dst is in/out: entries the permutation does not write (a 32x32 block

@@ -23,8 +23,8 @@ def lib():
 def declared_symbols():
     hdr = open(os.path.join(ROOT, 'include', 'daala_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    names = re.findall(r'^(?:int|void|const char \*|od_hip_ctx \*)\s*(od_hip_\w+)\s*\(', hdr, re.M)
-    assert len(names) > 40
+    names = re.findall(r'^(?:int|long|void|const char \*|od_hip_\w+ \*)\s*(od_hip_\w+)\s*\(', hdr, re.M)
+    assert len(names) > 85
     return sorted(set(names))
 
 
@@ -56,6 +56,20 @@ def test_no_cpu_fallback_without_a_device(lib):
         b.pvq_search_vectors(np.zeros((1, 8)), np.ones(1, np.int32), np.ones(1))
     # argument validation happens before any device work
     assert lib.od_hip_fdct_blocks(7, None, None, 1) < 0
+
+
+def test_new_objects_refuse_without_a_device(lib):
+    """The round-3 objects (resident motion compensation, P-frame feed) have no CPU path either."""
+    import daala_amd.binding as b
+    if lib.od_hip_device_count() > 0:
+        pytest.skip('a device is present')
+    lib.od_hip_mc_create.restype = ctypes.c_void_p
+    assert not lib.od_hip_mc_create(0, 4)
+    g = b.Geometry()
+    g.pic_width, g.pic_height, g.frame_width, g.frame_height, g.nplanes, g.nslots = 64, 64, 64, 64, 3, 2
+    g.xdec[1] = g.xdec[2] = 1
+    lib.od_hip_pfeed_create.restype = ctypes.c_void_p
+    assert not lib.od_hip_pfeed_create(0, ctypes.byref(g))
 
 
 def test_product_never_imports_the_oracle():

@@ -695,39 +695,6 @@ def test_superblock_row_strips_in_c_equal_the_full_frame(hip):
     part.close()
 
 
-@pytest.mark.gpu
-def test_sad_satd_pairs_equal_oracle_and_golden():
-    """F3: od_hip_mc_sad_pairs (k_mc_sad_pairs) against the reference outputs of
-    tests/golden/mc_sad_pairs.npz and, on a larger random list, against the oracle."""
-    from daala_amd import binding as B
-    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mc_sad_pairs.npz'))
-    got = B.od_mc_sad_pairs(g['src'], g['ref'], [tuple(p) for p in g['pairs']])
-    assert np.array_equal(got, g['out'])
-    o = oracle()
-    o.orc_mc_sad8.restype = o.orc_mc_satd8.restype = ctypes.c_int32
-    U8P = ctypes.POINTER(ctypes.c_uint8)
-    rng = np.random.default_rng(9)
-    H, W, RW = 200, 328, 344
-    src = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
-    rf = rng.integers(0, 256, size=(H + 8, RW), dtype=np.uint8)
-    rf[:H, :W][::2] = src[::2]                                 # half the rows identical
-    rf[5] = 0; src[5] = 255                                    # extreme differences
-    pairs = []
-    for i in range(4000):
-        lg = int(rng.integers(2, 7)); n = 1 << lg
-        pairs.append((int(rng.integers(0, W - n + 1)), int(rng.integers(0, H - n + 1)),
-                      int(rng.integers(0, RW - n + 1)), int(rng.integers(0, H + 8 - n + 1)), lg, i & 1))
-    got = B.od_mc_sad_pairs(src, rf, pairs)
-    want = [(o.orc_mc_satd8 if sa else o.orc_mc_sad8)(
-        ctypes.cast(src.ctypes.data + sy*W + sx, U8P), W,
-        ctypes.cast(rf.ctypes.data + ry*RW + rx, U8P), RW, lg) for sx, sy, rx, ry, lg, sa in pairs]
-    assert np.array_equal(got, np.array(want, np.int32))
-    # edge cases: empty list, out-of-plane block refused
-    assert B.od_mc_sad_pairs(src, rf, []).size == 0
-    with pytest.raises(Exception):
-        B.od_mc_sad_pairs(src, rf, [(W - 4, 0, 0, 0, 3, 0)])
-
-
 def test_pframe_feed_complete_candidate_lists_vs_oracle(hip):
     """The P-frame feed (include/daala_hip.h 4d): for an input frame and a prediction, every band
     of every block of every level of every plane gets pvq_theta's COMPLETE candidate list on the
