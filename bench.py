@@ -251,6 +251,7 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    issue = time.perf_counter() - t0          # the host is done issuing; the device may not be
     ctx.sync()
     elapsed = time.perf_counter() - t0
     s_y, s_c = FW*FH, (FW//2)*(FH//2)
@@ -283,6 +284,7 @@ def device_step(ctx_args, frames, rank, steps, warmup, skip_pvq, world):
     alg_bytes.update({k: v[0] for k, v in pair_bytes.items()})
     out = {'Mpixels_per_s': round(FRAMES*PIC_W*PIC_H*steps/elapsed/1e6, 1),
            'ms_per_step': round(elapsed/steps*1e3, 3), 'steps': steps,
+           'host_issue_ms_per_step': round(issue/steps*1e3, 3),
            'host_compand_stage_s_once': round(compand_s, 4),
            'what': 'device-only hot path over 30 frames resident in HBM: forward pyramid, PVQ gain '
                    'pass + no-ref search pass of every band, forward known, inverse (no PCIe; the '
@@ -597,6 +599,15 @@ def main():
         nw = max(1, min(FRAMES, budget//world))
     prm = H.Params(PIC_W, PIC_H, 20, 7, 1, nw, 0, FRAMES)
     out = np.zeros(buf.size, np.uint8)
+    ds = roofline = None
+    if rank == 0:
+        # The kernel-level section (roofline of the dominant HBM-bound kernel, PVQ counters) on
+        # rank 0's GPU, BEFORE the session exists: measured on the boxes, once a device session
+        # with 8 or more workers has run in the process, every later launch shows 60-100 us more
+        # between its bracketing HIP events (kernel durations in a rocprofv3 trace are unchanged;
+        # DESIGN.md section 4) - the per-kernel figures are taken in the clean state.  The other
+        # ranks wait at the barrier below.
+        ds, roofline = device_step(local_rank, frames, rank, args.device_steps, 2, args.skip_pvq, world)
     ses = H.Session(prm, use_device=1, device=local_rank)     # no device -> raises
 
     def barrier():
@@ -649,9 +660,6 @@ def main():
                     'last_step_s': round(st.t_total_s, 4), 'session_setup_s': round(st.t_setup_s, 3)},
         }
     if rank == 0:
-        # the kernel-level section (roofline of the dominant HBM-bound kernel, PVQ counters):
-        # rank 0's GPU, after the timed region; at N > 1 the other ranks are done by now
-        ds, roofline = device_step(local_rank, frames, rank, args.device_steps, 2, args.skip_pvq, world)
         line['roofline'] = roofline
         line['device_step'] = ds
     if world == 1 and rank == 0:

@@ -46,6 +46,30 @@ double od_hipenc_now(void) {
 }
 #define now_s od_hipenc_now
 
+/* The fine-grained timers of HIPENC_TIME=1 (tens of millions of intervals of about a
+   microsecond per step) read the time stamp counter: a clock_gettime that is a system call on
+   this kind of guest costs as much as what it brackets.  Seconds per tick are calibrated once
+   per process against the monotonic clock. */
+static double tsc_period;
+static pthread_once_t tsc_once = PTHREAD_ONCE_INIT;
+static void tsc_calibrate(void) {
+  double t0;
+  double t1;
+  unsigned long long c0;
+  unsigned long long c1;
+  t0 = od_hipenc_now();
+  c0 = __builtin_ia32_rdtsc();
+  do t1 = od_hipenc_now(); while (t1 - t0 < 0.005);
+  c1 = __builtin_ia32_rdtsc();
+  tsc_period = (t1 - t0)/(double)(c1 - c0);
+}
+void od_hipenc_fine_timer_init(void) {
+  pthread_once(&tsc_once, tsc_calibrate);
+}
+double od_hipenc_fine_now(void) {
+  return (double)__builtin_ia32_rdtsc()*tsc_period;
+}
+
 /* pvq_search_rdo_double as the reference's own pvq_theta calls it (inter frames, and the
    reference's od_pvq_encode in check mode).  Check mode keeps the reference's C search (it is
    the checker there); otherwise vectors of 24 coefficients and more take the lane-wise search
@@ -54,8 +78,10 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
  double g2) {
   double t0;
   double r;
+  int timed;
   T.st.cpu_other++;
-  t0 = T.time_cpu ? now_s() : 0;
+  timed = T.time_cpu && ++T.search_tick % OD_HIPENC_TIME_SAMPLE == 0;
+  t0 = timed ? od_hipenc_fine_now() : 0;
   if (n >= 24 && !T.check) {
     /* the reference's pvq_theta searches one vector once per (gain, theta) candidate: while
        the input stays the same (compared by value) the search context is kept, so the
@@ -71,9 +97,9 @@ double pvq_search_rdo_double(const double *xcoeff, int n, int k, od_coeff *ypuls
     r = od_hip_search_run(&sc, k, ypulse, g2);
   }
   else r = od_ref_pvq_search_rdo_double_cpu(xcoeff, n, k, ypulse, g2);
-  if (T.time_cpu) {
+  if (timed) {
     double dt;
-    dt = now_s() - t0;
+    dt = OD_HIPENC_TIME_SAMPLE*(od_hipenc_fine_now() - t0);
     T.st.search_cpu_s += dt;
     T.st.search_class_s[(T.pli != 0)*2 + !(n == 15 || n == 8 || n == 32 || n == 128)] += dt;
   }
@@ -1046,6 +1072,7 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     S->sample_every = e != NULL ? atoi(e) : 256;
     e = getenv("HIPENC_TIME");
     S->time_cpu = e != NULL && atoi(e) != 0;
+    if (S->time_cpu) od_hipenc_fine_timer_init();
     e = getenv("HIPENC_FDCT_MIN_BS");
     if (e != NULL) fdct_min_bs = atoi(e);
     e = getenv("HIPENC_PFEED");

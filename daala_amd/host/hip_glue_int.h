@@ -39,6 +39,7 @@ typedef struct glue_tls {
   od_hip_pfeed *pf;
   int pf_valid;
   double t_frame0;                /* start of the frame being coded (timers) */
+  unsigned search_tick;           /* sampling counter of the search timers */
   od_hip_pfeed_level pfv[3][4];
   od_hipenc_stats st;
 } glue_tls;
@@ -62,6 +63,9 @@ void od_encode_checkpoint_cpu(const daala_enc_ctx *enc, od_rollback_buffer *rbuf
 void od_encode_rollback_cpu(daala_enc_ctx *enc, const od_rollback_buffer *rbuf);
 
 double od_hipenc_now(void);
+double od_hipenc_fine_now(void);   /* time stamp counter, seconds; HIPENC_TIME=1 only */
+void od_hipenc_fine_timer_init(void);
+#define OD_HIPENC_TIME_SAMPLE 61   /* the per-call timers time one call in this many */
 /* src/pvq_encoder.c:589 (no prototype in the reference's headers) */
 int od_rdo_quant(od_coeff x, int q, double delta0);
 

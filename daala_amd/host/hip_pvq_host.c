@@ -288,13 +288,16 @@ static double pvq_codeword_rate(const od_adapt_ctx *adapt, const od_coeff *y0, i
   double t1;
   double r;
   if (!T.time_cpu) return pvq_codeword_rate_untimed(adapt, y0, k, n, noref, bs);
-  t0 = od_hipenc_now();
-  r = pvq_codeword_rate_untimed(adapt, y0, k, n, noref, bs);
-  t1 = od_hipenc_now();
-  rate_skeleton(y0, n - !noref, k);
-  T.st.rate_s += t1 - t0;
-  T.st.rate_state_free_s += od_hipenc_now() - t1;
   T.st.rate_calls++;
+  /* one call in OD_HIPENC_TIME_SAMPLE is timed and stands for all of them: a timer read costs
+     about as much as a pricing on these guests, timing every call triples the step */
+  if (T.st.rate_calls % OD_HIPENC_TIME_SAMPLE) return pvq_codeword_rate_untimed(adapt, y0, k, n, noref, bs);
+  t0 = od_hipenc_fine_now();
+  r = pvq_codeword_rate_untimed(adapt, y0, k, n, noref, bs);
+  t1 = od_hipenc_fine_now();
+  rate_skeleton(y0, n - !noref, k);
+  T.st.rate_s += OD_HIPENC_TIME_SAMPLE*(t1 - t0);
+  T.st.rate_state_free_s += OD_HIPENC_TIME_SAMPLE*(od_hipenc_fine_now() - t1);
   return r;
 }
 
@@ -459,10 +462,10 @@ static void reflect(double *x, double *r, const od_coeff *x0, const od_coeff *r0
 static inline double timed_search(od_hip_search *sc, int k, od_coeff *y, double g2, int cls) {
   double t0;
   double r;
-  if (!T.time_cpu) return od_hip_search_run(sc, k, y, g2);
-  t0 = od_hipenc_now();
+  if (!T.time_cpu || ++T.search_tick % OD_HIPENC_TIME_SAMPLE) return od_hip_search_run(sc, k, y, g2);
+  t0 = od_hipenc_fine_now();
   r = od_hip_search_run(sc, k, y, g2);
-  t0 = od_hipenc_now() - t0;
+  t0 = OD_HIPENC_TIME_SAMPLE*(od_hipenc_fine_now() - t0);
   T.st.search_cpu_s += t0;
   T.st.search_class_s[cls] += t0;
   return r;
