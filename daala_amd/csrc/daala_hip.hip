@@ -1989,4 +1989,5 @@ int od_hip_timing_get(od_hip_ctx *ctx, const char *kernel, int *launches, double
 
 #include "enc_feed.hpp"
 #include "pfeed.hpp"
+#include "dsynth.hpp"
 #include "comm.hpp"

@@ -249,6 +249,14 @@ def md_stats():
     return int(out[0]), int(out[1])
 
 
+def synth_stats():
+    """(P frames of the last decode whose PVQ synthesis ran on the device - the host parsed
+    symbols only -, check-mode mismatches of reference gains / coefficient planes)."""
+    out = (ctypes.c_long*2)()
+    hipenc().od_hipdec_synth_stats(out)
+    return int(out[0]), int(out[1])
+
+
 def tail_frames():
     """Frames of the last decode whose pixel-domain stage (od_hip_decode_tail) ran on the device."""
     f = hipenc().od_hipdec_tail_frames

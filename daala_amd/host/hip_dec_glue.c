@@ -27,6 +27,8 @@
 
 #include "decint.h"
 #include "filter.h"
+#include "partition.h"
+#include "pvq.h"
 #include "state.h"
 
 #include "hip_enc_glue.h"
@@ -93,6 +95,21 @@ typedef struct dec_tls {
   int haar_frame;           /* the frame being decoded uses the Haar wavelet with a quantizer > 0: host path */
   int check;
   double t_device;
+  /* P frames: PVQ synthesis on the device (below) */
+  od_hip_dsynth *ds;
+  int ds_off;               /* HIPDEC_SYNTH=0 */
+  int ds_on;                /* this frame's blocks are recorded for the device */
+  int ds_overflow;
+  od_hip_dsynth_block *ds_blocks;
+  od_hip_dsynth_band *ds_bands;
+  int16_t *ds_pulses;
+  long ds_max_blocks, ds_max_bands, ds_max_pulses;
+  long ds_nblocks, ds_nbands, ds_npulses;
+  const double *ds_gr[3][4];
+  long ds_cur;              /* record of the block being parsed, -1: none */
+  unsigned ds_cur_mask;     /* its bands that went through pvq_synthesis */
+  int ds_md_sentinel;       /* state->mdtmp holds DS_SENTINEL everywhere */
+  int16_t *ds_qm_seen;      /* the tables the device holds */
 } dec_tls;
 
 static __thread dec_tls D;
@@ -103,6 +120,10 @@ static long g_tail_dev_frames;
 static long g_md_hits;            /* prediction-side transforms served from the device pyramid */
 static long g_md_check_fail;
 static __thread long mc_check_fail;
+static __thread long ds_frames;          /* P frames whose PVQ synthesis ran on the device */
+static __thread long ds_check_fail;
+static long g_ds_frames;
+static long g_ds_check_fail;
 static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
 static long g_mc_check_fail;
 
@@ -113,6 +134,13 @@ void od_hipdec_md_stats(long out[2]) {
 
 long od_hipdec_tail_frames(void) {
   return g_tail_dev_frames;
+}
+
+/* After od_hipdec_decode_frames: out[0] = P frames whose PVQ synthesis ran on the device,
+   out[1] = check-mode mismatches (reference gains, coefficient planes). */
+void od_hipdec_synth_stats(long out[2]) {
+  out[0] = g_ds_frames;
+  out[1] = g_ds_check_fail;
 }
 
 void od_hipdec_mc_stats(long out[2]) {
@@ -147,6 +175,8 @@ static void haar_frame_seen(void) {
   int pli;
   if (D.dec == NULL || D.ctx == NULL || D.haar_frame || D.dec->state.quantizer[0] == 0) return;
   D.haar_frame = 1;
+  D.ds_on = 0;
+  D.ds_md_sentinel = 0;
   st = &D.dec->state;
   if (D.md_valid && !D.check) {
     od_img *rec;
@@ -225,6 +255,215 @@ void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, in
   od_prefilter_split_cpu(c0, stride, bs, f, hfilter, vfilter);
 }
 
+/* ------------------------------------------------------------------------ */
+/* P frames: PVQ synthesis on the device (include/daala_hip.h section 4e).
+   The reference of every band of a P frame is the prediction's transform, which the device
+   holds (md_pyramid): the decoder thread only PARSES.  The reference's od_block_decode /
+   od_pvq_decode (src/decode.c:536-640, src/pvq_decoder.c:312-388) stay the code that runs;
+   four of their leaf calls are bound by the build (Makefile):
+     fdct_2d of the prediction      md_fdct(): names the block (plane, size, origin)
+     od_pvq_compute_gain(ref, ..)   od_hipdec_pvq_compute_gain(): gr from the device's gain pass
+     pvq_synthesis(..)              records (gain, theta -> host sin / cos, pulses)
+     od_coding_order_to_raster(..)  od_hipdec_coding_order_to_raster(): closes the block - DC,
+                                    which bands were cleared (OD_PVQ_SKIP_ZERO)
+   Nothing else of the parse reads the reference VALUES, so the host's mdtmp planes are not
+   filled at all: they hold a sentinel, a band that still holds it after od_pvq_decode was
+   copied from the reference (OD_PVQ_SKIP_COPY, skipped blocks) and needs no record - the
+   device starts every block from the prediction's transform (od_init_skipped_coeffs).  The
+   33 MB of level planes down and the 12.5 MB of coefficients up per 1080p frame become
+   4 MB of gains down and the records up.  Check mode keeps the reference's host path with
+   real planes beside it and compares the gains and the finished coefficient planes. */
+#define DS_SENTINEL (1 << 28)
+
+static int ds_lvl(int pli, int bs) {
+  return (pli > 0 ? 2 : 3) - bs;
+}
+
+static const int DS_OFF[] = {1, 16, 24, 32, 64, 96, 128, 256, 384, 512};
+static const int DS_NB[4] = {1, 4, 7, 9};
+
+static void ds_begin_block(int pli, int bs, long org) {
+  od_hip_dsynth_block *b;
+  D.ds_cur = -1;
+  if (D.ds_nblocks >= D.ds_max_blocks) {
+    D.ds_overflow = 1;
+    return;
+  }
+  b = D.ds_blocks + D.ds_nblocks;
+  b->org = (int32_t)org;
+  b->dc = 0;
+  b->pli = (uint8_t)pli;
+  b->bs = (uint8_t)bs;
+  b->pad[0] = b->pad[1] = 0;
+  D.ds_cur = D.ds_nblocks++;
+  D.ds_cur_mask = 0;
+}
+
+/* which band of the current block a qm pointer of od_pvq_decode belongs to */
+static int ds_band_of(const int16_t *qm) {
+  const od_state *st;
+  const od_hip_dsynth_block *b;
+  long o;
+  int i;
+  st = &D.dec->state;
+  b = D.ds_blocks + D.ds_cur;
+  o = qm - (st->qm + od_qm_offset(b->bs, b->pli > 0));
+  for (i = 0; i < DS_NB[b->bs]; i++) if (DS_OFF[i] == o) return i;
+  return -1;
+}
+
+double od_hipdec_pvq_compute_gain(od_coeff *x, int n, int q0, double *g, double beta,
+ const int16_t *qm) {
+  if (D.ds_on && D.ds_cur >= 0 && D.dec != NULL) {
+    const od_hip_dsynth_block *b;
+    int band;
+    b = D.ds_blocks + D.ds_cur;
+    band = ds_band_of(qm);
+    if (band >= 0 && DS_OFF[band + 1] - DS_OFF[band] == n) {
+      int w;
+      int bn;
+      long blk;
+      long nblk;
+      double gr;
+      double cg2;
+      w = D.dec->state.frame_width >> (b->pli > 0);
+      bn = 4 << b->bs;
+      blk = (b->org/w/bn)*(w/bn) + (b->org%w)/bn;
+      nblk = (long)(w/bn)*((D.dec->state.frame_height >> (b->pli > 0))/bn);
+      gr = D.ds_gr[b->pli][ds_lvl(b->pli, b->bs)][band*nblk + blk];
+      cg2 = 0;
+      if (D.check) {
+        double g2;
+        cg2 = od_pvq_compute_gain(x, n, q0, &g2, beta, qm);
+        if (g2 != gr) ds_check_fail++;
+      }
+      *g = gr;
+      {
+        /* od_gain_compand (static, src/pvq.c:422-425) as the C-ABI restates it on the host:
+           this process's pow; check mode compares with the reference's own return value */
+        double cgr;
+        if (od_hip_pvq_compand(1, &gr, q0, beta, &cgr) != 0) D.ds_overflow = 1;
+        if (D.check && cgr != cg2) ds_check_fail++;
+        return cgr;
+      }
+    }
+    D.ds_overflow = 1;
+  }
+  return od_pvq_compute_gain(x, n, q0, g, beta, qm);
+}
+
+void pvq_synthesis_cpu(od_coeff *xcoeff, od_coeff *ypulse, od_coeff *ref, int n, double gr,
+ int noref, double g, double theta, const int16_t *qm, const int16_t *qm_inv);
+void pvq_synthesis(od_coeff *xcoeff, od_coeff *ypulse, od_coeff *ref, int n, double gr,
+ int noref, double g, double theta, const int16_t *qm, const int16_t *qm_inv) {
+  if (D.ds_on && D.ds_cur >= 0 && D.dec != NULL) {
+    int band;
+    int nn;
+    band = ds_band_of(qm);
+    nn = n - !noref;
+    if (band >= 0 && DS_OFF[band + 1] - DS_OFF[band] == n && D.ds_nbands < D.ds_max_bands
+     && D.ds_npulses + nn <= D.ds_max_pulses) {
+      od_hip_dsynth_band *r;
+      int16_t *y;
+      int i;
+      r = D.ds_bands + D.ds_nbands++;
+      r->block = (uint32_t)D.ds_cur;
+      r->band = (uint8_t)band;
+      r->mode = noref ? OD_HIP_DSYNTH_NOREF : OD_HIP_DSYNTH_REF;
+      r->pad[0] = r->pad[1] = 0;
+      r->yoff = (uint32_t)D.ds_npulses;
+      r->pad2 = 0;
+      r->g = g;
+      /* od_pvq_synthesis_partial's sin(theta), cos(theta) (src/pvq.c:574-577): this process's libm */
+      r->sin_theta = noref ? 0 : sin(theta);
+      r->cos_theta = noref ? 0 : cos(theta);
+      y = D.ds_pulses + D.ds_npulses;
+      for (i = 0; i < nn; i++) y[i] = (int16_t)ypulse[i];
+      D.ds_npulses += nn;
+      D.ds_cur_mask |= 1u << band;
+    }
+    else D.ds_overflow = 1;
+    if (!D.check) return;
+  }
+  pvq_synthesis_cpu(xcoeff, ypulse, ref, n, gr, noref, g, theta, qm, qm_inv);
+}
+
+void od_hipdec_coding_order_to_raster(od_coeff *dst, int stride, const od_coeff *src, int n) {
+  if (D.ds_on && D.ds_cur >= 0 && D.dec != NULL) {
+    od_hip_dsynth_block *b;
+    const od_state *st;
+    int i;
+    st = &D.dec->state;
+    b = D.ds_blocks + D.ds_cur;
+    if (dst == st->dtmp[b->pli] + b->org && n == 4 << b->bs) {
+      b->dc = src[0] - st->mdtmp[b->pli][b->org];
+      for (i = 0; i < DS_NB[b->bs]; i++) {
+        int j;
+        int len;
+        if (D.ds_cur_mask >> i & 1) continue;
+        len = DS_OFF[i + 1] - DS_OFF[i];
+        for (j = 0; j < len && src[DS_OFF[i] + j] == 0; j++);
+        if (j < len) continue;          /* still the reference (sentinel): copied, no record */
+        if (D.ds_nbands >= D.ds_max_bands) {
+          D.ds_overflow = 1;
+          break;
+        }
+        memset(D.ds_bands + D.ds_nbands, 0, sizeof(*D.ds_bands));
+        D.ds_bands[D.ds_nbands].block = (uint32_t)D.ds_cur;
+        D.ds_bands[D.ds_nbands].band = (uint8_t)i;
+        D.ds_bands[D.ds_nbands].mode = OD_HIP_DSYNTH_ZERO;
+        D.ds_nbands++;
+      }
+    }
+    else D.ds_overflow = 1;
+    D.ds_cur = -1;
+    if (!D.check) return;               /* the host's dtmp plane is not what the device reads */
+  }
+  od_coding_order_to_raster(dst, stride, src, n);
+}
+
+/* per P frame, after the prediction's pyramid: tables (when they changed), gains, a clean
+   record list */
+static int ds_frame_begin(od_state *state) {
+  int pli;
+  int bs;
+  size_t qn;
+  D.ds_on = 0;
+  if (D.ds == NULL) return 0;
+  qn = OD_QM_BUFFER_SIZE*sizeof(state->qm[0]);
+  if (D.ds_qm_seen == NULL) {
+    D.ds_qm_seen = (int16_t *)malloc(2*qn);
+    if (D.ds_qm_seen == NULL) return -1;
+    memset(D.ds_qm_seen, 0xff, 2*qn);
+  }
+  if (memcmp(D.ds_qm_seen, state->qm, qn) != 0 || memcmp((char *)D.ds_qm_seen + qn, state->qm_inv, qn) != 0) {
+    for (pli = 0; pli < 3; pli++) {
+      for (bs = 0; bs < (pli > 0 ? 3 : 4); bs++) {
+        int off;
+        off = od_qm_offset(bs, pli > 0);
+        if (od_hip_dsynth_set_level(D.ds, pli, ds_lvl(pli, bs), state->qm + off, state->qm_inv + off) != 0) return -2;
+      }
+    }
+    memcpy(D.ds_qm_seen, state->qm, qn);
+    memcpy((char *)D.ds_qm_seen + qn, state->qm_inv, qn);
+  }
+  if (od_hip_dsynth_ref_gains(D.ds, D.ds_gr) != 0) return -3;
+  if (!D.check && !D.ds_md_sentinel) {
+    for (pli = 0; pli < 3; pli++) {
+      size_t i;
+      size_t np;
+      np = (size_t)(state->frame_width >> (pli > 0))*(state->frame_height >> (pli > 0));
+      for (i = 0; i < np; i++) state->mdtmp[pli][i] = DS_SENTINEL;
+    }
+    D.ds_md_sentinel = 1;
+  }
+  D.ds_nblocks = D.ds_nbands = D.ds_npulses = 0;
+  D.ds_cur = -1;
+  D.ds_overflow = 0;
+  D.ds_on = 1;
+  return 0;
+}
+
 static void md_fdct(int bs, od_coeff *y, int ystride, const od_coeff *x, int xstride) {
   if (D.md_valid && D.dec != NULL && D.dec->state.quantizer[0] > 0) {
     const od_state *st;
@@ -240,10 +479,16 @@ static void md_fdct(int bs, od_coeff *y, int ystride, const od_coeff *x, int xst
       n = 4 << bs;
       lvl = (pli > 0 ? 2 : 3) - bs;
       off = (size_t)(y - st->mdtmp[pli]);
-      if (ystride == w && lvl >= 0 && D.md[pli][lvl] != NULL && (off/w & (n - 1)) == 0
+      if (ystride == w && lvl >= 0 && (D.md[pli][lvl] != NULL || (D.ds_on && !D.check)) && (off/w & (n - 1)) == 0
        && (off%w & (n - 1)) == 0) {
         const od_coeff *src;
         int i;
+        if (D.ds_on) ds_begin_block(pli, bs, (long)off);
+        if (D.ds_on && !D.check) {
+          /* the prediction's transform stays on the device: mdtmp keeps its sentinel */
+          D.md_hits++;
+          return;
+        }
         src = D.md[pli][lvl] + off;
         if (D.check) {
           od_coeff tmp[32*32];
@@ -260,6 +505,12 @@ static void md_fdct(int bs, od_coeff *y, int ystride, const od_coeff *x, int xst
         return;
       }
     }
+  }
+  D.ds_md_sentinel = 0;
+  if (D.ds_on) {
+    /* a block of a frame recorded for the device took the host transform: the records no
+       longer cover the frame */
+    D.ds_overflow = 1;
   }
   (*D.fdct_cpu[bs])(y, ystride, x, xstride);
 }
@@ -281,6 +532,19 @@ static int md_pyramid(od_state *state, od_img *pred) {
   int lvl;
   double t0;
   t0 = now_s();
+  if (D.ds == NULL && !D.ds_off) {
+    /* HIPDEC_SYNTH=0: the PVQ synthesis of P frames stays on the host (A/B, tests) */
+    const char *e;
+    e = getenv("HIPDEC_SYNTH");
+    D.ds_off = e != NULL && atoi(e) == 0;
+    if (!D.ds_off) {
+      D.ds = od_hip_dsynth_create(D.ctx);
+      if (D.ds == NULL || od_hip_dsynth_buffers(D.ds, &D.ds_blocks, &D.ds_max_blocks, &D.ds_bands,
+       &D.ds_max_bands, &D.ds_pulses, &D.ds_max_pulses) != 0) {
+        return -6;
+      }
+    }
+  }
   for (pli = 0; pli < 3; pli++) {
     int nl;
     size_t np;
@@ -288,7 +552,7 @@ static int md_pyramid(od_state *state, od_img *pred) {
     np = (size_t)(state->frame_width >> (pli > 0))*(state->frame_height >> (pli > 0))*sizeof(od_coeff);
     np = (np + 4095) & ~(size_t)4095;
     for (lvl = 0; lvl < nl; lvl++) {
-      if (D.md[pli][lvl] == NULL) {
+      if (D.md[pli][lvl] == NULL && (D.ds == NULL || D.check)) {
         void *mem;
         mem = NULL;
         if (posix_memalign(&mem, 4096, np) != 0) return -1;
@@ -301,9 +565,12 @@ static int md_pyramid(od_state *state, od_img *pred) {
   }
   if (od_hip_upload_planes(D.ctx, 0, planes, strides) != 0) return -2;
   if (od_hip_forward_pyramid(D.ctx, 0, 1) != 0) return -3;
-  for (pli = 0; pli < 3; pli++) {
-    for (lvl = 0; lvl < (pli > 0 ? 3 : 4); lvl++) {
-      if (od_hip_download_level(D.ctx, 0, pli, lvl, D.md[pli][lvl]) != 0) return -4;
+  if (D.ds != NULL && ds_frame_begin(state) != 0) return -5;
+  if (!D.ds_on || D.check) {
+    for (pli = 0; pli < 3; pli++) {
+      for (lvl = 0; lvl < (pli > 0 ? 3 : 4); lvl++) {
+        if (od_hip_download_level(D.ctx, 0, pli, lvl, D.md[pli][lvl]) != 0) return -4;
+      }
     }
   }
   D.t_device += now_s() - t0;
@@ -359,19 +626,54 @@ void od_smooth_recursive(od_coeff *c, unsigned char *bsize, int bstride, int bx,
 
 static int injected_failure(void);
 
+/* Which device stage failed and with what code (the frame itself is reported through
+   daala_decode_packet_in's OD_EFAULT): one line on stderr when HIPDEC_DEBUG is set. */
+static void stage_failed(const char *stage, int rc) {
+  if (getenv("HIPDEC_DEBUG") != NULL) {
+    fprintf(stderr, "daala_hipdec: %s failed (step %d): %s\n", stage, rc, od_hip_last_error());
+  }
+}
+
 static int device_frame(od_state *state) {
   const unsigned char *bskip[3];
   int32_t thr[3];
   int32_t quant[3];
   int pli;
   int nplanes;
+  int synth;
   double t0;
   if (injected_failure()) return -9;
   t0 = now_s();
   nplanes = state->info.nplanes;
   if (od_hip_set_bsize(D.ctx, 0, state->bsize, state->bstride) != 0) return -1;
+  synth = D.ds_on && state->frame_type == OD_P_FRAME;
+  if (synth) {
+    if (D.ds_overflow || D.ds_cur >= 0) return -6;
+    if (od_hip_dsynth_run(D.ds, D.ds_nblocks, D.ds_nbands, D.ds_npulses) != 0) return -7;
+    ds_frames++;
+    if (D.check) {
+      /* the reference's host path filled dtmp from real planes: the device's must be equal */
+      for (pli = 0; pli < nplanes; pli++) {
+        size_t np;
+        od_coeff *got;
+        np = (size_t)(state->frame_width >> (pli > 0))*(state->frame_height >> (pli > 0));
+        got = (od_coeff *)malloc(np*sizeof(od_coeff));
+        if (got == NULL || od_hip_download_coeffs(D.ctx, 0, pli, got) != 0
+         || memcmp(got, state->dtmp[pli], np*sizeof(od_coeff)) != 0) {
+          ds_check_fail++;
+        }
+        free(got);
+      }
+    }
+  }
+  D.ds_on = 0;
   for (pli = 0; pli < nplanes; pli++) {
     const od_coeff *src;
+    bskip[pli] = state->bskip[pli];
+    quant[pli] = state->quantizer[pli];
+    /* od_dering's threshold (src/filter.c:1876), host libm as in the reference */
+    thr[pli] = (int32_t)(1.0*pow(state->quantizer[pli], 0.84182));
+    if (synth) continue;
     src = state->dtmp[pli];
     if (D.stage[pli] != NULL) {
       memcpy(D.stage[pli], src, sizeof(od_coeff)*(size_t)(state->frame_width >> (pli > 0))
@@ -379,10 +681,6 @@ static int device_frame(od_state *state) {
       src = D.stage[pli];
     }
     if (od_hip_upload_coeffs(D.ctx, 0, pli, src) != 0) return -2;
-    bskip[pli] = state->bskip[pli];
-    quant[pli] = state->quantizer[pli];
-    /* od_dering's threshold (src/filter.c:1876), host libm as in the reference */
-    thr[pli] = (int32_t)(1.0*pow(state->quantizer[pli], 0.84182));
   }
   if (od_hip_set_decode_info(D.ctx, 0, state->dering_flags, bskip,
    state->skip_stride) != 0) return -3;
@@ -460,7 +758,10 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
     return;
   }
   if (pli == 0) {
-    if (D.idct_skipped == 0 || device_frame(state) != 0) {
+    int rc;
+    rc = D.idct_skipped == 0 ? -100 : device_frame(state);
+    if (rc != 0) {
+      stage_failed("pixel-domain stage", rc);
       /* The device pass for a frame whose inverse transforms were skipped has failed (or,
          idct_skipped == 0, a frame reached this point without a single block: malformed).
          No picture exists: the frame is reported as failed - daala_decode_packet_in returns
@@ -496,9 +797,11 @@ int daala_decode_packet_in(daala_dec_ctx *dec, const daala_packet *op) {
   D.failed = 0;
   D.idct_skipped = 0;
   D.haar_skipped = 0;
+  D.ds_on = 0;
   rc = daala_decode_packet_in_cpu(dec, op);
   D.dec = NULL;
   D.md_valid = 0;
+  D.ds_on = 0;
   if (rc >= 0 && D.failed) rc = OD_EFAULT;
   return rc;
 }
@@ -703,6 +1006,8 @@ static void *dworker(void *arg) {
   g_tail_dev_frames += tail_dev_frames;
   tail_dev_frames = 0;
   g_md_hits += D.md_hits;
+  g_ds_frames += ds_frames;
+  g_ds_check_fail += ds_check_fail;
   g_md_check_fail += D.md_check_fail;
   g_mc_check_fail += mc_check_fail;
   mc_dev_frames = mc_check_fail = 0;
@@ -725,6 +1030,8 @@ static void *dworker(void *arg) {
     free(D.stage[pli]);
   }
   od_hipdec_thread_cleanup();
+  if (D.ds != NULL) od_hip_dsynth_destroy(D.ds);
+  free(D.ds_qm_seen);
   if (D.ctx != NULL) od_hip_ctx_destroy(D.ctx);
   for (pli = 0; pli < 3; pli++) free(D.rec[pli]);
   if (dec != NULL) daala_decode_free(dec);
@@ -910,8 +1217,13 @@ void od_state_mc_predict(od_state *state, od_img *img_dst) {
       mc_dev_frames++;
       if (D.ctx != NULL && D.dec != NULL && state == &D.dec->state
        && state->info.nplanes == 3 && state->frame_type == OD_P_FRAME) {
-        D.md_valid = md_pyramid(state, img_dst) == 0;
-        if (!D.md_valid) D.failed = 1;      /* surfaced by daala_decode_packet_in, no silent host path */
+        int rc;
+        rc = md_pyramid(state, img_dst);
+        D.md_valid = rc == 0;
+        if (!D.md_valid) {
+          D.failed = 1;      /* surfaced by daala_decode_packet_in, no silent host path */
+          stage_failed("prediction pyramid", rc);
+        }
       }
       /* encoder threads: the frame's prediction exists - the P-frame feed can run */
       if (D.ctx == NULL && od_hipenc_device_thread() && od_hipenc_pframe_feed(state, img_dst) < 0) D.failed = 1;
@@ -968,6 +1280,7 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   g_mc_dev_frames = g_mc_check_fail = 0;
   g_tail_dev_frames = 0;
   g_md_hits = g_md_check_fail = 0;
+  g_ds_frames = g_ds_check_fail = 0;
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;

@@ -382,6 +382,47 @@ int od_hip_pfeed_search(od_hip_pfeed *pf);
 int od_hip_pfeed_view(od_hip_pfeed *pf, int pli, int level, od_hip_pfeed_level *v);
 
 /* ---------------------------------------------------------------------------
+ * 4e. Decoder-side PVQ synthesis of an inter frame: pvq_synthesis (src/pvq_decoder.c:104-118) =
+ *    od_compute_householder + od_pvq_synthesis_partial (src/pvq.c:364-413, :552-585) of every
+ *    coded band, od_init_skipped_coeffs (src/state.c:1351-1357), the DC (src/decode.c:599-609)
+ *    and od_coding_order_to_raster (src/partition.c:176) of every block, written into the
+ *    context's coefficient planes of slot 0 - what od_hip_decode_tail reads.  On a P frame the
+ *    reference of every band is the transform of the motion-compensated prediction: the object
+ *    is attached to a context whose slot 0 holds od_hip_forward_pyramid of the prediction.
+ *    The host only parses symbols:
+ *      od_hip_dsynth_ref_gains  gr = od_pvq_compute_gain's *g (src/pvq.c:456-464) of every band
+ *                               of every block size, [band][block at that level]: the parse
+ *                               needs it (src/pvq_decoder.c:221-240);
+ *      od_hip_dsynth_buffers    page-locked record buffers the parse fills in place;
+ *      od_hip_dsynth_run        uploads nblocks / nbands / npulses entries of them and runs.
+ *    Every sample of the frame must belong to exactly one block record.  Bands that copy the
+ *    reference (OD_PVQ_SKIP_COPY, skipped blocks, the uncoded half of a 32x32) need no record.
+ *    g is od_gain_expand's result, sin_theta / cos_theta the host's libm of the decoded theta. */
+typedef struct od_hip_dsynth od_hip_dsynth;
+typedef struct od_hip_dsynth_block {
+  int32_t org;          /* raster origin in the plane: (by*4)*(frame_width >> xdec) + bx*4 */
+  int32_t dc;           /* decoded DC minus the prediction's: pred[0]*dc_quant (src/decode.c:608) */
+  uint8_t pli, bs, pad[2];
+} od_hip_dsynth_block;
+#define OD_HIP_DSYNTH_ZERO 0     /* OD_PVQ_SKIP_ZERO: the band is cleared */
+#define OD_HIP_DSYNTH_NOREF 1    /* synthesis without reference, n pulses */
+#define OD_HIP_DSYNTH_REF 2      /* synthesis with reference, n - 1 pulses */
+typedef struct od_hip_dsynth_band {
+  uint32_t block;       /* index of the band's block in the block records */
+  uint8_t band, mode, pad[2];
+  uint32_t yoff;        /* first pulse of the band in the pulse buffer */
+  uint32_t pad2;
+  double g, sin_theta, cos_theta;
+} od_hip_dsynth_band;
+od_hip_dsynth *od_hip_dsynth_create(od_hip_ctx *ctx);
+void od_hip_dsynth_destroy(od_hip_dsynth *s);
+int od_hip_dsynth_set_level(od_hip_dsynth *s, int pli, int level, const int16_t *qm, const int16_t *qm_inv);
+int od_hip_dsynth_ref_gains(od_hip_dsynth *s, const double *gr[3][4]);
+int od_hip_dsynth_buffers(od_hip_dsynth *s, od_hip_dsynth_block **blocks, long *max_blocks,
+ od_hip_dsynth_band **bands, long *max_bands, int16_t **pulses, long *max_pulses);
+int od_hip_dsynth_run(od_hip_dsynth *s, long nblocks, long nbands, long npulses);
+
+/* ---------------------------------------------------------------------------
  * 4c. Encoder-side deringing: od_dering() (src/filter.c:1835) of EVERY 32x32 superblock of
  *    one frame in one pass - what the encoder's filter on/off loop (src/encode.c:2552-2685)
  *    asks for superblock by superblock.  in[pli]: the unfiltered post-filter planes

@@ -236,13 +236,43 @@ def test_inter_stream_motion_compensation_on_the_device():
     assert H.tail_frames() == nf             # I and P frames: inverse + filters + clamp on the device
     hits, md_bad = H.md_stats()
     assert hits > 0 and md_bad == 0          # check mode: device prediction pyramid == host transforms
+    # the P frames' PVQ synthesis (Householder + od_pvq_synthesis_partial + scatter of every coded
+    # band, DC, skipped coefficients) ran on the device from parsed symbols; check mode compared
+    # every reference gain and the finished coefficient planes with the reference's host path
+    synth, synth_bad = H.synth_stats()
+    assert synth == 4 and synth_bad == 0
     assert np.array_equal(got, want)
     assert np.array_equal(got[-1], rec)
-    # without check mode the prediction side of every P frame is the device pyramid alone
+    # without check mode the prediction side of every P frame is the device pyramid alone: no
+    # level plane comes to the host, no coefficient plane goes to the device
     prm.check = 0
     nd, got2, _, _ = H.decode(prm, hdr, pk, use_device=1)
     hits2, _ = H.md_stats()
     assert nd == nf and hits2 == hits and np.array_equal(got2, want)
+    assert H.synth_stats() == (4, 0)
+
+
+def test_inter_decode_1080p_synthesis_on_the_device(monkeypatch):
+    """configs[3] at its own size, decoder side: 1920x1080 I P P from the pure reference encoder.
+    The P frames' prediction (OBMC), its forward pyramid, the PVQ synthesis of every band and the
+    whole pixel-domain stage run on the device; the host parses symbols.  Pictures identical to
+    the reference decoder's; the same with the synthesis left on the host (HIPDEC_SYNTH=0)."""
+    from test_hipenc_cpu import inter_stream
+    w, h, nf = 1920, 1080, 3
+    pk, rec = inter_stream(w, h, nf, keyrate=30)
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0)
+    hdr = H.headers(prm)
+    n0, want, s0, _ = H.decode(prm, hdr, pk)
+    nd, got, s1, _ = H.decode(prm, hdr, pk, use_device=1)
+    assert n0 == nf and nd == nf and np.array_equal(got, want) and np.array_equal(got[-1], rec)
+    assert H.synth_stats() == (2, 0)
+    nd, got, s1, _ = H.decode(prm, hdr, pk, use_device=1)       # warm
+    monkeypatch.setenv('HIPDEC_SYNTH', '0')
+    nd2, got2, s2, _ = H.decode(prm, hdr, pk, use_device=1)
+    nd2, got2, s2, _ = H.decode(prm, hdr, pk, use_device=1)
+    assert nd2 == nf and np.array_equal(got2, want) and H.synth_stats() == (0, 0)
+    print('1080p I P P decode: reference %.3f s, device with synthesis %.3f s, synthesis on the host %.3f s'
+          % (s0, s1, s2))
 
 
 def test_stream_ordering_regression_many_workers_repeated():
