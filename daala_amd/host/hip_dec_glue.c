@@ -108,7 +108,6 @@ typedef struct dec_tls {
   const double *ds_gr[3][4];
   long ds_cur;              /* record of the block being parsed, -1: none */
   unsigned ds_cur_mask;     /* its bands that went through pvq_synthesis */
-  int ds_md_sentinel;       /* state->mdtmp holds DS_SENTINEL everywhere */
   int16_t *ds_qm_seen;      /* the tables the device holds */
 } dec_tls;
 
@@ -176,7 +175,6 @@ static void haar_frame_seen(void) {
   if (D.dec == NULL || D.ctx == NULL || D.haar_frame || D.dec->state.quantizer[0] == 0) return;
   D.haar_frame = 1;
   D.ds_on = 0;
-  D.ds_md_sentinel = 0;
   st = &D.dec->state;
   if (D.md_valid && !D.check) {
     od_img *rec;
@@ -266,13 +264,17 @@ void od_prefilter_split(od_coeff *c0, int stride, int bs, int f, int hfilter, in
      pvq_synthesis(..)              records (gain, theta -> host sin / cos, pulses)
      od_coding_order_to_raster(..)  od_hipdec_coding_order_to_raster(): closes the block - DC,
                                     which bands were cleared (OD_PVQ_SKIP_ZERO)
-   Nothing else of the parse reads the reference VALUES, so the host's mdtmp planes are not
-   filled at all: they hold a sentinel, a band that still holds it after od_pvq_decode was
-   copied from the reference (OD_PVQ_SKIP_COPY, skipped blocks) and needs no record - the
-   device starts every block from the prediction's transform (od_init_skipped_coeffs).  The
-   33 MB of level planes down and the 12.5 MB of coefficients up per 1080p frame become
-   4 MB of gains down and the records up.  Check mode keeps the reference's host path with
-   real planes beside it and compares the gains and the finished coefficient planes. */
+   Nothing else of the parse reads the reference VALUES, so the host never sees them: three
+   more bindings take the per-coefficient work the device now does out of the block decoder -
+     od_decode_compute_pred         (static; decode_tail.c) no copy of the prediction's transform
+     od_init_skipped_coeffs         no host coefficient plane is written
+     od_raster_to_coding_order      the reference vector handed to od_pvq_decode is a SENTINEL
+   - a band that holds the sentinel after od_pvq_decode was copied from the reference
+   (OD_PVQ_SKIP_COPY, skipped blocks) and needs no record: the device starts every block from
+   the prediction's transform.  The 33 MB of level planes down and the 12.5 MB of coefficients
+   up per 1080p frame become 4 MB of gains down and the records up, and the decoder thread no
+   longer touches a coefficient plane.  Check mode keeps the reference's host path with real
+   planes beside the records and compares the gains and the finished coefficient planes. */
 #define DS_SENTINEL (1 << 28)
 
 static int ds_lvl(int pli, int bs) {
@@ -388,6 +390,33 @@ void pvq_synthesis(od_coeff *xcoeff, od_coeff *ypulse, od_coeff *ref, int n, dou
   pvq_synthesis_cpu(xcoeff, ypulse, ref, n, gr, noref, g, theta, qm, qm_inv);
 }
 
+/* the block being parsed is synthesised on the device and no host copy of its data is kept */
+static int ds_device_only(void) {
+  return D.ds_on && D.ds_cur >= 0 && !D.check;
+}
+
+/* decode_tail.c: od_decode_compute_pred asks before it copies the prediction's transform */
+int od_hipdec_pred_from_device(void) {
+  return ds_device_only();
+}
+
+void od_hipdec_init_skipped_coeffs(od_coeff *d, od_coeff *pred, int is_keyframe, int bo, int n,
+ int w) {
+  if (ds_device_only()) return;
+  od_init_skipped_coeffs(d, pred, is_keyframe, bo, n, w);
+}
+
+void od_hipdec_raster_to_coding_order(od_coeff *dst, int n, const od_coeff *src, int stride) {
+  if (ds_device_only()) {
+    int i;
+    int len;
+    len = n*n < 512 ? n*n : 512;        /* the coded positions (OD_BAND_OFFSETS, src/partition.c:77-83) */
+    for (i = 0; i < len; i++) dst[i] = DS_SENTINEL;
+    return;
+  }
+  od_raster_to_coding_order(dst, n, src, stride);
+}
+
 void od_hipdec_coding_order_to_raster(od_coeff *dst, int stride, const od_coeff *src, int n) {
   if (D.ds_on && D.ds_cur >= 0 && D.dec != NULL) {
     od_hip_dsynth_block *b;
@@ -396,7 +425,7 @@ void od_hipdec_coding_order_to_raster(od_coeff *dst, int stride, const od_coeff 
     st = &D.dec->state;
     b = D.ds_blocks + D.ds_cur;
     if (dst == st->dtmp[b->pli] + b->org && n == 4 << b->bs) {
-      b->dc = src[0] - st->mdtmp[b->pli][b->org];
+      b->dc = src[0] - (D.check ? st->mdtmp[b->pli][b->org] : DS_SENTINEL);
       for (i = 0; i < DS_NB[b->bs]; i++) {
         int j;
         int len;
@@ -448,15 +477,6 @@ static int ds_frame_begin(od_state *state) {
     memcpy((char *)D.ds_qm_seen + qn, state->qm_inv, qn);
   }
   if (od_hip_dsynth_ref_gains(D.ds, D.ds_gr) != 0) return -3;
-  if (!D.check && !D.ds_md_sentinel) {
-    for (pli = 0; pli < 3; pli++) {
-      size_t i;
-      size_t np;
-      np = (size_t)(state->frame_width >> (pli > 0))*(state->frame_height >> (pli > 0));
-      for (i = 0; i < np; i++) state->mdtmp[pli][i] = DS_SENTINEL;
-    }
-    D.ds_md_sentinel = 1;
-  }
   D.ds_nblocks = D.ds_nbands = D.ds_npulses = 0;
   D.ds_cur = -1;
   D.ds_overflow = 0;
@@ -485,7 +505,7 @@ static void md_fdct(int bs, od_coeff *y, int ystride, const od_coeff *x, int xst
         int i;
         if (D.ds_on) ds_begin_block(pli, bs, (long)off);
         if (D.ds_on && !D.check) {
-          /* the prediction's transform stays on the device: mdtmp keeps its sentinel */
+          /* the prediction's transform stays on the device */
           D.md_hits++;
           return;
         }
@@ -506,7 +526,6 @@ static void md_fdct(int bs, od_coeff *y, int ystride, const od_coeff *x, int xst
       }
     }
   }
-  D.ds_md_sentinel = 0;
   if (D.ds_on) {
     /* a block of a frame recorded for the device took the host transform: the records no
        longer cover the frame */
@@ -628,6 +647,7 @@ static int injected_failure(void);
 
 /* Which device stage failed and with what code (the frame itself is reported through
    daala_decode_packet_in's OD_EFAULT): one line on stderr when HIPDEC_DEBUG is set. */
+static __thread double tm_mc, tm_pyr, tm_tail, tm_mark, tm_parse;   /* HIPDEC_DEBUG=2: where a frame's time goes */
 static void stage_failed(const char *stage, int rc) {
   if (getenv("HIPDEC_DEBUG") != NULL) {
     fprintf(stderr, "daala_hipdec: %s failed (step %d): %s\n", stage, rc, od_hip_last_error());
@@ -759,7 +779,12 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
   }
   if (pli == 0) {
     int rc;
+    double t_a;
+    t_a = now_s();
+    if (tm_mark > 0) tm_parse += t_a - tm_mark;
+    tm_mark = 0;
     rc = D.idct_skipped == 0 ? -100 : device_frame(state);
+    tm_tail += now_s() - t_a;
     if (rc != 0) {
       stage_failed("pixel-domain stage", rc);
       /* The device pass for a frame whose inverse transforms were skipped has failed (or,
@@ -798,7 +823,18 @@ int daala_decode_packet_in(daala_dec_ctx *dec, const daala_packet *op) {
   D.idct_skipped = 0;
   D.haar_skipped = 0;
   D.ds_on = 0;
-  rc = daala_decode_packet_in_cpu(dec, op);
+  {
+    static int dbg = -1;
+    double t_a;
+    if (dbg < 0) dbg = getenv("HIPDEC_DEBUG") != NULL ? atoi(getenv("HIPDEC_DEBUG")) : 0;
+    tm_mc = tm_pyr = tm_tail = tm_parse = tm_mark = 0;
+    t_a = now_s();
+    rc = daala_decode_packet_in_cpu(dec, op);
+    if (dbg >= 2) {
+      fprintf(stderr, "daala_hipdec: packet %.2f ms: prediction %.2f, pyramid+gains %.2f, parse %.2f, synthesis+tail %.2f\n",
+       1e3*(now_s() - t_a), 1e3*tm_mc, 1e3*tm_pyr, 1e3*tm_parse, 1e3*tm_tail);
+    }
+  }
   D.dec = NULL;
   D.md_valid = 0;
   D.ds_on = 0;
@@ -1213,12 +1249,18 @@ void od_hipdec_thread_cleanup(void) {
 
 void od_state_mc_predict(od_state *state, od_img *img_dst) {
   if ((D.ctx != NULL || od_hipenc_device_thread()) && !D.failed) {
+    double t_a;
+    t_a = now_s();
     if (!injected_failure() && mc_predict_device(state, img_dst) == 0) {
+      tm_mc += now_s() - t_a;
       mc_dev_frames++;
       if (D.ctx != NULL && D.dec != NULL && state == &D.dec->state
        && state->info.nplanes == 3 && state->frame_type == OD_P_FRAME) {
         int rc;
+        t_a = now_s();
         rc = md_pyramid(state, img_dst);
+        tm_pyr += now_s() - t_a;
+        tm_mark = now_s();
         D.md_valid = rc == 0;
         if (!D.md_valid) {
           D.failed = 1;      /* surfaced by daala_decode_packet_in, no silent host path */
