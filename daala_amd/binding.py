@@ -791,3 +791,79 @@ class PFeed:
         if self.h:
             self.lib.od_hip_pfeed_destroy(self.h)
             self.h = None
+
+
+class DSynthBlock(ctypes.Structure):
+    """od_hip_dsynth_block (include/daala_hip.h section 4e)."""
+    _fields_ = [('org', ctypes.c_int32), ('dc', ctypes.c_int32), ('pli', ctypes.c_uint8),
+                ('bs', ctypes.c_uint8), ('pad', ctypes.c_uint8*2)]
+
+
+class DSynthBand(ctypes.Structure):
+    """od_hip_dsynth_band."""
+    _fields_ = [('block', ctypes.c_uint32), ('band', ctypes.c_uint8), ('mode', ctypes.c_uint8),
+                ('pad', ctypes.c_uint8*2), ('yoff', ctypes.c_uint32), ('pad2', ctypes.c_uint32),
+                ('g', ctypes.c_double), ('sin_theta', ctypes.c_double), ('cos_theta', ctypes.c_double)]
+
+
+DSYNTH_ZERO, DSYNTH_NOREF, DSYNTH_REF, DSYNTH_WIDE = 0, 1, 2, 4
+
+
+class DSynth:
+    """od_hip_dsynth_*: decoder-side PVQ synthesis of an inter frame into the coefficient planes
+    of slot 0 of `ctx` (a DaalaHip whose slot 0 holds the forward pyramid of the prediction)."""
+
+    def __init__(self, ctx):
+        self.lib, self.ctx = ctx.lib, ctx
+        L = self.lib
+        L.od_hip_dsynth_create.restype = ctypes.c_void_p
+        L.od_hip_dsynth_create.argtypes = [ctypes.c_void_p]
+        L.od_hip_dsynth_destroy.argtypes = [ctypes.c_void_p]
+        L.od_hip_dsynth_set_level.argtypes = [ctypes.c_void_p, c_int, c_int, I16P, I16P]
+        L.od_hip_dsynth_ref_gains.argtypes = [ctypes.c_void_p, ctypes.POINTER(F64P*4)]
+        L.od_hip_dsynth_buffers.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(DSynthBlock)),
+                                            ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.POINTER(DSynthBand)),
+                                            ctypes.POINTER(ctypes.c_long), ctypes.POINTER(I16P),
+                                            ctypes.POINTER(ctypes.c_long)]
+        L.od_hip_dsynth_run.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long]
+        self.h = L.od_hip_dsynth_create(ctx.ctx)
+        if not self.h:
+            raise HipError(L.od_hip_last_error().decode())
+        b, nb = ctypes.POINTER(DSynthBlock)(), ctypes.c_long()
+        r, nr = ctypes.POINTER(DSynthBand)(), ctypes.c_long()
+        y, ny = I16P(), ctypes.c_long()
+        _chk(L.od_hip_dsynth_buffers(self.h, ctypes.byref(b), ctypes.byref(nb), ctypes.byref(r), ctypes.byref(nr),
+                                     ctypes.byref(y), ctypes.byref(ny)))
+        self.blocks, self.max_blocks = b, nb.value
+        self.bands, self.max_bands = r, nr.value
+        self.pulses, self.max_pulses = y, ny.value
+
+    def close(self):
+        if self.h:
+            self.lib.od_hip_dsynth_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_level(self, pli, level, qm, qm_inv):
+        qm = np.ascontiguousarray(qm, np.int16)
+        qm_inv = np.ascontiguousarray(qm_inv, np.int16)
+        _chk(self.lib.od_hip_dsynth_set_level(self.h, pli, level, qm.ctypes.data_as(I16P),
+                                              qm_inv.ctypes.data_as(I16P)))
+
+    def ref_gains(self):
+        """{(pli, level): gr [nbands, nblk]} of the pyramid in slot 0."""
+        arr = ((F64P*4)*3)()
+        _chk(self.lib.od_hip_dsynth_ref_gains(self.h, arr))
+        out = {}
+        for pli in range(3):
+            for level in range(self.ctx.nlevels(pli)):
+                n = (32 >> self.ctx.xdec[pli]) >> level
+                nb = {4: 1, 8: 4, 16: 7, 32: 9}[n]
+                nblk = self.ctx.pvq_nblocks(pli, level)
+                out[pli, level] = np.ctypeslib.as_array(arr[pli][level], shape=(nb, nblk)).copy()
+        return out
+
+    def run(self, nblocks, nbands, npulses):
+        _chk(self.lib.od_hip_dsynth_run(self.h, nblocks, nbands, npulses))

@@ -31,7 +31,7 @@ struct DsBand {              // == od_hip_dsynth_band
   uint32_t pad2;
   double g, sin_theta, cos_theta;
 };
-enum { DS_ZERO = 0, DS_NOREF = 1, DS_REF = 2 };
+enum { DS_ZERO = 0, DS_NOREF = 1, DS_REF = 2, DS_WIDE = 4 };   // WIDE: a pulse is two 16-bit entries (low, high)
 
 struct DsPlanes {
   const int32_t *lev[3][4];  // prediction pyramid level planes (slot 0)
@@ -71,21 +71,25 @@ __global__ __launch_bounds__(64) void k_dsynth_bands(DsPlanes P, const DsBlock *
   const int32_t *md = P.lev[q.pli][lvl] + q.org;
   int32_t *d = P.d[q.pli] + q.org;
   auto pos = [&](int i) { const int rt = tab[i]; return (size_t)(rt >> lg)*w + (rt & (bn - 1)); };
-  if (B.mode == DS_ZERO) {
+  if ((B.mode & 3) == DS_ZERO) {
     for (int i = 0; i < n; i++) d[pos(i)] = 0;
     return;
   }
-  const int16_t *yp = pulses + B.yoff;
+  const int16_t *yq = pulses + B.yoff;
   const int16_t *qm = P.qm[q.pli][lvl] + o0, *qm_inv = P.qm_inv[q.pli][lvl] + o0;
   const double g = B.g;
-  const int noref = B.mode == DS_NOREF;
+  const int noref = (B.mode & 3) == DS_NOREF;
+  const bool wide = B.mode & DS_WIDE;
+  auto ypv = [&](int i) -> int32_t {
+    return wide ? (int32_t)((uint32_t)(uint16_t)yq[2*i] | ((uint32_t)(uint16_t)yq[2*i + 1] << 16)) : (int32_t)yq[i];
+  };
   const int nn = n - !noref;
   int yy = 0;
-  for (int i = 0; i < nn; i++) yy += yp[i]*(int32_t)yp[i];
+  for (int i = 0; i < nn; i++) yy += ypv(i)*ypv(i);
   double scale = yy == 0 ? 0 : g/sqrt((double)yy);
   if (noref) {
     for (int i = 0; i < n; i++) {
-      d[pos(i)] = (int32_t)floor(.5 + (yp[i]*scale)*(qm_inv[i]*PVQ_QM_INV_SCALE_1));
+      d[pos(i)] = (int32_t)floor(.5 + (ypv(i)*scale)*(qm_inv[i]*PVQ_QM_INV_SCALE_1));
     }
     return;
   }
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(64) void k_dsynth_bands(DsPlanes P, const DsBlock *
   const int s = rref(m) > 0 ? 1 : -1;
   auto rv = [&](int i) { double r = rref(i); if (i == m) r += gr*s; return r; };
   scale *= B.sin_theta;
-  auto xv = [&](int i) { return i < m ? yp[i]*scale : i == m ? -s*g*B.cos_theta : yp[i - 1]*scale; };
+  auto xv = [&](int i) { return i < m ? ypv(i)*scale : i == m ? -s*g*B.cos_theta : ypv(i - 1)*scale; };
   // od_apply_householder
   double l2r = 0, proj = 0;
   for (int i = 0; i < n; i++) { const double r = rv(i); l2r += r*r; }
@@ -159,7 +163,7 @@ od_hip_dsynth *od_hip_dsynth_create(od_hip_ctx *ctx) {
   for (int p = 0; p < 3; p++) samples += (long)ctx->psz[p];
   s->cap_blocks = samples/16;
   s->cap_bands = samples/16;
-  s->cap_pulses = samples;
+  s->cap_pulses = 2*samples;                     // a band whose pulses do not fit 16 bits takes two entries per pulse
   bool ok = hipHostMalloc((void **)&s->h_blocks, s->cap_blocks*sizeof(DsBlock)) == hipSuccess;
   ok = ok && hipHostMalloc((void **)&s->h_bands, s->cap_bands*sizeof(DsBand)) == hipSuccess;
   ok = ok && hipHostMalloc((void **)&s->h_pulses, s->cap_pulses*sizeof(int16_t)) == hipSuccess;
@@ -253,11 +257,13 @@ int od_hip_dsynth_run(od_hip_dsynth *s, long nblocks, long nbands, long npulses)
   static const int off_all[] = {1, 16, 24, 32, 64, 96, 128, 256, 384, 512};
   for (long v = 0; v < nbands; v++) {
     const DsBand &B = s->h_bands[v];
-    if (B.block >= (uint32_t)nblocks || B.mode > DS_REF) return fail(OD_HIP_EINVAL, "bad synthesis band");
+    if (B.block >= (uint32_t)nblocks || (B.mode & 3) > DS_REF || (B.mode & ~7) || ((B.mode & DS_WIDE) && (B.mode & 3) == DS_ZERO))
+      return fail(OD_HIP_EINVAL, "bad synthesis band");
     const DsBlock &q = s->h_blocks[B.block];
     if (B.band >= nb_of[q.bs]) return fail(OD_HIP_EINVAL, "band index beyond the block size");
     const int n = off_all[B.band + 1] - off_all[B.band];
-    if (B.mode != DS_ZERO && (long)B.yoff + n - (B.mode == DS_REF) > npulses) return fail(OD_HIP_EINVAL, "pulses beyond the buffer");
+    if ((B.mode & 3) != DS_ZERO && (long)B.yoff + (long)(n - ((B.mode & 3) == DS_REF))*((B.mode & DS_WIDE) ? 2 : 1) > npulses)
+      return fail(OD_HIP_EINVAL, "pulses beyond the buffer");
   }
   if (nblocks == 0) return 0;
   HIPCHK(hipMemcpyAsync(s->d_blocks, s->h_blocks, nblocks*sizeof(DsBlock), hipMemcpyHostToDevice, ctx->stream));

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #define PVQ_MAXN 128                       /* OD_MAX_PVQ_SIZE, src/pvq.h:55 */
+#define PVQ_K_MAX16 32767                 /* largest K whose pulses fit the 16-bit records */
 #define PVQ_QM_SCALE_1 (1./32767)          /* OD_QM_SCALE_1, src/pvq.h:57-59 */
 #define PVQ_QM_INV_SCALE_1 (1./4096)       /* OD_QM_INV_SCALE_1 */
 #define PVQ_COMPAND_SCALE 4096.            /* OD_COMPAND_SCALE, src/pvq.h:68 */
@@ -816,9 +817,12 @@ __global__ __launch_bounds__(64, PVQ_V4_WAVES(N)) void k_pvq_cand(PvqLevelArgs3 
   if (i0 < 1) i0 = 1;
   const int i1 = (int)ceil(cg);
   const int gi = i0 + c;
-  const bool has = live && gi <= i1;
   const double qcg = gi;
-  const int k = has ? pvq_k_noref(qcg, N, beta) : 0;
+  // pulses travel as int16: a candidate whose K does not fit (quantizer 1-2 on noise-like
+  // content) is left to the host - its qg stays 0, which the consumer reads as "not fed"
+  const int kraw = live && gi <= i1 ? pvq_k_noref(qcg, N, beta) : 0;
+  const bool has = live && gi <= i1 && kraw <= PVQ_K_MAX16;
+  const int k = has ? kraw : 0;
   int y[NL];
   int npg = 0, npr = 0;
   PVQ_STAMP(2);                                    // norms + companded gain

@@ -176,9 +176,9 @@ __global__ __launch_bounds__(64, PVQ_V4_WAVES(N)) void k_pvq_pcand(PfeedArgs pa)
     if (i0 < 1) i0 = 1;
     const int gi = i0 + (c - PFEED_NREF);
     if (gi <= ceil(cg)) {
-      has = true;
       const double qcg = gi;
       k = pvq_k_noref(qcg, N, beta);
+      has = k <= PVQ_K_MAX16;                      // 16-bit pulses: larger K stays on the host (slot unused)
       g2 = qcg*cg;
     }
   }

@@ -252,9 +252,16 @@ def md_stats():
 def synth_stats():
     """(P frames of the last decode whose PVQ synthesis ran on the device - the host parsed
     symbols only -, check-mode mismatches of reference gains / coefficient planes)."""
-    out = (ctypes.c_long*2)()
+    out = (ctypes.c_long*3)()
     hipenc().od_hipdec_synth_stats(out)
     return int(out[0]), int(out[1])
+
+
+def synth_wide_bands():
+    """Bands of the last decode whose pulses did not fit 16 bits (two entries per pulse)."""
+    out = (ctypes.c_long*3)()
+    hipenc().od_hipdec_synth_stats(out)
+    return int(out[2])
 
 
 def tail_frames():

@@ -121,8 +121,10 @@ static long g_md_check_fail;
 static __thread long mc_check_fail;
 static __thread long ds_frames;          /* P frames whose PVQ synthesis ran on the device */
 static __thread long ds_check_fail;
+static __thread long ds_wide_bands;      /* bands whose pulses needed more than 16 bits */
 static long g_ds_frames;
 static long g_ds_check_fail;
+static long g_ds_wide_bands;
 static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
 static long g_mc_check_fail;
 
@@ -136,10 +138,12 @@ long od_hipdec_tail_frames(void) {
 }
 
 /* After od_hipdec_decode_frames: out[0] = P frames whose PVQ synthesis ran on the device,
-   out[1] = check-mode mismatches (reference gains, coefficient planes). */
-void od_hipdec_synth_stats(long out[2]) {
+   out[1] = check-mode mismatches (reference gains, coefficient planes), out[2] = bands whose
+   pulses went up as two 16-bit entries each. */
+void od_hipdec_synth_stats(long out[3]) {
   out[0] = g_ds_frames;
   out[1] = g_ds_check_fail;
+  out[2] = g_ds_wide_bands;
 }
 
 void od_hipdec_mc_stats(long out[2]) {
@@ -363,15 +367,18 @@ void pvq_synthesis(od_coeff *xcoeff, od_coeff *ypulse, od_coeff *ref, int n, dou
     int nn;
     band = ds_band_of(qm);
     nn = n - !noref;
+    int wide;
+    int i;
+    wide = 0;
+    for (i = 0; i < nn; i++) wide |= ypulse[i] > 32767 || ypulse[i] < -32768;
     if (band >= 0 && DS_OFF[band + 1] - DS_OFF[band] == n && D.ds_nbands < D.ds_max_bands
-     && D.ds_npulses + nn <= D.ds_max_pulses) {
+     && D.ds_npulses + (nn << wide) <= D.ds_max_pulses) {
       od_hip_dsynth_band *r;
       int16_t *y;
-      int i;
       r = D.ds_bands + D.ds_nbands++;
       r->block = (uint32_t)D.ds_cur;
       r->band = (uint8_t)band;
-      r->mode = noref ? OD_HIP_DSYNTH_NOREF : OD_HIP_DSYNTH_REF;
+      r->mode = (noref ? OD_HIP_DSYNTH_NOREF : OD_HIP_DSYNTH_REF) | (wide ? OD_HIP_DSYNTH_WIDE : 0);
       r->pad[0] = r->pad[1] = 0;
       r->yoff = (uint32_t)D.ds_npulses;
       r->pad2 = 0;
@@ -380,8 +387,16 @@ void pvq_synthesis(od_coeff *xcoeff, od_coeff *ypulse, od_coeff *ref, int n, dou
       r->sin_theta = noref ? 0 : sin(theta);
       r->cos_theta = noref ? 0 : cos(theta);
       y = D.ds_pulses + D.ds_npulses;
-      for (i = 0; i < nn; i++) y[i] = (int16_t)ypulse[i];
-      D.ds_npulses += nn;
+      if (!wide) for (i = 0; i < nn; i++) y[i] = (int16_t)ypulse[i];
+      else {
+        /* quantizer 1-2 on noise-like content: K beyond 16 bits - two entries per pulse */
+        for (i = 0; i < nn; i++) {
+          y[2*i] = (int16_t)(uint16_t)((uint32_t)ypulse[i] & 0xffff);
+          y[2*i + 1] = (int16_t)(uint16_t)((uint32_t)ypulse[i] >> 16);
+        }
+      }
+      D.ds_npulses += nn << wide;
+      ds_wide_bands += wide;
       D.ds_cur_mask |= 1u << band;
     }
     else D.ds_overflow = 1;
@@ -1044,6 +1059,7 @@ static void *dworker(void *arg) {
   g_md_hits += D.md_hits;
   g_ds_frames += ds_frames;
   g_ds_check_fail += ds_check_fail;
+  g_ds_wide_bands += ds_wide_bands;
   g_md_check_fail += D.md_check_fail;
   g_mc_check_fail += mc_check_fail;
   mc_dev_frames = mc_check_fail = 0;
@@ -1322,7 +1338,7 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   g_mc_dev_frames = g_mc_check_fail = 0;
   g_tail_dev_frames = 0;
   g_md_hits = g_md_check_fail = 0;
-  g_ds_frames = g_ds_check_fail = 0;
+  g_ds_frames = g_ds_check_fail = g_ds_wide_bands = 0;
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;

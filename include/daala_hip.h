@@ -407,6 +407,7 @@ typedef struct od_hip_dsynth_block {
 #define OD_HIP_DSYNTH_ZERO 0     /* OD_PVQ_SKIP_ZERO: the band is cleared */
 #define OD_HIP_DSYNTH_NOREF 1    /* synthesis without reference, n pulses */
 #define OD_HIP_DSYNTH_REF 2      /* synthesis with reference, n - 1 pulses */
+#define OD_HIP_DSYNTH_WIDE 4     /* or-ed in: a pulse does not fit 16 bits, every pulse is two entries (low, high half) */
 typedef struct od_hip_dsynth_band {
   uint32_t block;       /* index of the band's block in the block records */
   uint8_t band, mode, pad[2];

@@ -4,6 +4,7 @@ here as a prebuilt binary) takes every keyframe-luma no-reference PVQ search fro
 device feed and must produce the packets of the pure-C reference, byte for byte."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -273,6 +274,34 @@ def test_inter_decode_1080p_synthesis_on_the_device(monkeypatch):
     assert nd2 == nf and np.array_equal(got2, want) and H.synth_stats() == (0, 0)
     print('1080p I P P decode: reference %.3f s, device with synthesis %.3f s, synthesis on the host %.3f s'
           % (s0, s1, s2))
+
+
+def test_inter_quantizer_1_single_frequency_patterns():
+    """Quantizer 1 on full-swing single-frequency patterns (flat, checkerboard, vertical and
+    horizontal stripes in turn - nothing a motion vector can predict): all of a block's energy
+    sits in one coefficient and K runs into the tens of thousands: the encoder-side feeds leave
+    candidates whose K does not fit their 16-bit pulse records to the host, the decoder's synthesis
+    records switch to two entries per pulse when one does not fit (that path itself:
+    tests/test_gpu_parity.py::test_decoder_synthesis_frame_vs_oracle).  Packets identical to the
+    pure reference encoder's, pictures to its decoder's."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import configs_round as C
+    w, h, nf = 96, 64, 4
+    yy, xx = np.mgrid[0:h, 0:w]
+    pats = [np.full((h, w), 128), 255*((xx + yy) & 1), 255*(xx & 1), 255*(yy & 1)]
+    frames = [[p.astype(np.uint8), p[:h//2, :w//2].astype(np.uint8), p[:h//2, :w//2].astype(np.uint8)] for p in pats]
+    buf = H.pack_frames(frames, w, h)
+    want, _ = C.reference(w, h, buf, nf, 1, 0, 30, 7)
+    prm = H.Params(w, h, 1, 7, 0, 1, 1, 0, 30)
+    n, got, st = H.encode(prm, buf, nf, use_device=1)
+    assert n > 0 and got == want and st.check_fail == 0 and st.pvq_check_fail == 0
+    hdr = H.headers(prm)
+    n0, p0, _, _ = H.decode(prm, hdr, want)
+    for check in (1, 0):
+        prm.check = check
+        nd, p1, _, _ = H.decode(prm, hdr, want, use_device=1)
+        assert nd == nf and np.array_equal(p0, p1)
+        assert H.synth_stats() == (3, 0)
 
 
 def test_stream_ordering_regression_many_workers_repeated():

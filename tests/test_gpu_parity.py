@@ -797,3 +797,131 @@ def test_pframe_feed_complete_candidate_lists_vs_oracle(hip):
                     checked += 1
     pf.close()
     assert checked > 2000 and nsearch > 3000 and nnoref > 500, (checked, nsearch, nnoref)
+
+
+def test_decoder_synthesis_frame_vs_oracle(hip):
+    """od_hip_dsynth_* (header section 4e; pvq_synthesis src/pvq_decoder.c:104-118, od_init_skipped_coeffs
+    src/state.c:1351-1357, od_coding_order_to_raster src/partition.c:176, od_pvq_compute_gain
+    src/pvq.c:456-464): a whole frame of random block sizes, DC values and band decisions (copied
+    from the reference, cleared, synthesised with and without reference; pulses within and beyond
+    16 bits) against the oracle's band-by-band restatement on the same prediction pyramid."""
+    import daala_amd.binding as b
+    o = oracle()
+    o.orc_pvq_synthesis.argtypes = [ctypes.POINTER(ctypes.c_int32)]*3 + [
+        c_int, ctypes.c_double, c_int, ctypes.c_double, ctypes.c_double,
+        ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16)]
+    o.orc_pvq_compute_gain.restype = ctypes.c_double
+    o.orc_pvq_compute_gain.argtypes = [ctypes.POINTER(ctypes.c_int32), c_int, c_int,
+                                       ctypes.POINTER(ctypes.c_double), ctypes.c_double,
+                                       ctypes.POINTER(ctypes.c_int16)]
+    rng = np.random.default_rng(123)
+    W, Hh = 128, 96
+    ctx = b.DaalaHip(W, Hh, W, Hh, nplanes=3, xdec=(0, 1, 1), nslots=1)
+    planes = [rng.integers(0, 256, size=(Hh, W), dtype=np.uint8),
+              rng.integers(0, 256, size=(Hh//2, W//2), dtype=np.uint8),
+              rng.integers(0, 256, size=(Hh//2, W//2), dtype=np.uint8)]
+    ctx.upload_planes(0, planes)
+    ctx.forward_pyramid(0, 1)
+    ds = b.DSynth(ctx)
+    OFF = [1, 16, 24, 32, 64, 96, 128, 256, 384, 512]
+    NB = [1, 4, 7, 9]
+    qm, qmi, md = {}, {}, {}
+    for pli in range(3):
+        for level in range(ctx.nlevels(pli)):
+            n = (32 >> ctx.xdec[pli]) >> level
+            q = rng.integers(9000, 32768, size=n*n).astype(np.int16)
+            qm[pli, level] = q
+            qmi[pli, level] = np.floor(.5 + 32768.*4096./q.astype(np.float64)).astype(np.int16)
+            ds.set_level(pli, level, qm[pli, level], qmi[pli, level])
+            md[pli, level] = ctx.download_level(0, pli, level)
+    # reference gains of every band of every block size
+    gr = ds.ref_gains()
+    for (pli, level), g in gr.items():
+        n = (32 >> ctx.xdec[pli]) >> level
+        bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+        w = W >> ctx.xdec[pli]
+        for blk in rng.integers(0, g.shape[1], size=12):
+            by, bx = divmod(int(blk), w//n)
+            cod = np.zeros(n*n, np.int32)
+            o.orc_raster_to_coding_order(p32(cod), n, p32(np.ascontiguousarray(md[pli, level][by*n:(by + 1)*n, bx*n:(bx + 1)*n])), n)
+            for band in range(NB[bs]):
+                gg = ctypes.c_double()
+                ref = np.ascontiguousarray(cod[OFF[band]:OFF[band + 1]])
+                o.orc_pvq_compute_gain(p32(ref), ref.size, 1, ctypes.byref(gg), 1.0, p16(qm[pli, level][OFF[band]:]))
+                assert gg.value == g[band, blk], (pli, level, band, blk)
+    # a frame of records
+    want = []
+    nblocks = nbands = npulses = 0
+    for pli in range(3):
+        w, h = W >> ctx.xdec[pli], Hh >> ctx.xdec[pli]
+        sb = 32 >> ctx.xdec[pli]
+        exp = np.zeros((h, w), np.int32)
+        for sy in range(0, h, sb):
+            for sx in range(0, w, sb):
+                level = int(rng.integers(0, ctx.nlevels(pli)))
+                n = sb >> level
+                bs = {4: 0, 8: 1, 16: 2, 32: 3}[n]
+                for by in range(sy, sy + sb, n):
+                    for bx in range(sx, sx + sb, n):
+                        blk = ds.blocks[nblocks]
+                        blk.org, blk.pli, blk.bs = by*w + bx, pli, bs
+                        blk.dc = int(rng.integers(-5000, 5001))
+                        mdb = np.ascontiguousarray(md[pli, level][by:by + n, bx:bx + n])
+                        cod = np.zeros(n*n, np.int32)
+                        o.orc_raster_to_coding_order(p32(cod), n, p32(mdb), n)
+                        out = cod.copy()
+                        for band in range(NB[bs]):
+                            nn = OFF[band + 1] - OFF[band]
+                            mode = int(rng.choice([-1, b.DSYNTH_ZERO, b.DSYNTH_NOREF, b.DSYNTH_REF]))
+                            if mode < 0:
+                                continue                                  # copied from the reference: no record
+                            r = ds.bands[nbands]
+                            r.block, r.band, r.yoff = nblocks, band, npulses
+                            if mode == b.DSYNTH_ZERO:
+                                r.mode = mode
+                                out[OFF[band]:OFF[band + 1]] = 0
+                                nbands += 1
+                                continue
+                            noref = mode == b.DSYNTH_NOREF
+                            ny = nn - (not noref)
+                            wide = rng.random() < .15
+                            y = rng.integers(-3, 4, size=ny).astype(np.int32)
+                            if wide:
+                                y[int(rng.integers(0, ny))] = int(rng.choice([-1, 1]))*int(rng.integers(32768, 46000))   # y*y stays an int32
+                            g = float(rng.uniform(1, 60000))
+                            theta = float(rng.uniform(0, 1.5))
+                            r.mode = mode | (b.DSYNTH_WIDE if wide else 0)
+                            r.g, r.sin_theta, r.cos_theta = g, (0. if noref else np.sin(theta)), (0. if noref else np.cos(theta))
+                            for i in range(ny):
+                                if wide:
+                                    v = int(y[i]) & 0xffffffff
+                                    ds.pulses[npulses + 2*i] = ctypes.c_int16(v & 0xffff).value
+                                    ds.pulses[npulses + 2*i + 1] = ctypes.c_int16(v >> 16).value
+                                else:
+                                    ds.pulses[npulses + i] = int(y[i])
+                            npulses += ny*(2 if wide else 1)
+                            nbands += 1
+                            ref = np.ascontiguousarray(cod[OFF[band]:OFF[band + 1]])
+                            ypad = np.zeros(nn, np.int32)
+                            ypad[:ny] = y
+                            gg = ctypes.c_double()
+                            o.orc_pvq_compute_gain(p32(ref), nn, 1, ctypes.byref(gg), 1.0, p16(qm[pli, level][OFF[band]:]))
+                            e = np.zeros(nn, np.int32)
+                            o.orc_pvq_synthesis(p32(e), p32(ypad), p32(ref), nn, gg.value, int(noref), g, theta,
+                                                p16(qm[pli, level][OFF[band]:]), p16(qmi[pli, level][OFF[band]:]))
+                            out[OFF[band]:OFF[band + 1]] = e
+                        out[0] = cod[0] + blk.dc
+                        ras = mdb.copy()                 # od_init_skipped_coeffs: what coding order does not cover
+                        o.orc_coding_order_to_raster(p32(ras), n, p32(out), n)
+                        exp[by:by + n, bx:bx + n] = ras
+                        nblocks += 1
+        want.append(exp)
+    ds.run(nblocks, nbands, npulses)
+    for pli in range(3):
+        got = ctx.download_coeffs(0, pli)
+        assert np.array_equal(got, want[pli]), pli
+    # a record that points outside its plane is refused on the host, not launched
+    ds.blocks[0].org = (Hh*W) - 4
+    with pytest.raises(b.HipError):
+        ds.run(nblocks, nbands, npulses)
+    ds.close()
