@@ -157,7 +157,7 @@ struct PvqSoA {
   double *cos_dist, *dist;  // [2][nbands*nblk]
   int32_t *qg, *k;          // [2][nbands*nblk]
   int32_t *ncand;           // [nbands*nblk]
-  // pulses, int16 (|y| <= K <= 738): band b occupies y + 2*nblk*yo[b], laid out
+  // pulses, int16 (candidates with K > PVQ_K_MAX16 are left to the host): band b occupies y + 2*nblk*yo[b], laid out
   // [cand][block][ns[b]] with ns = the band size rounded up to even (one pad entry for the
   // 15-coefficient band: runs start 4-byte aligned) and yo = 0, off[1], off[2], ...
   int16_t *y;

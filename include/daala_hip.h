@@ -280,7 +280,8 @@ int od_hip_pvq_download(od_hip_ctx *ctx, int slot, int pli, int level,
  *      record r = band*nblk + block (blocks in raster order of the level)
  *      cg[r], ncand[r], qg[c*nrec + r], k[c*nrec + r], cos_dist[c*nrec + r]
  *                                                          c = candidate 0/1
- *      y of band b, 16-bit (|y| <= K <= 738):
+ *      y of band b, 16-bit.  A candidate whose K exceeds 32767 (quantizer 1-2 on noise-like
+ *      content) is not searched: its qg[] reads 0, the consumer must search it itself:
  *           y + 2*nblk*yo[b] + (c*nblk + block)*ns[b]
  *           ns[b] = the band's size rounded up to even (one pad entry after the 15 pulses of
  *           band 0), yo[0] = 0, yo[b] = off[b] for b >= 1
