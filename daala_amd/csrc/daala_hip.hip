@@ -476,6 +476,7 @@ struct od_hip_mc {
   } pl[3];
   McBlock *d_blocks = nullptr, *h_blocks = nullptr;
   size_t blocks_cap = 0;
+  hipEvent_t done = nullptr;        // od_hip_mc_predict_ctx: the prediction is in the context's plane
 };
 
 extern "C" {
@@ -492,6 +493,7 @@ void od_hip_mc_destroy(od_hip_mc *m) {
   }
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->h_blocks) (void)hipHostFree(m->h_blocks);
+  if (m->done) (void)hipEventDestroy(m->done);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
@@ -538,9 +540,15 @@ int od_hip_mc_set_ref(od_hip_mc *m, int pli, int k, const unsigned char *plane, 
   return 0;
 }
 
-int od_hip_mc_predict(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nblocks, unsigned char *dst,
-                      int dst_stride, int dst_w, int dst_h) {
-  if (!m || !blocks || !dst) return fail(OD_HIP_EFAULT, "null pointer");
+}  // extern "C"
+
+namespace {
+// One plane's prediction.  dev_dst == nullptr: into the object's own dense plane, then to the
+// caller's host plane (dst).  dev_dst != nullptr: straight into that dense device plane (a
+// context's picture plane), nothing comes to the host; the launch is left in flight on m->stream.
+int mc_predict_impl(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nblocks, unsigned char *dst,
+                    int dst_stride, int dst_w, int dst_h, uint8_t *dev_dst) {
+  if (!m || !blocks || (!dst && !dev_dst)) return fail(OD_HIP_EFAULT, "null pointer");
   if (pli < 0 || pli > 2 || nblocks < 0 || dst_stride < 1 || dst_w < 1 || dst_w > dst_stride || dst_h < 1)
     return fail(OD_HIP_EINVAL, "bad geometry");
   auto &P = m->pl[pli];
@@ -557,7 +565,7 @@ int od_hip_mc_predict(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int 
   if (nblocks == 0) return 0;
   HIPCHK(hipSetDevice(m->device));
   const size_t dbytes = (size_t)dst_w*dst_h;        // dense picture area on the device
-  if (P.dst_cap < dbytes) {
+  if (!dev_dst && P.dst_cap < dbytes) {
     HIPCHK(hipStreamSynchronize(m->stream));
     if (P.d_dst) (void)hipFree(P.d_dst);
     if (P.h_dst) (void)hipHostFree(P.h_dst);
@@ -590,14 +598,46 @@ int od_hip_mc_predict(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int 
   a.org_y = P.org_y;
   a.blocks = m->d_blocks;
   a.nblocks = nblocks;
-  a.dst = P.d_dst;
+  a.dst = dev_dst ? dev_dst : P.d_dst;
   a.dst_stride = dst_w;
   hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(MC_THREADS), 0, m->stream, a);
   HIPCHK(hipGetLastError());
+  if (dev_dst) return 0;
   HIPCHK(hipMemcpyAsync(P.h_dst, P.d_dst, dbytes, hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   // the blocks tile the picture area; only that area of the caller's plane is written
   for (int y = 0; y < dst_h; y++) memcpy(dst + (size_t)y*dst_stride, P.h_dst + (size_t)y*dst_w, dst_w);
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int od_hip_mc_predict(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nblocks, unsigned char *dst,
+                      int dst_stride, int dst_w, int dst_h) {
+  if (!dst) return fail(OD_HIP_EFAULT, "null pointer");
+  return mc_predict_impl(m, pli, blocks, nblocks, dst, dst_stride, dst_w, dst_h, nullptr);
+}
+
+// The same prediction written into picture plane `pli` of slot `slot` of a context on the same
+// device (the blocks must tile the context's frame_width >> xdec x frame_height >> ydec plane):
+// what a decoder needs when the prediction's only consumer is the forward pyramid of that
+// context - no copy to the host and back.  The context's stream waits for the prediction on the
+// device; the call itself does not block.
+static int check_plane(od_hip_ctx *ctx, int slot, int pli);
+int od_hip_mc_predict_ctx(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nblocks, od_hip_ctx *ctx,
+                          int slot) {
+  if (!m || !ctx) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (ctx->device != m->device) return fail(OD_HIP_EINVAL, "prediction object and context live on different devices");
+  long area = 0;
+  for (int b = 0; blocks && b < nblocks; b++) area += 1L << (blocks[b].log_xblk_sz + blocks[b].log_yblk_sz);
+  if (area != (long)ctx->pw[pli]*ctx->ph[pli]) return fail(OD_HIP_EINVAL, "the blocks do not tile the context's plane");
+  if (int rc = mc_predict_impl(m, pli, blocks, nblocks, nullptr, ctx->pw[pli], ctx->pw[pli], ctx->ph[pli],
+                               ctx->pix[pli] + (size_t)slot*ctx->psz[pli])) return rc;
+  if (!m->done) HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(m->done, m->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, m->done, 0));
   return 0;
 }
 

@@ -96,6 +96,7 @@ typedef struct dec_tls {
   int check;
   double t_device;
   /* P frames: PVQ synthesis on the device (below) */
+  int pred_on_device;       /* this P frame's prediction went straight into the context's picture planes */
   od_hip_dsynth *ds;
   int ds_off;               /* HIPDEC_SYNTH=0 */
   int ds_on;                /* this frame's blocks are recorded for the device */
@@ -183,6 +184,10 @@ static void haar_frame_seen(void) {
   if (D.md_valid && !D.check) {
     od_img *rec;
     rec = st->ref_imgs + st->ref_imgi[OD_FRAME_SELF];
+    /* the prediction itself may never have come to the host: the reference's own function
+       computes the same picture */
+    if (D.pred_on_device) od_state_mc_predict_cpu(st, rec);
+    D.pred_on_device = 0;
     for (pli = 0; pli < st->info.nplanes; pli++) {
       od_ref_plane_to_coeff_cpu(st, st->mctmp[pli], st->quantizer[pli] == 0, rec, pli);
     }
@@ -597,7 +602,7 @@ static int md_pyramid(od_state *state, od_img *pred) {
     planes[pli] = pred->planes[pli].data;
     strides[pli] = pred->planes[pli].ystride;
   }
-  if (od_hip_upload_planes(D.ctx, 0, planes, strides) != 0) return -2;
+  if (!D.pred_on_device && od_hip_upload_planes(D.ctx, 0, planes, strides) != 0) return -2;
   if (od_hip_forward_pyramid(D.ctx, 0, 1) != 0) return -3;
   if (D.ds != NULL && ds_frame_begin(state) != 0) return -5;
   if (!D.ds_on || D.check) {
@@ -1184,9 +1189,17 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
   int rc;
   int k;
   int dev;
+  int to_ctx;
   rc = 0;
   memset(&L, 0, sizeof(L));
   if (state->full_precision_references) return -1;
+  /* A decoder thread's prediction has one consumer, the forward pyramid of the thread's
+     context (md_pyramid): it is predicted straight into the context's picture planes and never
+     visits the host - unless somebody wants to look at it (check mode, user_mc_img). */
+  to_ctx = D.ctx != NULL && D.dec != NULL && state == &D.dec->state && !D.check
+   && D.dec->user_mc_img == NULL && img_dst->nplanes == 3 && state->frame_type == OD_P_FRAME
+   && state->quantizer[0] > 0;
+  D.pred_on_device = 0;
   if (D.mc == NULL) {
     dev = D.device;
     D.mc = od_hip_mc_create(dev, OD_FRAME_MAX + 1);
@@ -1243,11 +1256,15 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
     }
     /* a block may name any image the grid refers to: all of those were refreshed above */
     if (rc == 0) {
-      rc = od_hip_mc_predict(D.mc, pli, L.b, L.n, dp->data, dp->ystride, state->frame_width >> xdec,
-       state->frame_height >> ydec);
+      if (to_ctx) rc = od_hip_mc_predict_ctx(D.mc, pli, L.b, L.n, D.ctx, 0);
+      else {
+        rc = od_hip_mc_predict(D.mc, pli, L.b, L.n, dp->data, dp->ystride, state->frame_width >> xdec,
+         state->frame_height >> ydec);
+      }
     }
   }
   free(L.b);
+  if (rc == 0 && to_ctx) D.pred_on_device = 1;
   return rc;
 }
 

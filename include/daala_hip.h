@@ -555,6 +555,12 @@ int od_hip_mc_set_ref(od_hip_mc *mc, int pli, int k, const unsigned char *plane,
  int ref_h, int org_x, int org_y);
 int od_hip_mc_predict(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int nblocks,
  unsigned char *dst, int dst_stride, int dst_w, int dst_h);
+/* The same prediction written into picture plane pli of slot `slot` of a context on the same
+ * device (the blocks must tile the context's padded plane): for a decoder, whose only consumer
+ * of the prediction is od_hip_forward_pyramid of that context - nothing crosses PCIe.  The
+ * context's stream waits for the prediction on the device; the call does not block. */
+int od_hip_mc_predict_ctx(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int nblocks,
+ od_hip_ctx *ctx, int slot);
 
 /* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
  * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks
