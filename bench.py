@@ -80,16 +80,20 @@ def host_cpu_budget():
     return n
 
 
-def reference_packets(frames, nframes, masking=1):
+def reference_packets(frames, nframes, masking=1, after_frame=None):
     """The first `nframes` packets of the pure reference encoder (oracle/_ref/enc_probe.so,
     gcc -std=c89 -O2, one thread) and its speed: the CPU baseline of record and the
-    bit-exactness pin."""
+    bit-exactness pin.  after_frame(f, seconds_so_far): progress callback."""
     so = os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so')
     if not os.path.exists(so):
         return None
     import daala_amd.hipenc as H
     lib = ctypes.CDLL(so)
     lib.probe_encode_frames.restype = ctypes.c_long
+    cb = None
+    if after_frame is not None and hasattr(lib, 'probe_set_frame_callback'):
+        cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_double)(after_frame)
+        lib.probe_set_frame_callback(cb)
     buf = H.pack_frames(frames[:nframes], PIC_W, PIC_H)
     out = np.zeros(max(1 << 20, buf.size), np.uint8)
     fnv = ctypes.c_uint()
@@ -483,7 +487,41 @@ def strong_step_setup(H, b, local_rank, rank, world, nframes, rehearse, dist):
     return step, close, what, (w, h, buf)
 
 
+def ref_helper_main(path):
+    """Child process of the default N = 1 run (started before anything touches the GPU: a
+    process that has initialised it must not exec): the pure reference encoder over ALL 30
+    frames, in order, one thread - started on a line from the parent once the timed region is
+    over, so that it never competes with it.  The first 10 frames are the CPU baseline of record
+    (the parent idles until they are done and reads their seconds from this process's stdout);
+    the other 20 run at the lowest priority.  Writes all 30 packets to `path`."""
+    sys.path.insert(0, ROOT)
+    frames = make_frames(FRAMES, seed0=1)
+    sys.stdin.readline()                      # "go": the timed region is over
+    nref = 10
+
+    def after_frame(f, seconds):
+        if f == nref - 1:
+            # the CPU baseline of record: the first 10 frames, timed while the parent waits;
+            # the remaining 20 run at the lowest priority beside the parent's other sections
+            sys.stdout.write(json.dumps({'frames': nref, 'seconds': seconds}) + '\n')
+            sys.stdout.flush()
+            try:
+                os.nice(19)
+            except OSError:
+                pass
+
+    ref = reference_packets(frames, FRAMES, after_frame=after_frame)
+    with open(path + '.tmp', 'wb') as f:
+        if ref is not None:
+            for p in ref['packets']:
+                f.write(len(p).to_bytes(4, 'little') + p)
+    os.replace(path + '.tmp', path)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == '--_ref-helper':
+        ref_helper_main(sys.argv[2])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -499,6 +537,17 @@ def main():
     ap.add_argument('--device-only', action='store_true',
                     help='profiling aid: only the device-only section (INVALID as a bench result)')
     args = ap.parse_args()
+
+    helper = helper_path = None
+    if (int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline and not args.strong
+            and not args.device_only and os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so'))):
+        # every packet of the step is pinned to the PURE reference build: a child runs it over all
+        # 30 frames after the timed region (ref_helper_main); exec'd here, before the GPU is touched
+        import subprocess
+        import tempfile
+        helper_path = os.path.join(tempfile.gettempdir(), 'bench_ref_packets_%d.bin' % os.getpid())
+        helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--_ref-helper', helper_path],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE)
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
@@ -635,6 +684,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ses.close()                         # frees the HBM slots and the pinned mirrors
+    if helper is not None:
+        try:
+            helper.stdin.write(b'go\n')
+            helper.stdin.flush()
+        except OSError:
+            helper = None
 
     line = None
     if rank == 0:
@@ -665,23 +720,46 @@ def main():
     if world == 1 and rank == 0:
         if not args.no_cpu_baseline:
             nref = 10                # ~14 s of single-core work (the contract asks for 10-30 s)
-            ref = reference_packets(frames, nref)
-            if ref:
-                line['cpu_baseline'] = {'value': round(ref['Mpixels_per_s'], 4), 'unit': 'Mpixels/s',
+            ref = None
+            ref_seconds = None
+            if helper is not None:
+                # the child is encoding the first 10 frames right now; this process idles until
+                # they are done, so nothing of ours competes with the baseline being timed
+                import select
+                try:
+                    if select.select([helper.stdout], [], [], 180)[0]:
+                        msg = json.loads(helper.stdout.readline().decode())
+                        if msg.get('frames') == nref:
+                            ref_seconds = float(msg['seconds'])
+                except (OSError, ValueError):
+                    ref_seconds = None
+                if ref_seconds is None:
+                    try:
+                        helper.kill()
+                    except OSError:
+                        pass
+                    helper = None
+            if ref_seconds is None:
+                ref = reference_packets(frames, nref)
+                ref_seconds = ref['seconds'] if ref else None
+            if ref_seconds:
+                ref_mpx = nref*PIC_W*PIC_H/ref_seconds/1e6
+                line['cpu_baseline'] = {'value': round(ref_mpx, 4), 'unit': 'Mpixels/s',
                                         'cores': 1, 'kind': 'reference',
                                         'sample': 'first %d of the 30 1080p frames through the pure reference '
                                                   'encoder (oracle/_ref, gcc -std=c89 -O2, src/x86 off), whole '
-                                                  'bitstream, %.1f s' % (nref, ref['seconds'])}
-                line['x_single_thread_reference'] = round(value/ref['Mpixels_per_s'], 2)
+                                                  'bitstream, %.1f s' % (nref, ref_seconds)}
+                line['x_single_thread_reference'] = round(value/ref_mpx, 2)
             # Bit-exactness of EVERY packet: the same driver with the device off runs the
             # reference's own C search for all 30 frames (its first packets in turn equal the
             # pure -O2 reference build's).
             hp = H.Params(PIC_W, PIC_H, 20, 7, 1, nw, 0, 0)
             n0, pk0, st0 = H.encode(hp, buf, FRAMES)
             line['bit_exact'] = {
-                'all_%d_packets_equal_reference_code_without_device' % FRAMES: bool(n0 == nbytes and pk0 == packets),
-                'first_%d_packets_equal_pure_reference_build' % nref:
-                    bool(ref is not None and packets[:nref] == ref['packets'])}
+                'all_%d_packets_equal_reference_code_without_device' % FRAMES: bool(n0 == nbytes and pk0 == packets)}
+            if ref is not None:          # no child process: the in-process reference run of the first 10
+                line['bit_exact']['first_%d_packets_equal_pure_reference_build' % nref] = \
+                    bool(packets[:nref] == ref['packets'])
             line['host_only'] = {'Mpixels_per_s': round(FRAMES*PIC_W*PIC_H/st0.t_total_s/1e6, 3),
                                  'host_workers': nw,
                                  'what': 'the same driver and host build with the device off (plain C '
@@ -721,6 +799,31 @@ def main():
                                   'reference_decoder_1thread_Mpixels_per_s': round(4*PIC_W*PIC_H/sec1/1e6, 2),
                                   'what': 'daala_decode_packet_in of the 30 packets; symbol parse on host '
                                           'workers, pixel-domain stage = one od_hip_decode_tail per frame'}
+    if helper is not None and rank == 0 and line is not None:
+        # the child's 30 packets of the pure reference build (single thread, niced, started after
+        # the timed region; it has had the whole post-processing above to finish)
+        try:
+            helper.stdin.close()
+            helper.wait(timeout=120)
+            blob = open(helper_path, 'rb').read()
+            ref_all, o = [], 0
+            while o + 4 <= len(blob):
+                n = int.from_bytes(blob[o:o + 4], 'little')
+                ref_all.append(blob[o + 4:o + 4 + n])
+                o += 4 + n
+            line.setdefault('bit_exact', {})['all_%d_packets_equal_pure_reference_build' % FRAMES] = \
+                bool(len(ref_all) == FRAMES and ref_all == [bytes(p) for p in packets])
+        except Exception as e:
+            line.setdefault('bit_exact', {})['all_%d_packets_equal_pure_reference_build' % FRAMES] = 'not checked: %r' % (e,)
+            try:
+                helper.kill()
+            except OSError:
+                pass
+        finally:
+            try:
+                os.remove(helper_path)
+            except OSError:
+                pass
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

@@ -112,6 +112,13 @@ static daala_enc_ctx *make_encoder(int w, int h, int quant, int complexity,
    od_state_opt_vtbl after creation (entries 0..3) - the drop-in seam of
    src/state.c:347-353 / src/x86/x86state.c:39-96 exercised at run time, without
    touching the reference sources.  NULL keeps the pure-C tables. */
+/* Progress callback (bench.py's reference child): called after every frame with the frame
+   index and the encode seconds so far. */
+static void (*g_after_frame)(int f, double seconds);
+void probe_set_frame_callback(void (*cb)(int f, double seconds)) {
+  g_after_frame = cb;
+}
+
 long probe_encode_frames_vtbl(int w, int h, int nframes, int quant, int complexity,
  int masking, int keyrate, const unsigned char *frames, unsigned *fnv,
  double *seconds, unsigned char *pkt_out, long pkt_cap,
@@ -175,6 +182,7 @@ long probe_encode_frames_vtbl(int w, int h, int nframes, int quant, int complexi
       t0 = now_s();
     }
     t += now_s() - t0;
+    if (g_after_frame != NULL) (*g_after_frame)(f, t);
   }
   if (recon_out != NULL) {
     /* reconstruction of the last frame, visible area, Y U V dense */
