@@ -98,6 +98,12 @@ __device__ __forceinline__ void rt_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// RT_NT_STORES: the level planes are written once and read much later by other kernels (1 GB per
+// 30-frame luma launch, far beyond the L2): non-temporal stores.  Measured, alternating builds on
+// one box: luma pyramid 0.2956 / 0.2944 ms with plain stores, 0.2864 / 0.2855 ms with these (-3 %).
+#ifndef RT_NT_STORES
+#define RT_NT_STORES 1
+#endif
 // Store a rectangle of the coefficient tile: rows [row0, row0+NR), columns
 // [col0, col0+NC) (NC in {32, 64}), one int4 per lane.
 template <int SB, int NR, int NC>
@@ -117,7 +123,13 @@ __device__ __forceinline__ void rt_store_rect(int32_t *__restrict__ dst, int w, 
       const int r = row0 + it*RPI + rr;
       if (NR % RPI == 0 || it*RPI + rr < NR) {
         const int32_t *p = Z + r*T::LDZ + c4;
+#if RT_NT_STORES
+        typedef int rt_v4i __attribute__((ext_vector_type(4)));
+        rt_v4i nv = {p[0], p[1], p[2], p[3]};
+        __builtin_nontemporal_store(nv, reinterpret_cast<rt_v4i *>(q));
+#else
         *reinterpret_cast<int4 *>(q) = make_int4(p[0], p[1], p[2], p[3]);
+#endif
       }
       q += step;
     }
