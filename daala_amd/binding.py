@@ -541,6 +541,15 @@ class DaalaHip(object):
             _chk(lib.od_hip_enc_feed_set_level(self.feed, l, qm_l.ctypes.data_as(I16P), _p32(q_l),
                                                b_l.ctypes.data_as(F64P)))
 
+    def enc_feed_set_level_plane(self, pli, level, qm, q, beta):
+        """od_hip_enc_feed_set_level_plane: puts plane pli into the feed (all its levels must be set)."""
+        self.lib.od_hip_enc_feed_set_level_plane.argtypes = [ctypes.c_void_p, c_int, c_int, I16P, I32P, F64P]
+        qm_l = np.ascontiguousarray(qm, dtype=np.int16)
+        q_l = np.ascontiguousarray(q, dtype=np.int32)
+        b_l = np.ascontiguousarray(beta, dtype=np.float64)
+        _chk(self.lib.od_hip_enc_feed_set_level_plane(self.feed, pli, level, qm_l.ctypes.data_as(I16P), _p32(q_l),
+                                                      b_l.ctypes.data_as(F64P)))
+
     def enc_feed_phases(self, slot0=0, nslots=None):
         """od_hip_enc_feed_gains -> _compand per slot -> _search (what enc_feed_run does), as
         separate calls so that a strip set with set_strip() is honoured by every phase."""
@@ -568,12 +577,14 @@ class DaalaHip(object):
     def enc_feed_run(self, slot0=0, nslots=None):
         _chk(self.lib.od_hip_enc_feed_run(self.feed, slot0, nslots or self.nslots - slot0))
 
-    def enc_feed_view(self, slot):
-        """Host arrays (copies) of one slot: list of 4 dicts cg/ncand/qg/k/cos_dist/y."""
+    def enc_feed_view(self, slot, pli=0):
+        """Host arrays (copies) of one slot of plane pli: list of dicts cg/ncand/qg/k/cos_dist/y,
+        one per level of the plane."""
         lev = (FeedLevel*4)()
-        _chk(self.lib.od_hip_enc_feed_view(self.feed, slot, lev))
+        self.lib.od_hip_enc_feed_view_plane.argtypes = [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(FeedLevel)]
+        _chk(self.lib.od_hip_enc_feed_view_plane(self.feed, slot, pli, lev))
         out = []
-        for v in lev:
+        for v in list(lev)[:self.nlevels(pli)]:
             nrec = v.nbands*v.nblk
             ny = 2*v.nblk*min(v.n*v.n, 512)      # int16, bands padded to even (daala_hip.h 4b)
             out.append({'n': v.n, 'nbands': v.nbands, 'nblk': v.nblk, 'nbx': v.nbx,
@@ -585,7 +596,7 @@ class DaalaHip(object):
                         'k': np.ctypeslib.as_array(v.k, (2*nrec,)).copy(),
                         'cos_dist': np.ctypeslib.as_array(v.cos_dist, (2*nrec,)).copy(),
                         'y': np.ctypeslib.as_array(v.y, (ny,)).copy(),
-                        'lev': np.ctypeslib.as_array(v.lev, self.plane_shape(0)).copy()})
+                        'lev': np.ctypeslib.as_array(v.lev, self.plane_shape(pli)).copy()})
         return out
 
     def set_decode_info(self, slot, dering_flags, bskip):

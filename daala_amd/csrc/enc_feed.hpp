@@ -18,18 +18,41 @@ struct od_hip_enc_feed {
   od_coeff *haar[3] = {nullptr, nullptr, nullptr};   // lossless frames: pinned [slot][h][w] Haar planes (lazy)
   std::vector<char> lossless;             // slot holds Haar planes, not the PVQ feed
   std::vector<char> pending;              // slot has a copy in flight / landed
-  // Pinned host mirrors of the luma plane's per-slot arenas (PvqArena): ONE transfer per frame
-  // slot and direction - records + pulses down, gains down, companded gains + work lists up -
-  // and one for the four level planes of a slot (they are contiguous in the context).
-  char *h_out = nullptr, *h_g = nullptr, *h_in = nullptr;
-  od_coeff *h_planes = nullptr;           // [slot][level][h][w]
+  // Per plane in the feed (luma always; the chroma planes once od_hip_enc_feed_set_level_plane
+  // has named their levels): pinned host mirrors of the plane's per-slot arenas (PvqArena) - ONE
+  // transfer per frame slot and direction: records + pulses down, gains down, companded gains +
+  // work lists up - and one for the level planes of a slot (they are contiguous in the context).
   struct Lev {
     bool set = false;
     std::vector<int16_t> qm;
     int32_t q[11];
     double beta[11];
-  } lev[4];
+  };
+  struct Plane {
+    bool on = false;
+    char *h_out = nullptr, *h_g = nullptr, *h_in = nullptr;
+    od_coeff *h_planes = nullptr;         // [slot][level][h][w]
+    Lev lev[4];
+  } P[3];
 };
+
+namespace {
+// pinned mirrors of plane p (its arenas are allocated with it)
+int feed_plane_on(od_hip_enc_feed *f, int p) {
+  od_hip_ctx *ctx = f->ctx;
+  auto &Q = f->P[p];
+  if (Q.on) return 0;
+  if (int rc = pvq_arena(ctx, p)) return rc;
+  const PvqArena &A = ctx->arena[p];
+  const size_t ns = ctx->geo.nslots;
+  HIPCHK(hipHostMalloc((void **)&Q.h_out, ns*A.out_slot));
+  HIPCHK(hipHostMalloc((void **)&Q.h_g, ns*A.g_slot));
+  HIPCHK(hipHostMalloc((void **)&Q.h_in, ns*A.in_slot));
+  HIPCHK(hipHostMalloc((void **)&Q.h_planes, ns*ctx->nlev[p]*ctx->psz[p]*sizeof(od_coeff)));
+  Q.on = true;
+  return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -37,10 +60,12 @@ void od_hip_enc_feed_destroy(od_hip_enc_feed *f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   if (f->copy) (void)hipStreamSynchronize(f->copy);
-  if (f->h_out) (void)hipHostFree(f->h_out);
-  if (f->h_g) (void)hipHostFree(f->h_g);
-  if (f->h_in) (void)hipHostFree(f->h_in);
-  if (f->h_planes) (void)hipHostFree(f->h_planes);
+  for (auto &Q : f->P) {
+    if (Q.h_out) (void)hipHostFree(Q.h_out);
+    if (Q.h_g) (void)hipHostFree(Q.h_g);
+    if (Q.h_in) (void)hipHostFree(Q.h_in);
+    if (Q.h_planes) (void)hipHostFree(Q.h_planes);
+  }
   for (auto &h : f->haar) if (h) (void)hipHostFree(h);
   for (auto e : f->ready) if (e) (void)hipEventDestroy(e);
   for (auto e : f->gready) if (e) (void)hipEventDestroy(e);
@@ -76,14 +101,7 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
   f->pending.assign(ns, 0);
   for (size_t s = 0; ok && s < ns; s++)
     ok = hipEventCreateWithFlags(&f->ready[s], hipEventDisableTiming) == hipSuccess;
-  ok = ok && pvq_arena(ctx, 0) == 0;
-  if (ok) {
-    const PvqArena &A = ctx->arena[0];
-    ok = hipHostMalloc((void **)&f->h_out, ns*A.out_slot) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&f->h_g, ns*A.g_slot) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&f->h_in, ns*A.in_slot) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&f->h_planes, ns*ctx->nlev[0]*ctx->psz[0]*sizeof(od_coeff)) == hipSuccess;
-  }
+  ok = ok && feed_plane_on(f, 0) == 0;
   if (!ok) {
     fail(OD_HIP_ENODEV, "encoder feed allocation failed");
     od_hip_enc_feed_destroy(f);
@@ -92,16 +110,29 @@ od_hip_enc_feed *od_hip_enc_feed_create(od_hip_ctx *ctx) {
   return f;
 }
 
-int od_hip_enc_feed_set_level(od_hip_enc_feed *f, int level, const int16_t *qm,
-                              const int32_t *q, const double *beta) {
+// Level parameters of plane pli.  Naming a chroma plane's level puts that plane into the feed:
+// its forward transforms and its no-reference candidates - state-free on a keyframe like luma's
+// (src/pvq_encoder.c:449-455 runs the chroma search when the CfL reference correlates badly) -
+// then travel with luma's.  All levels of a plane in the feed must be set before a run.
+int od_hip_enc_feed_set_level_plane(od_hip_enc_feed *f, int pli, int level, const int16_t *qm,
+                                    const int32_t *q, const double *beta) {
   if (!f || !qm || !q || !beta) return fail(OD_HIP_EFAULT, "null pointer");
-  if (level < 0 || level > 3) return fail(OD_HIP_EINVAL, "level out of range");
-  auto &L = f->lev[level];
-  const PvqLevelLayout &Y = f->ctx->arena[0].lev[level];
+  od_hip_ctx *ctx = f->ctx;
+  if (pli < 0 || pli >= ctx->geo.nplanes || pli > 2) return fail(OD_HIP_EINVAL, "plane out of range");
+  if (level < 0 || level >= ctx->nlev[pli]) return fail(OD_HIP_EINVAL, "level out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (int rc = feed_plane_on(f, pli)) return rc;
+  auto &L = f->P[pli].lev[level];
+  const PvqLevelLayout &Y = ctx->arena[pli].lev[level];
   L.qm.assign(qm, qm + Y.n*Y.n);
   for (int b = 0; b < Y.nb; b++) { L.q[b] = q[b]; L.beta[b] = beta[b]; }
   L.set = true;
   return 0;
+}
+
+int od_hip_enc_feed_set_level(od_hip_enc_feed *f, int level, const int16_t *qm,
+                              const int32_t *q, const double *beta) {
+  return od_hip_enc_feed_set_level_plane(f, 0, level, qm, q, beta);
 }
 
 // Phase 1: forward pyramid + exact gains g of every band of the four luma levels; the
@@ -110,7 +141,10 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
   if (!f) return fail(OD_HIP_EFAULT, "null feed");
   od_hip_ctx *ctx = f->ctx;
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
-  for (auto &L : f->lev) if (!L.set) return fail(OD_HIP_EINVAL, "feed level parameters not set");
+  for (int p = 0; p < 3; p++) {
+    if (!f->P[p].on) continue;
+    for (int l = 0; l < ctx->nlev[p]; l++) if (!f->P[p].lev[l].set) return fail(OD_HIP_EINVAL, "feed level parameters not set");
+  }
   // a slot's host mirror must not be overwritten while a previous copy is in flight
   for (int s = slot0; s < slot0 + nslots; s++) {
     if (f->pending[s]) HIPCHK(hipEventSynchronize(f->ready[s]));
@@ -122,20 +156,29 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
   // the level planes are final here: their copies overlap everything that follows
   HIPCHK(hipEventRecord(f->transformed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->transformed, 0));
-  const size_t pl = (size_t)ctx->nlev[0]*ctx->psz[0];
   for (int s = slot0; s < slot0 + nslots; s++) {
-    HIPCHK(hipMemcpyAsync(f->h_planes + (size_t)s*pl, ctx->lev[0] + (size_t)s*pl, pl*sizeof(od_coeff),
-                          hipMemcpyDeviceToHost, f->copy));
+    for (int p = 0; p < 3; p++) {
+      if (!f->P[p].on) continue;
+      const size_t pl = (size_t)ctx->nlev[p]*ctx->psz[p];
+      HIPCHK(hipMemcpyAsync(f->P[p].h_planes + (size_t)s*pl, ctx->lev[p] + (size_t)s*pl, pl*sizeof(od_coeff),
+                            hipMemcpyDeviceToHost, f->copy));
+    }
   }
-  for (int l = 0; l < 4; l++) {
-    auto &L = f->lev[l];
-    if (int rc = od_hip_pvq_gains(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
+  for (int p = 0; p < 3; p++) {
+    if (!f->P[p].on) continue;
+    for (int l = 0; l < ctx->nlev[p]; l++) {
+      auto &L = f->P[p].lev[l];
+      if (int rc = od_hip_pvq_gains(ctx, slot0, nslots, p, l, L.qm.data(), L.q, L.beta)) return rc;
+    }
   }
   HIPCHK(hipEventRecord(f->gains_done, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->up, f->gains_done, 0));
-  const PvqArena &A = ctx->arena[0];
   for (int s = slot0; s < slot0 + nslots; s++) {
-    HIPCHK(hipMemcpyAsync(f->h_g + (size_t)s*A.g_slot, A.g + (size_t)s*A.g_slot, A.g_slot, hipMemcpyDeviceToHost, f->up));
+    for (int p = 0; p < 3; p++) {
+      if (!f->P[p].on) continue;
+      const PvqArena &A = ctx->arena[p];
+      HIPCHK(hipMemcpyAsync(f->P[p].h_g + (size_t)s*A.g_slot, A.g + (size_t)s*A.g_slot, A.g_slot, hipMemcpyDeviceToHost, f->up));
+    }
     HIPCHK(hipEventRecord(f->gready[s], f->up));
   }
   return 0;
@@ -149,29 +192,33 @@ int od_hip_enc_feed_compand(od_hip_enc_feed *f, int slot) {
   if (slot < 0 || slot >= ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipEventSynchronize(f->gready[slot]));
-  const PvqArena &A = ctx->arena[0];
-  for (int l = 0; l < 4; l++) {
-    auto &L = f->lev[l];
-    const PvqLevelLayout &Y = A.lev[l];
-    const double *g = (const double *)(f->h_g + (size_t)slot*A.g_slot + Y.o_g);
-    double *cg = (double *)(f->h_in + (size_t)slot*A.in_slot + Y.o_cg);
-    int32_t *perm = (int32_t *)(f->h_in + (size_t)slot*A.in_slot + Y.o_perm);
-    // the strip of the context (od_hip_set_strip; the whole frame by default): its blocks'
-    // gains are companded and its work list ordered - the search launch walks the list
-    // positions of the strip's blocks only
-    const int per_sb = 32/Y.n;
-    const long nbx = ctx->pw[0]/Y.n;
-    const long first = (long)ctx->strip0*per_sb*nbx, count = (long)(ctx->strip1 - ctx->strip0)*per_sb*nbx;
-    for (int b = 0; b < Y.nb; b++) {
-      const int q0 = L.q[b];
-      const double beta = L.beta[b];
-      const size_t o = (size_t)b*Y.nblk + first;
-      for (long i = 0; i < count; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
-      pvq_block_order(cg + o, first, count, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
+  for (int p = 0; p < 3; p++) {
+    if (!f->P[p].on) continue;
+    auto &Q = f->P[p];
+    const PvqArena &A = ctx->arena[p];
+    for (int l = 0; l < ctx->nlev[p]; l++) {
+      auto &L = Q.lev[l];
+      const PvqLevelLayout &Y = A.lev[l];
+      const double *g = (const double *)(Q.h_g + (size_t)slot*A.g_slot + Y.o_g);
+      double *cg = (double *)(Q.h_in + (size_t)slot*A.in_slot + Y.o_cg);
+      int32_t *perm = (int32_t *)(Q.h_in + (size_t)slot*A.in_slot + Y.o_perm);
+      // the strip of the context (od_hip_set_strip; the whole frame by default): its blocks'
+      // gains are companded and its work list ordered - the search launch walks the list
+      // positions of the strip's blocks only
+      const int per_sb = (32 >> ctx->geo.xdec[p])/Y.n;
+      const long nbx = ctx->pw[p]/Y.n;
+      const long first = (long)ctx->strip0*per_sb*nbx, count = (long)(ctx->strip1 - ctx->strip0)*per_sb*nbx;
+      for (int b = 0; b < Y.nb; b++) {
+        const int q0 = L.q[b];
+        const double beta = L.beta[b];
+        const size_t o = (size_t)b*Y.nblk + first;
+        for (long i = 0; i < count; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
+        pvq_block_order(cg + o, first, count, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
+      }
     }
+    HIPCHK(hipMemcpyAsync(A.in + (size_t)slot*A.in_slot, Q.h_in + (size_t)slot*A.in_slot, A.in_slot,
+                          hipMemcpyHostToDevice, f->up));
   }
-  HIPCHK(hipMemcpyAsync(A.in + (size_t)slot*A.in_slot, f->h_in + (size_t)slot*A.in_slot, A.in_slot,
-                        hipMemcpyHostToDevice, f->up));
   HIPCHK(hipEventRecord(f->cgup[slot], f->up));
   f->companded[slot] = 1;
   return 0;
@@ -186,17 +233,23 @@ int od_hip_enc_feed_search(od_hip_enc_feed *f, int slot0, int nslots) {
     if (!f->companded[s]) return fail(OD_HIP_EINVAL, "slot was not companded (od_hip_enc_feed_compand)");
     HIPCHK(hipStreamWaitEvent(ctx->stream, f->cgup[s], 0));
   }
-  for (int l = 0; l < 4; l++) {
-    auto &L = f->lev[l];
-    if (int rc = od_hip_pvq_search(ctx, slot0, nslots, 0, l, L.qm.data(), L.q, L.beta)) return rc;
+  for (int p = 0; p < 3; p++) {
+    if (!f->P[p].on) continue;
+    for (int l = 0; l < ctx->nlev[p]; l++) {
+      auto &L = f->P[p].lev[l];
+      if (int rc = od_hip_pvq_search(ctx, slot0, nslots, p, l, L.qm.data(), L.q, L.beta)) return rc;
+    }
   }
   if (int rc = join_aux(ctx)) return rc;          // the PVQ launches run on side streams
   HIPCHK(hipEventRecord(f->computed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
-  const PvqArena &A = ctx->arena[0];
   for (int s = slot0; s < slot0 + nslots; s++) {
-    HIPCHK(hipMemcpyAsync(f->h_out + (size_t)s*A.out_slot, A.out + (size_t)s*A.out_slot, A.out_slot,
-                          hipMemcpyDeviceToHost, f->copy));
+    for (int p = 0; p < 3; p++) {
+      if (!f->P[p].on) continue;
+      const PvqArena &A = ctx->arena[p];
+      HIPCHK(hipMemcpyAsync(f->P[p].h_out + (size_t)s*A.out_slot, A.out + (size_t)s*A.out_slot, A.out_slot,
+                            hipMemcpyDeviceToHost, f->copy));
+    }
     HIPCHK(hipEventRecord(f->ready[s], f->copy));
     f->pending[s] = 1;
   }
@@ -210,17 +263,21 @@ int od_hip_enc_feed_refresh(od_hip_enc_feed *f, int slot0, int nslots) {
   if (!f) return fail(OD_HIP_EFAULT, "null feed");
   od_hip_ctx *ctx = f->ctx;
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
-  const PvqArena &A = ctx->arena[0];
-  const size_t pl = (size_t)ctx->nlev[0]*ctx->psz[0];
   HIPCHK(hipEventRecord(f->computed, ctx->stream));
   HIPCHK(hipStreamWaitEvent(f->copy, f->computed, 0));
   for (int s = slot0; s < slot0 + nslots; s++) {
-    HIPCHK(hipMemcpyAsync(f->h_planes + (size_t)s*pl, ctx->lev[0] + (size_t)s*pl, pl*sizeof(od_coeff),
-                          hipMemcpyDeviceToHost, f->copy));
-    HIPCHK(hipMemcpyAsync(f->h_g + (size_t)s*A.g_slot, A.g + (size_t)s*A.g_slot, A.g_slot, hipMemcpyDeviceToHost, f->copy));
-    HIPCHK(hipMemcpyAsync(f->h_in + (size_t)s*A.in_slot, A.in + (size_t)s*A.in_slot, A.in_slot, hipMemcpyDeviceToHost, f->copy));
-    HIPCHK(hipMemcpyAsync(f->h_out + (size_t)s*A.out_slot, A.out + (size_t)s*A.out_slot, A.out_slot,
-                          hipMemcpyDeviceToHost, f->copy));
+    for (int p = 0; p < 3; p++) {
+      if (!f->P[p].on) continue;
+      auto &Q = f->P[p];
+      const PvqArena &A = ctx->arena[p];
+      const size_t pl = (size_t)ctx->nlev[p]*ctx->psz[p];
+      HIPCHK(hipMemcpyAsync(Q.h_planes + (size_t)s*pl, ctx->lev[p] + (size_t)s*pl, pl*sizeof(od_coeff),
+                            hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(Q.h_g + (size_t)s*A.g_slot, A.g + (size_t)s*A.g_slot, A.g_slot, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(Q.h_in + (size_t)s*A.in_slot, A.in + (size_t)s*A.in_slot, A.in_slot, hipMemcpyDeviceToHost, f->copy));
+      HIPCHK(hipMemcpyAsync(Q.h_out + (size_t)s*A.out_slot, A.out + (size_t)s*A.out_slot, A.out_slot,
+                            hipMemcpyDeviceToHost, f->copy));
+    }
     HIPCHK(hipEventRecord(f->ready[s], f->copy));
     f->pending[s] = 1;
     f->lossless[s] = 0;
@@ -282,23 +339,26 @@ int od_hip_enc_feed_run(od_hip_enc_feed *f, int slot0, int nslots) {
   return od_hip_enc_feed_search(f, slot0, nslots);
 }
 
-int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4]) {
+int od_hip_enc_feed_view_plane(od_hip_enc_feed *f, int slot, int pli, od_hip_feed_level lev[4]) {
   if (!f || !lev) return fail(OD_HIP_EFAULT, "null pointer");
   if (slot < 0 || slot >= f->ctx->geo.nslots) return fail(OD_HIP_EINVAL, "slot out of range");
+  if (pli < 0 || pli > 2 || !f->P[pli].on) return fail(OD_HIP_EINVAL, "plane is not in the feed");
   if (!f->pending[slot] || f->lossless[slot]) return fail(OD_HIP_EINVAL, "no feed run covers this slot");
   HIPCHK(hipSetDevice(f->ctx->device));       // callers are host worker threads
   HIPCHK(hipEventSynchronize(f->ready[slot]));
-  const PvqArena &A = f->ctx->arena[0];
-  const char *out = f->h_out + (size_t)slot*A.out_slot;
-  const char *in = f->h_in + (size_t)slot*A.in_slot;
-  const char *hg = f->h_g + (size_t)slot*A.g_slot;
-  for (int l = 0; l < 4; l++) {
+  const auto &Q = f->P[pli];
+  const PvqArena &A = f->ctx->arena[pli];
+  const char *out = Q.h_out + (size_t)slot*A.out_slot;
+  const char *in = Q.h_in + (size_t)slot*A.in_slot;
+  const char *hg = Q.h_g + (size_t)slot*A.g_slot;
+  memset(lev, 0, 4*sizeof(lev[0]));
+  for (int l = 0; l < f->ctx->nlev[pli]; l++) {
     const PvqLevelLayout &Y = A.lev[l];
     od_hip_feed_level &v = lev[l];
     v.n = Y.n;
     v.nbands = Y.nb;
     v.nblk = Y.nblk;
-    v.nbx = f->ctx->pw[0]/Y.n;
+    v.nbx = f->ctx->pw[pli]/Y.n;
     for (int i = 0; i < 11; i++) v.off[i] = i <= Y.nb ? Y.off[i] : 0;
     v.pad = 0;
     v.ncand = (const int32_t *)(out + Y.o_nc);
@@ -308,11 +368,15 @@ int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4])
     v.y = (const int16_t *)(out + Y.o_y);
     v.cg = (const double *)(in + Y.o_cg);
     v.g = (const double *)(hg + Y.o_g);
-    v.lev = f->h_planes + ((size_t)slot*f->ctx->nlev[0] + l)*f->ctx->psz[0];
-    v.lev_stride = f->ctx->pw[0];
+    v.lev = Q.h_planes + ((size_t)slot*f->ctx->nlev[pli] + l)*f->ctx->psz[pli];
+    v.lev_stride = f->ctx->pw[pli];
     v.pad2 = 0;
   }
   return 0;
+}
+
+int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4]) {
+  return od_hip_enc_feed_view_plane(f, slot, 0, lev);
 }
 
 }  // extern "C"

@@ -405,14 +405,26 @@ static void fdct_from_feed(int bs, od_coeff *y, int ystride, const od_coeff *x,
    && T.enc->state.frame_type == OD_I_FRAME) {
     const od_state *st;
     od_coeff *d0;
+    const od_hip_feed_level *L;
     int w;
     int h;
+    int pli;
     st = &T.enc->state;
-    d0 = st->dtmp[0];
-    w = st->frame_width;
-    h = st->frame_height;
-    if (ystride == w && y >= d0 && y < d0 + (size_t)w*h) {
-      const od_hip_feed_level *L;
+    /* which plane's dtmp the block is written into: luma, or a chroma plane of the feed */
+    L = NULL;
+    d0 = NULL;
+    w = h = 0;
+    for (pli = 0; pli < 3; pli++) {
+      w = st->frame_width >> (pli > 0);
+      h = st->frame_height >> (pli > 0);
+      d0 = st->dtmp[pli];
+      if (d0 != NULL && y >= d0 && y < d0 + (size_t)w*h) {
+        if (pli == 0) L = &T.lev[3 - bs];
+        else if (T.levc[pli - 1] != NULL && bs <= 2) L = &T.levc[pli - 1][2 - bs];
+        break;
+      }
+    }
+    if (L != NULL && ystride == w) {
       size_t off;
       int n;
       int yy;
@@ -421,7 +433,6 @@ static void fdct_from_feed(int bs, od_coeff *y, int ystride, const od_coeff *x,
       yy = (int)(off/w);
       xx = (int)(off%w);
       n = 4 << bs;
-      L = &T.lev[3 - bs];
       if (L->lev != NULL && L->n == n && (yy & (n - 1)) == 0 && (xx & (n - 1)) == 0) {
         const od_coeff *src;
         int i;
@@ -621,7 +632,16 @@ static void fill_img(od_img *img, const unsigned char *base, int w, int h) {
   }
 }
 
+int od_hipenc_level_params_plane(const od_hipenc_params *p, int pli, int16_t qm[4][1024],
+ int32_t q[4][11], double beta[4][11]);
 int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
+ int32_t q[4][11], double beta[4][11]) {
+  return od_hipenc_level_params_plane(p, 0, qm, q, beta);
+}
+
+/* The same for plane pli of a 4:2:0 stream: level l of a chroma plane holds its (16 >> l)-sized
+   blocks (three levels; the fourth entry is left zero). */
+int od_hipenc_level_params_plane(const od_hipenc_params *p, int pli, int16_t qm[4][1024],
  int32_t q[4][11], double beta[4][11]) {
   unsigned char frame[64*64 + 2*32*32];
   daala_enc_ctx *enc;
@@ -630,6 +650,7 @@ int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
   int left;
   int l;
   if (p == NULL) return OD_HIP_EFAULT;
+  if (pli < 0 || pli > 2) return OD_HIP_EINVAL;
   /* state.qm / pvq_qm_q4 / quantizer are filled while the first frame is coded
      (src/encode.c:3025-3050): code one flat 64x64 frame and read them back. */
   memset(frame, 128, sizeof(frame));
@@ -646,20 +667,21 @@ int od_hipenc_level_params(const od_hipenc_params *p, int16_t qm[4][1024],
     int n;
     int nb;
     int b;
-    bs = 3 - l;
-    n = 4 << bs;
-    nb = OD_BAND_OFFSETS[bs][0];
+    bs = (pli > 0 ? 2 : 3) - l;
     memset(qm[l], 0, sizeof(qm[l]));
-    memcpy(qm[l], enc->state.qm + od_qm_offset(bs, 0), sizeof(int16_t)*n*n);
     for (b = 0; b < 11; b++) {
       q[l][b] = 1;
       beta[l][b] = 1;
     }
+    if (bs < 0) continue;
+    n = 4 << bs;
+    nb = OD_BAND_OFFSETS[bs][0];
+    memcpy(qm[l], enc->state.qm + od_qm_offset(bs, pli > 0), sizeof(int16_t)*n*n);
     for (b = 0; b < nb; b++) {
       /* src/pvq_encoder.c:712 */
-      q[l][b] = OD_MAXI(1, enc->state.quantizer[0]
-       *enc->state.pvq_qm_q4[0][od_qm_get_index(bs, b + 1)] >> 4);
-      beta[l][b] = OD_PVQ_BETA[enc->use_activity_masking][0][bs][b];
+      q[l][b] = OD_MAXI(1, enc->state.quantizer[pli]
+       *enc->state.pvq_qm_q4[pli][od_qm_get_index(bs, b + 1)] >> 4);
+      beta[l][b] = OD_PVQ_BETA[enc->use_activity_masking][pli][bs][b];
     }
   }
   daala_encode_free(enc);
@@ -719,6 +741,7 @@ struct od_hipenc {
   int next_worker_id;
   int host_pvq;         /* keyframe od_pvq_encode: 1 hip_pvq_host.c (default), 0 the reference's */
   int time_cpu;         /* per-call timers around the C searches (HIPENC_TIME=1) */
+  int chroma_feed;      /* the chroma planes are in the device feed too (keyframes) */
   int sample_every;     /* HIPENC_SAMPLE: re-search every n-th feed candidate (default 256, 0 off) */
   int pfeed_on;         /* HIPENC_PFEED (default 1): inter frames take the P-frame feed */
   long job_seq;         /* number of jobs submitted so far */
@@ -775,7 +798,9 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   daala_packet dp;
   int left;
   od_hip_feed_level lev[4];
+  od_hip_feed_level levc[2][4];
   T.lev = NULL;
+  T.levc[0] = T.levc[1] = NULL;
   T.haar[0] = T.haar[1] = T.haar[2] = NULL;
   if (J->views != NULL) T.lev = J->views + 4*(size_t)f;
   else if (S->feed != NULL && S->p.quant == 0) {
@@ -784,6 +809,14 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   else if (S->feed != NULL) {
     if (od_hip_enc_feed_view(S->feed, f % J->nslots, lev) != 0) return -1;
     T.lev = lev;
+    if (S->chroma_feed) {
+      if (od_hip_enc_feed_view_plane(S->feed, f % J->nslots, 1, levc[0]) != 0
+       || od_hip_enc_feed_view_plane(S->feed, f % J->nslots, 2, levc[1]) != 0) {
+        return -1;
+      }
+      T.levc[0] = levc[0];
+      T.levc[1] = levc[1];
+    }
   }
   /* Frame f of the stream on a context that did not code frames 0..f-1: the
      only history a keyframe packet carries is the golden-frame flag
@@ -825,6 +858,7 @@ static int encode_frame(od_hipenc *S, job *J, daala_enc_ctx *enc, int f) {
   }
   if (T.time_cpu) T.st.frame_cpu_s += now_s() - T.t_frame0;
   T.lev = NULL;
+  T.levc[0] = T.levc[1] = NULL;
   T.haar[0] = T.haar[1] = T.haar[2] = NULL;
   T.enc = NULL;
   T.pf_valid = 0;
@@ -1124,6 +1158,20 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     if (S->ctx == NULL || S->feed == NULL) rc = OD_HIP_ENODEV;
     else if (od_hipenc_level_params(p, qm, q, beta) != 0) rc = OD_HIP_EINVAL;
     else for (l = 0; l < 4; l++) od_hip_enc_feed_set_level(S->feed, l, qm[l], q[l], beta[l]);
+    /* the chroma planes' transforms and no-reference candidates travel with luma's
+       (HIPENC_CHROMA_FEED=0: luma only, as before round 3) */
+    {
+      const char *e;
+      int pli;
+      e = getenv("HIPENC_CHROMA_FEED");
+      S->chroma_feed = rc == 0 && p->quant != 0 && !(e != NULL && atoi(e) == 0);
+      for (pli = 1; S->chroma_feed && pli < 3 && rc == 0; pli++) {
+        if (od_hipenc_level_params_plane(p, pli, qm, q, beta) != 0) rc = OD_HIP_EINVAL;
+        for (l = 0; l < 3 && rc == 0; l++) {
+          if (od_hip_enc_feed_set_level_plane(S->feed, pli, l, qm[l], q[l], beta[l]) != 0) rc = OD_HIP_ENODEV;
+        }
+      }
+    }
   }
   if (rc != 0) {
     S->nw = 0;

@@ -9,6 +9,7 @@
 /* Per-thread state: which frame's feed this worker consumes. */
 typedef struct glue_tls {
   const od_hip_feed_level *lev;   /* 4 views, or NULL: plain reference */
+  const od_hip_feed_level *levc[2];  /* keyframes: the chroma planes' views (3 levels each), or NULL */
   const od_coeff *haar[3];        /* lossless frames: the device's Haar planes of this frame, or NULL */
   int haar_stride[3];
   int check;

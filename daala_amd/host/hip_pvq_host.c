@@ -976,10 +976,12 @@ static void set_block_context(daala_enc_ctx *enc, int pli, int bs, int is_keyfra
   T.cur_L = NULL;
   T.cur_P = NULL;
   T.cur_blk = 0;
-  if (is_keyframe && pli == 0 && T.lev != NULL) {
+  if (is_keyframe && T.lev != NULL && (pli == 0 || (pli > 0 && pli < 3 && T.levc[pli - 1] != NULL && bs <= 2))) {
+    /* keyframes: luma always, a chroma plane when it is in the feed (its no-reference candidates
+       are used whenever pvq_theta's condition for that search holds) */
     const od_hip_feed_level *L;
     int blk;
-    L = &T.lev[3 - bs];
+    L = pli == 0 ? &T.lev[3 - bs] : &T.levc[pli - 1][2 - bs];
     blk = (by >> bs)*L->nbx + (bx >> bs);
     if (L->g != NULL && blk >= 0 && blk < L->nblk && L->nbands == OD_BAND_OFFSETS[bs][0]) {
       T.cur_L = L;

@@ -323,6 +323,16 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_compand(od_hip_enc_feed *feed, int slot);
 int od_hip_enc_feed_search(od_hip_enc_feed *feed, int slot0, int nslots);
 int od_hip_enc_feed_view(od_hip_enc_feed *feed, int slot, od_hip_feed_level lev[4]);
+/* The chroma planes in the feed (keyframes).  Their forward transforms and their no-reference
+ * candidates are as state-free as luma's: pvq_theta runs the chroma no-reference search whenever
+ * the CfL reference correlates badly or the gain is small (src/pvq_encoder.c:449-455) on an input
+ * that depends on the picture alone.  od_hip_enc_feed_set_level_plane(feed, pli, ...) for every
+ * level of a chroma plane (level l holds its ((32 >> xdec) >> l)-sized blocks) puts the plane
+ * into every following run; od_hip_enc_feed_view_plane returns its levels (entries beyond the
+ * plane's level count are zero).  The two luma-only names above are pli = 0. */
+int od_hip_enc_feed_set_level_plane(od_hip_enc_feed *feed, int pli, int level, const int16_t *qm,
+ const int32_t *q, const double *beta);
+int od_hip_enc_feed_view_plane(od_hip_enc_feed *feed, int slot, int pli, od_hip_feed_level lev[4]);
 /* On the coding rank of a superblock-row sharded frame, after od_hip_gather_strips: fetches
  * the slots' host mirrors again (the other ranks' strips arrived device to device). */
 int od_hip_enc_feed_refresh(od_hip_enc_feed *feed, int slot0, int nslots);

@@ -91,6 +91,29 @@ def test_hip_encoder_packets_identical_cif(masking):
     assert st.g2_mismatch == 0 and st.pvq_check_fail == 0
 
 
+def test_chroma_planes_in_the_keyframe_feed(monkeypatch):
+    """Keyframes: the chroma planes' forward transforms and no-reference candidates come from the
+    device like luma's (od_hip_enc_feed_set_level_plane).  Check mode re-computes every transform
+    and re-searches every candidate taken from the feed on the host (fdct_check_fail, check_fail,
+    g2_mismatch); packets identical to the pure reference with the planes in the feed and without
+    (HIPENC_CHROMA_FEED=0), more searches and transforms served by the device with them."""
+    w, h, nf = 352, 288, 2
+    buf = H.pack_frames(frames_of(w, h, [11, 12]), w, h)
+    for masking in (1, 0):
+        want = reference_packets(buf, w, h, nf, masking)
+        prm = H.Params(w, h, 20, 7, masking, 2, 1, 0)
+        n1, got1, st1 = H.encode(prm, buf, nf, use_device=1)
+        monkeypatch.setenv('HIPENC_CHROMA_FEED', '0')
+        n0, got0, st0 = H.encode(prm, buf, nf, use_device=1)
+        monkeypatch.delenv('HIPENC_CHROMA_FEED')
+        assert n1 > 0 and got1 == want and got0 == want
+        for st in (st0, st1):
+            assert st.check_fail == 0 and st.fdct_check_fail == 0 and st.g2_mismatch == 0
+            assert st.pvq_check_fail == 0 and st.lost_sync == 0
+        assert st1.dev_hits > st0.dev_hits and st1.fdct_hits > st0.fdct_hits
+        assert st1.dev_hits + st1.cpu_other + st1.cpu_noref_luma == st0.dev_hits + st0.cpu_other + st0.cpu_noref_luma
+
+
 def test_hip_encoder_packets_identical_1080p():
     w, h, nf = 1920, 1080, 2
     buf = H.pack_frames(frames_of(w, h, [7, 8]), w, h)
