@@ -205,65 +205,50 @@ def od_mc_predict_blocks(refs, org_x, org_y, blocks, dst):
     return out
 
 
-def comm_unique_id():
-    """The 128-byte RCCL id rank 0 creates and every rank passes to Comm()."""
-    buf = (ctypes.c_ubyte*128)()
-    _chk(load().od_hip_comm_unique_id(buf))
-    return bytes(buf)
+class McSad(object):
+    """od_hip_mc with the frame being coded resident too: the batched OBMC + SAD of the motion
+    search (od_hip_mc_set_ref / od_hip_mc_set_src / od_hip_mc_sad_items).
+    refs[pli]: [nref, rows, stride] u8 with the picture origin at (org_x[pli], org_y[pli]);
+    src[pli]: the padded input plane; dec[pli]: (xdec, ydec)."""
 
+    ITEM = np.dtype([('x', np.int32), ('y', np.int32), ('log_blk_sz', np.int32), ('oc', np.int32),
+                     ('s', np.int32), ('ref', np.int32, 4), ('mvx', np.int32, 4), ('mvy', np.int32, 4),
+                     ('reserved', np.int32)])
 
-class Comm(object):
-    """od_hip_comm: an RCCL communicator over the ranks of a superblock-row sharded frame."""
-
-    def __init__(self, device, world, rank, uid):
+    def __init__(self, refs, org_x, org_y, src, dec, device=0):
         lib = load()
-        lib.od_hip_comm_create.restype = ctypes.c_void_p
-        lib.od_hip_comm_create.argtypes = [c_int, c_int, c_int, ctypes.c_char_p]
-        lib.od_hip_comm_destroy.argtypes = [ctypes.c_void_p]
+        lib.od_hip_mc_create.restype = ctypes.c_void_p
+        lib.od_hip_mc_create.argtypes = [c_int, c_int]
+        lib.od_hip_mc_destroy.argtypes = [ctypes.c_void_p]
+        lib.od_hip_mc_set_ref.argtypes = [ctypes.c_void_p, c_int, c_int, U8P, c_int, c_int, c_int, c_int]
+        lib.od_hip_mc_set_src.argtypes = [ctypes.c_void_p, c_int, U8P, c_int, c_int, c_int, c_int, c_int]
+        lib.od_hip_mc_sad_items.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, ctypes.c_void_p, c_int,
+                                            ctypes.POINTER(ctypes.c_int32)]
         self.lib = lib
-        self.h = lib.od_hip_comm_create(device, world, rank, uid)
+        self.nplanes = len(refs)
+        self.h = lib.od_hip_mc_create(device, refs[0].shape[0])
         if not self.h:
             raise HipError(lib.od_hip_last_error().decode())
+        for pli in range(self.nplanes):
+            r = np.ascontiguousarray(refs[pli], dtype=np.uint8)
+            for k in range(r.shape[0]):
+                _chk(lib.od_hip_mc_set_ref(self.h, pli, k, r[k].ctypes.data_as(U8P), r.shape[2], r.shape[1],
+                                           int(org_x[pli]), int(org_y[pli])))
+            sp = np.ascontiguousarray(src[pli], dtype=np.uint8)
+            _chk(lib.od_hip_mc_set_src(self.h, pli, sp.ctypes.data_as(U8P), sp.shape[1], sp.shape[1], sp.shape[0],
+                                       int(dec[pli][0]), int(dec[pli][1])))
+
+    def sad_items(self, items, pic_w, pic_h, nplanes=None):
+        it = np.ascontiguousarray(items, dtype=self.ITEM)
+        out = np.zeros(len(it), np.int32)
+        _chk(self.lib.od_hip_mc_sad_items(self.h, self.nplanes if nplanes is None else nplanes, pic_w, pic_h,
+                                          it.ctypes.data, len(it), _p32(out)))
+        return out
 
     def close(self):
         if self.h:
-            self.lib.od_hip_comm_destroy(self.h)
+            self.lib.od_hip_mc_destroy(self.h)
             self.h = None
-
-
-class McBlock(ctypes.Structure):
-    """od_hip_mc_block (include/daala_hip.h)."""
-    _fields_ = [('x', ctypes.c_int32), ('y', ctypes.c_int32), ('log_xblk_sz', ctypes.c_int32),
-                ('log_yblk_sz', ctypes.c_int32), ('ref', ctypes.c_int32*4),
-                ('mvx', ctypes.c_int32*4), ('mvy', ctypes.c_int32*4), ('oc', ctypes.c_int32),
-                ('s', ctypes.c_int32)]
-
-
-def od_mc_predict_blocks(refs, org_x, org_y, blocks, dst):
-    """F3: OBMC prediction of a list of blocks.  refs: list of equal-shape padded u8 planes;
-    blocks: list of dicts (x, y, lx, ly, ref[4], mvx[4], mvy[4], oc, s); dst: u8 plane (copy)."""
-    refs = [np.ascontiguousarray(r, dtype=np.uint8) for r in refs]
-    out = np.ascontiguousarray(dst, dtype=np.uint8).copy()
-    arr = (McBlock*len(blocks))()
-    for i, b in enumerate(blocks):
-        arr[i].x, arr[i].y, arr[i].log_xblk_sz, arr[i].log_yblk_sz = b['x'], b['y'], b['lx'], b['ly']
-        for k in range(4):
-            arr[i].ref[k], arr[i].mvx[k], arr[i].mvy[k] = int(b['ref'][k]), int(b['mvx'][k]), int(b['mvy'][k])
-        arr[i].oc, arr[i].s = b['oc'], b['s']
-    ptrs = (U8P*len(refs))(*[r.ctypes.data_as(U8P) for r in refs])
-    lib = load()
-    lib.od_hip_mc_predict_blocks.argtypes = [c_int, ctypes.POINTER(U8P), c_int, c_int, c_int, c_int,
-                                             ctypes.POINTER(McBlock), c_int, U8P, c_int, c_int]
-    _chk(lib.od_hip_mc_predict_blocks(len(refs), ptrs, refs[0].shape[1], refs[0].shape[0], org_x, org_y,
-                                      arr, len(blocks), out.ctypes.data_as(U8P), out.shape[1],
-                                      out.shape[0]))
-    return out
-
-
-class McPair(ctypes.Structure):
-    """od_hip_mc_pair (include/daala_hip.h)."""
-    _fields_ = [('sx', ctypes.c_int32), ('sy', ctypes.c_int32), ('rx', ctypes.c_int32),
-                ('ry', ctypes.c_int32), ('log_blk_sz', ctypes.c_int32), ('satd', ctypes.c_int32)]
 
 
 def od_coding_order_blocks(bs, blocks, to_raster=False, dst=None):

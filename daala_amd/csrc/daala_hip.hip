@@ -477,6 +477,15 @@ struct od_hip_mc {
   McBlock *d_blocks = nullptr, *h_blocks = nullptr;
   size_t blocks_cap = 0;
   hipEvent_t done = nullptr;        // od_hip_mc_predict_ctx: the prediction is in the context's plane
+  // od_hip_mc_sad_items: the frame being coded (one dense plane each) and the item / result lists
+  struct Src {
+    uint8_t *d = nullptr, *h = nullptr;
+    size_t cap = 0;
+    int w = 0, h_rows = 0, xdec = 0, ydec = 0;
+  } src[3];
+  McSadItem *d_items = nullptr, *h_items = nullptr;
+  int32_t *d_sad = nullptr, *h_sad = nullptr;
+  size_t items_cap = 0;
 };
 
 extern "C" {
@@ -493,6 +502,14 @@ void od_hip_mc_destroy(od_hip_mc *m) {
   }
   if (m->d_blocks) (void)hipFree(m->d_blocks);
   if (m->h_blocks) (void)hipHostFree(m->h_blocks);
+  for (auto &q : m->src) {
+    if (q.d) (void)hipFree(q.d);
+    if (q.h) (void)hipHostFree(q.h);
+  }
+  if (m->d_items) (void)hipFree(m->d_items);
+  if (m->h_items) (void)hipHostFree(m->h_items);
+  if (m->d_sad) (void)hipFree(m->d_sad);
+  if (m->h_sad) (void)hipHostFree(m->h_sad);
   if (m->done) (void)hipEventDestroy(m->done);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -638,6 +655,112 @@ int od_hip_mc_predict_ctx(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, 
   if (!m->done) HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
   HIPCHK(hipEventRecord(m->done, m->stream));
   HIPCHK(hipStreamWaitEvent(ctx->stream, m->done, 0));
+  return 0;
+}
+
+// F3, second half (mc_kernels.hpp: k_mc_sad_items).  od_hip_mc_set_src: plane pli of the frame
+// being coded, w x h samples (the encoder's padded input plane), resident until the next call.
+int od_hip_mc_set_src(od_hip_mc *m, int pli, const unsigned char *plane, int stride, int w, int h, int xdec,
+                      int ydec) {
+  if (!m || !plane) return fail(OD_HIP_EFAULT, "null pointer");
+  if (pli < 0 || pli > 2 || w < 1 || h < 1 || stride < w || xdec < 0 || xdec > 1 || ydec < 0 || ydec > 1)
+    return fail(OD_HIP_EINVAL, "bad source plane");
+  HIPCHK(hipSetDevice(m->device));
+  auto &S = m->src[pli];
+  const size_t bytes = (size_t)w*h;
+  HIPCHK(hipStreamSynchronize(m->stream));          // the staging plane may still be in flight
+  if (S.cap < bytes) {
+    if (S.d) (void)hipFree(S.d);
+    if (S.h) (void)hipHostFree(S.h);
+    S.d = S.h = nullptr;
+    S.cap = 0;
+    HIPCHK(hipMalloc((void **)&S.d, bytes));
+    HIPCHK(hipHostMalloc((void **)&S.h, bytes));
+    S.cap = bytes;
+  }
+  S.w = w;
+  S.h_rows = h;
+  S.xdec = xdec;
+  S.ydec = ydec;
+  for (int y = 0; y < h; y++) memcpy(S.h + (size_t)y*w, plane + (size_t)y*stride, w);
+  HIPCHK(hipMemcpyAsync(S.d, S.h, bytes, hipMemcpyHostToDevice, m->stream));
+  return 0;
+}
+
+// SAD of the OBMC prediction of every item against the source planes, planes 0 .. nplanes - 1
+// summed as od_mv_est_sad does (src/mcenc.c:2271-2300; chroma >> OD_MC_CHROMA_SCALE).
+int od_hip_mc_sad_items(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const od_hip_mc_sad_item *items,
+                        int nitems, int32_t *sad) {
+  if (!m || !items || !sad) return fail(OD_HIP_EFAULT, "null pointer");
+  if (nplanes < 1 || nplanes > 3 || pic_w < 1 || pic_h < 1 || nitems < 0) return fail(OD_HIP_EINVAL, "bad geometry");
+  for (int pli = 0; pli < nplanes; pli++) {
+    if (!m->pl[pli].d_refs) return fail(OD_HIP_EINVAL, "no reference planes set for this plane");
+    if (!m->src[pli].d) return fail(OD_HIP_EINVAL, "no source plane set for this plane");
+  }
+  // operand shapes are checked on the host before anything is launched
+  for (int b = 0; b < nitems; b++) {
+    const od_hip_mc_sad_item &q = items[b];
+    if (q.log_blk_sz < 3 || q.log_blk_sz > 6 || q.x < 0 || q.y < 0 || q.oc < 0 || q.oc > 3 || q.s < 0 || q.s > 3)
+      return fail(OD_HIP_EINVAL, "bad SAD item");
+    for (int pli = 0; pli < nplanes; pli++) {
+      const auto &S = m->src[pli];
+      if ((q.x & ((1 << S.xdec) - 1)) || (q.y & ((1 << S.ydec) - 1))
+          || (q.x >> S.xdec) + (1 << (q.log_blk_sz - S.xdec)) > S.w
+          || (q.y >> S.ydec) + (1 << (q.log_blk_sz - S.ydec)) > S.h_rows)
+        return fail(OD_HIP_EINVAL, "SAD item outside the source plane");
+    }
+    for (int k = 0; k < 4; k++) if (q.ref[k] < 0 || q.ref[k] >= m->nref) return fail(OD_HIP_EINVAL, "bad reference index");
+  }
+  if (nitems == 0) return 0;
+  HIPCHK(hipSetDevice(m->device));
+  static_assert(sizeof(McSadItem) == sizeof(od_hip_mc_sad_item), "McSadItem mirrors od_hip_mc_sad_item");
+  if (m->items_cap < (size_t)nitems) {
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->d_items) (void)hipFree(m->d_items);
+    if (m->h_items) (void)hipHostFree(m->h_items);
+    if (m->d_sad) (void)hipFree(m->d_sad);
+    if (m->h_sad) (void)hipHostFree(m->h_sad);
+    m->d_items = m->h_items = nullptr;
+    m->d_sad = m->h_sad = nullptr;
+    m->items_cap = 0;
+    const size_t cap = (size_t)nitems + nitems/2;
+    HIPCHK(hipMalloc((void **)&m->d_items, cap*sizeof(McSadItem)));
+    HIPCHK(hipHostMalloc((void **)&m->h_items, cap*sizeof(McSadItem)));
+    HIPCHK(hipMalloc((void **)&m->d_sad, cap*sizeof(int32_t)));
+    HIPCHK(hipHostMalloc((void **)&m->h_sad, cap*sizeof(int32_t)));
+    m->items_cap = cap;
+  }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  memcpy(m->h_items, items, (size_t)nitems*sizeof(McSadItem));
+  HIPCHK(hipMemcpyAsync(m->d_items, m->h_items, (size_t)nitems*sizeof(McSadItem), hipMemcpyHostToDevice, m->stream));
+  McSadArgs a;
+  for (int pli = 0; pli < 3; pli++) {
+    const int q = pli < nplanes ? pli : 0;
+    const auto &P = m->pl[q];
+    const auto &S = m->src[q];
+    a.pl[pli].R.refs = P.d_refs;
+    a.pl[pli].R.ref_plane = P.plane;
+    a.pl[pli].R.ref_stride = P.ref_stride;
+    a.pl[pli].R.ref_h = P.ref_h;
+    a.pl[pli].R.org_x = P.org_x;
+    a.pl[pli].R.org_y = P.org_y;
+    a.pl[pli].src = S.d;
+    a.pl[pli].src_stride = S.w;
+    a.pl[pli].xdec = S.xdec;
+    a.pl[pli].ydec = S.ydec;
+    a.pl[pli].clip_w = (pic_w + (1 << S.xdec) - 1) >> S.xdec;
+    a.pl[pli].clip_h = (pic_h + (1 << S.ydec) - 1) >> S.ydec;
+    a.pl[pli].shift = q > 0 ? 2 : 0;                 // OD_MC_CHROMA_SCALE (src/mcenc.c:53)
+  }
+  a.nplanes = nplanes;
+  a.items = m->d_items;
+  a.nitems = nitems;
+  a.sad = m->d_sad;
+  hipLaunchKernelGGL(k_mc_sad_items, dim3(nitems), dim3(MC_SAD_THREADS), 0, m->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(m->h_sad, m->d_sad, (size_t)nitems*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  memcpy(sad, m->h_sad, (size_t)nitems*sizeof(int32_t));
   return 0;
 }
 

@@ -38,42 +38,47 @@ __constant__ int16_t MC_SUBPEL[8][6] = {     // OD_SUBPEL_FILTER_SET (src/mc.c:6
   {3, -18, 97, 58, -15, 3}, {4, -20, 80, 80, -20, 4}, {3, -15, 58, 97, -18, 3},
   {2, -11, 37, 112, -15, 3}, {1, -5, 18, 122, -9, 1}};
 
-#define MC_THREADS 128
-__global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
-  __shared__ int16_t buff[(64 + 5)*64];
-  __shared__ uint8_t pred[4][64*64];
-  const int lane = threadIdx.x;
-  const int bidx = blockIdx.x;
-  if (bidx >= a.nblocks) return;
-  const McBlock blk = a.blocks[bidx];
-  const int lx = blk.log_xblk_sz, ly = blk.log_yblk_sz;
+// The reference planes of one image plane as a kernel sees them.
+struct McPlaneRef {
+  const uint8_t *refs;    // nref planes of ref_h x ref_stride bytes, back to back
+  size_t ref_plane;       // bytes per reference plane
+  int ref_stride, ref_h;
+  int org_x, org_y;       // picture origin inside a reference plane (the padding)
+};
+
+// The four single-vector predictions of a block (one per corner) into pred[k][...] (4096 bytes
+// apart), NT threads cooperating; corners that share reference and vector with an earlier corner
+// are not predicted again: alias[k] names the tile that holds corner k's prediction.
+template <int NT>
+__device__ __forceinline__ void mc_predict_corners(const McPlaneRef &R, int bx, int by, int lx, int ly,
+                                                   const int32_t *ref, const int32_t *cmvx, const int32_t *cmvy,
+                                                   int16_t *buff, uint8_t *pred, int *alias, int lane) {
   const int xblk = 1 << lx, yblk = 1 << ly, npix = xblk*yblk;
-  int alias[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     alias[k] = k;
     for (int e = 0; e < k; e++) {
-      if (alias[k] == k && blk.ref[e] == blk.ref[k] && blk.mvx[e] == blk.mvx[k]
-          && blk.mvy[e] == blk.mvy[k]) alias[k] = alias[e];
+      if (alias[k] == k && ref[e] == ref[k] && cmvx[e] == cmvx[k] && cmvy[e] == cmvy[k]) alias[k] = alias[e];
     }
   }
   for (int k = 0; k < 4; k++) {
     if (alias[k] != k) continue;                       // wave-uniform
-    const int mvx = blk.mvx[k], mvy = blk.mvy[k];
+    const int mvx = cmvx[k], mvy = cmvy[k];
     const int mvxf = mvx & 7, mvyf = mvy & 7;
-    const uint8_t *plane = a.refs + (size_t)blk.ref[k]*a.ref_plane;
-    const int sx0 = a.org_x + blk.x + (mvx >> 3), sy0 = a.org_y + blk.y + (mvy >> 3);
+    const uint8_t *plane = R.refs + (size_t)ref[k]*R.ref_plane;
+    const int sx0 = R.org_x + bx + (mvx >> 3), sy0 = R.org_y + by + (mvy >> 3);
+    uint8_t *pk = pred + k*4096;
     auto px = [&](int yy, int xx) -> int {
       // the reference relies on the padding of its reference frames; the clamp only keeps
       // a vector that points beyond it from reading outside the buffer
-      yy = yy < 0 ? 0 : yy >= a.ref_h ? a.ref_h - 1 : yy;
-      xx = xx < 0 ? 0 : xx >= a.ref_stride ? a.ref_stride - 1 : xx;
-      return plane[(size_t)yy*a.ref_stride + xx];
+      yy = yy < 0 ? 0 : yy >= R.ref_h ? R.ref_h - 1 : yy;
+      xx = xx < 0 ? 0 : xx >= R.ref_stride ? R.ref_stride - 1 : xx;
+      return plane[(size_t)yy*R.ref_stride + xx];
     };
     if (mvxf || mvyf) {
       // 1st stage: rows -2 .. yblk + 2 (src/mc.c:145-172)
       const int nrow = yblk + 5;
-      for (int e = lane; e < nrow*xblk; e += MC_THREADS) {
+      for (int e = lane; e < nrow*xblk; e += NT) {
         const int j = (e >> lx) - 2, i = e & (xblk - 1);
         int v;
         if (mvxf) {
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
       }
       __syncthreads();
       // 2nd stage (src/mc.c:174-198)
-      for (int e = lane; e < npix; e += MC_THREADS) {
+      for (int e = lane; e < npix; e += NT) {
         const int j = e >> lx, i = e & (xblk - 1);
         int v;
         if (mvyf) {
@@ -97,41 +102,39 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
           v = (sum + (1 << 13) + (128 << 14)) >> 14;
         }
         else v = (buff[(j + 2)*xblk + i] + (1 << 6) + (128 << 7)) >> 7;
-        pred[k][e] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        pk[e] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
       }
       __syncthreads();
     }
     else {
-      for (int e = lane; e < npix; e += MC_THREADS) pred[k][e] = (uint8_t)px(sy0 + (e >> lx), sx0 + (e & (xblk - 1)));
+      for (int e = lane; e < npix; e += NT) pk[e] = (uint8_t)px(sy0 + (e >> lx), sx0 + (e & (xblk - 1)));
       __syncthreads();
     }
   }
-  const uint8_t *p0 = pred[alias[0]], *p1 = pred[alias[1]], *p2 = pred[alias[2]], *p3 = pred[alias[3]];
-  uint8_t *d = a.dst + (size_t)blk.y*a.dst_stride + blk.x;
-  const int l2 = lx + ly;
-  if (blk.s == 3) {
-    // od_mc_blend_full8_c
-    const int round = 1 << (l2 - 1);
-    for (int e = lane; e < npix; e += MC_THREADS) {
-      const int j = e >> lx, i = e & (xblk - 1);
-      int av = p0[e], bv = p3[e];
-      av = (av << lx) + (p1[e] - av)*i;
-      bv = (bv << lx) + (p2[e] - bv)*i;
-      d[(size_t)j*a.dst_stride + i] = (uint8_t)(((av << ly) + (bv - av)*j + round) >> l2);
-    }
-  }
-  else {
-    // od_mc_setup_s_split + od_mc_blend_full_split8_c: the weight of corner c at (i, j) is
-    // s0[c] + j*dsdj[c] + i*(dsdi[c] + j*ddsdidj[c]) - the closed form of its row/column
-    // increments
-    int s0[4] = {2 << l2, 0, 0, 0};
-    int dsdi[4] = {-(2 << lx), 2 << lx, 0, 0};
-    int dsdj[4] = {-(2 << ly), 0, 0, 2 << ly};
-    int dd[4] = {2, -2, 2, -2};
-    const int oc = blk.oc & 3;
+}
+
+// Blending weights of a block: od_mc_blend_full8_c (s == 3) or od_mc_setup_s_split +
+// od_mc_blend_full_split8_c - the weight of corner c at (i, j) is
+// s0[c] + j*dsdj[c] + i*(dsdi[c] + j*dd[c]), the closed form of its row/column increments.
+struct McBlend {
+  int full, lx, ly, l2;
+  int s0[4], dsdi[4], dsdj[4], dd[4];
+  __device__ __forceinline__ void setup(int lx_, int ly_, int oc_, int s) {
+    lx = lx_;
+    ly = ly_;
+    l2 = lx + ly;
+    full = s == 3;
+    if (full) return;
+    const int is0[4] = {2 << l2, 0, 0, 0};
+    const int idsdi[4] = {-(2 << lx), 2 << lx, 0, 0};
+    const int idsdj[4] = {-(2 << ly), 0, 0, 2 << ly};
+    const int idd[4] = {2, -2, 2, -2};
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s0[q] = is0[q]; dsdi[q] = idsdi[q]; dsdj[q] = idsdj[q]; dd[q] = idd[q]; }
+    const int oc = oc_ & 3;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-      const bool on = t == 0 ? !(blk.s & 1) : !(blk.s & 2);
+      const bool on = t == 0 ? !(s & 1) : !(s & 2);
       const int c = t == 0 ? (oc + 1) & 3 : (oc + 3) & 3;
       if (on) {
 #pragma unroll
@@ -149,15 +152,130 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
         }
       }
     }
-    const int round = 1 << l2;
-    for (int e = lane; e < npix; e += MC_THREADS) {
-      const int j = e >> lx, i = e & (xblk - 1);
-      const int w1 = s0[1] + j*dsdj[1] + i*(dsdi[1] + j*dd[1]);
-      const int w2 = s0[2] + j*dsdj[2] + i*(dsdi[2] + j*dd[2]);
-      const int w3 = s0[3] + j*dsdj[3] + i*(dsdi[3] + j*dd[3]);
-      const int av = p0[e];
-      const int bv = (p1[e] - av)*w1, cv = (p2[e] - av)*w2, dv = (p3[e] - av)*w3;
-      d[(size_t)j*a.dst_stride + i] = (uint8_t)(((av << (l2 + 1)) + bv + cv + dv + round) >> (l2 + 1));
-    }
   }
+  __device__ __forceinline__ int value(int v0, int v1, int v2, int v3, int i, int j) const {
+    if (full) {
+      int av = v0, bv = v3;
+      av = (av << lx) + (v1 - av)*i;
+      bv = (bv << lx) + (v2 - bv)*i;
+      return ((av << ly) + (bv - av)*j + (1 << (l2 - 1))) >> l2;
+    }
+    const int w1 = s0[1] + j*dsdj[1] + i*(dsdi[1] + j*dd[1]);
+    const int w2 = s0[2] + j*dsdj[2] + i*(dsdi[2] + j*dd[2]);
+    const int w3 = s0[3] + j*dsdj[3] + i*(dsdi[3] + j*dd[3]);
+    return ((v0 << (l2 + 1)) + (v1 - v0)*w1 + (v2 - v0)*w2 + (v3 - v0)*w3 + (1 << l2)) >> (l2 + 1);
+  }
+};
+
+#define MC_THREADS 128
+__global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
+  __shared__ int16_t buff[(64 + 5)*64];
+  __shared__ uint8_t pred[4*4096];
+  const int lane = threadIdx.x;
+  const int bidx = blockIdx.x;
+  if (bidx >= a.nblocks) return;
+  const McBlock blk = a.blocks[bidx];
+  const int lx = blk.log_xblk_sz, ly = blk.log_yblk_sz;
+  const int xblk = 1 << lx, npix = xblk << ly;
+  McPlaneRef R;
+  R.refs = a.refs;
+  R.ref_plane = a.ref_plane;
+  R.ref_stride = a.ref_stride;
+  R.ref_h = a.ref_h;
+  R.org_x = a.org_x;
+  R.org_y = a.org_y;
+  int alias[4];
+  mc_predict_corners<MC_THREADS>(R, blk.x, blk.y, lx, ly, blk.ref, blk.mvx, blk.mvy, buff, pred, alias, lane);
+  const uint8_t *p0 = pred + alias[0]*4096, *p1 = pred + alias[1]*4096, *p2 = pred + alias[2]*4096,
+                *p3 = pred + alias[3]*4096;
+  uint8_t *d = a.dst + (size_t)blk.y*a.dst_stride + blk.x;
+  McBlend W;
+  W.setup(lx, ly, blk.oc, blk.s);
+  for (int e = lane; e < npix; e += MC_THREADS) {
+    const int j = e >> lx, i = e & (xblk - 1);
+    d[(size_t)j*a.dst_stride + i] = (uint8_t)W.value(p0[e], p1[e], p2[e], p3[e], i, j);
+  }
+}
+
+// F3, second half: the OBMC prediction of a block FUSED with its SAD against the frame being
+// coded - od_mv_est_sad (src/mcenc.c:2271-2300): od_state_pred_block_from_setup (src/state.c:689)
+// of every plane + od_enc_sad (:1615, the block clipped against the picture) with the chroma sums
+// scaled down by OD_MC_CHROMA_SCALE (:53).  The prediction never leaves LDS.  One item = one
+// (block, exterior corner, split state) with the four corner vectors in luma units; chroma
+// vectors and positions are derived here (OD_DIV_POW2_RE, src/odintrin.h:142).  One WAVE per
+// item (no workgroup barrier is ever waited on by a second wave), planes in turn.  What
+// od_mv_est_calc_sads (:3761) computes block by block for a fixed vector grid - every block of
+// two sizes x four split states - is one launch.
+struct McSadItem {        // == od_hip_mc_sad_item (include/daala_hip.h)
+  int32_t x, y;           // luma position
+  int32_t log_blk_sz;     // luma log2 size, 3 .. 6
+  int32_t oc, s;
+  int32_t ref[4];
+  int32_t mvx[4], mvy[4];
+  int32_t reserved;
+};
+
+struct McSadPlane {
+  McPlaneRef R;
+  const uint8_t *src;     // the frame being coded, src_stride bytes per row
+  int src_stride;
+  int xdec, ydec;
+  int clip_w, clip_h;     // picture size in this plane's samples (od_enc_sad's clip)
+  int shift;              // 0 for luma, OD_MC_CHROMA_SCALE for chroma
+};
+
+struct McSadArgs {
+  McSadPlane pl[3];
+  int nplanes;
+  const McSadItem *items;
+  int nitems;
+  int32_t *sad;
+};
+
+__device__ __forceinline__ int mc_div_pow2_re(int x, int shift) {
+  return (x + (((1 << shift) + ((x >> shift) & 1) - 1) >> 1)) >> shift;
+}
+
+#define MC_SAD_THREADS 64
+__global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_sad_items(McSadArgs a) {
+  __shared__ int16_t buff[(64 + 5)*64];
+  __shared__ uint8_t pred[4*4096];
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x;
+  if (idx >= a.nitems) return;
+  const McSadItem it = a.items[idx];
+  int total = 0;
+  for (int pli = 0; pli < a.nplanes; pli++) {
+    const McSadPlane &P = a.pl[pli];
+    const int lx = it.log_blk_sz - P.xdec, ly = it.log_blk_sz - P.ydec;
+    const int bx = it.x >> P.xdec, by = it.y >> P.ydec;
+    const int xblk = 1 << lx, yblk = 1 << ly, npix = xblk*yblk;
+    int32_t cmvx[4], cmvy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      cmvx[k] = mc_div_pow2_re(it.mvx[k], P.xdec);
+      cmvy[k] = mc_div_pow2_re(it.mvy[k], P.ydec);
+    }
+    int alias[4];
+    mc_predict_corners<MC_SAD_THREADS>(P.R, bx, by, lx, ly, it.ref, cmvx, cmvy, buff, pred, alias, lane);
+    const uint8_t *p0 = pred + alias[0]*4096, *p1 = pred + alias[1]*4096, *p2 = pred + alias[2]*4096,
+                  *p3 = pred + alias[3]*4096;
+    McBlend W;
+    W.setup(lx, ly, it.oc, it.s);
+    const int w = min(xblk, P.clip_w - bx), h = min(yblk, P.clip_h - by);
+    const uint8_t *src = P.src + (size_t)by*P.src_stride + bx;
+    int acc = 0;
+    for (int e = lane; e < npix; e += MC_SAD_THREADS) {
+      const int j = e >> lx, i = e & (xblk - 1);
+      if (i < w && j < h) {
+        const int v = W.value(p0[e], p1[e], p2[e], p3[e], i, j) & 255;     // the (unsigned char) store of the blend
+        acc += abs(v - (int)src[(size_t)j*P.src_stride + i]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    total += acc >> P.shift;
+    __syncthreads();                                   // the tiles are rewritten by the next plane
+  }
+  if (lane == 0) a.sad[idx] = total;
 }

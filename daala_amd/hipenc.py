@@ -61,13 +61,15 @@ class Stats(ctypes.Structure):
                 ('pfeed_frames', ctypes.c_int64), ('t_pfeed_s', ctypes.c_double),
                 ('rate_s', ctypes.c_double), ('rate_state_free_s', ctypes.c_double),
                 ('rate_calls', ctypes.c_int64), ('frame_cpu_s', ctypes.c_double), ('pre_mc_s', ctypes.c_double),
+                ('mv_stage_s', ctypes.c_double*8),
+                ('mv_dev_calls', ctypes.c_int64), ('mv_dev_sads', ctypes.c_int64), ('mv_dev_wait_s', ctypes.c_double), ('mv_check_fail', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_compand_s', ctypes.c_double),
                 ('t_total_s', ctypes.c_double), ('pkt_bytes_needed', ctypes.c_int64)]
 
     def as_dict(self):
-        return {k: (list(getattr(self, k)) if k == 'search_class_s' else getattr(self, k))
+        return {k: (list(getattr(self, k)) if k in ('search_class_s', 'mv_stage_s') else getattr(self, k))
                 for k, _ in self._fields_}
 
 

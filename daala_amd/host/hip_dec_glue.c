@@ -1183,26 +1183,17 @@ static int mc_collect(od_state *state, mc_list *L, int pli, int xdec, int ydec, 
   }
 }
 
-static int mc_predict_device(od_state *state, od_img *img_dst) {
-  mc_list L;
-  int pli;
+/* The thread's prediction object with every reference image the vector grid can name resident
+   and current: an image is uploaded when it changed since its last upload (src/state.c:236-300:
+   OD_BUFFER_PADDING >> dec samples of padding on every side of the frame).  img_dst: the image
+   about to be predicted into (this frame's SELF: rewritten, never read as a reference), or NULL. */
+static int mc_refresh_refs(od_state *state, od_img *img_dst, int nplanes) {
   int rc;
   int k;
-  int dev;
-  int to_ctx;
+  int pli;
   rc = 0;
-  memset(&L, 0, sizeof(L));
-  if (state->full_precision_references) return -1;
-  /* A decoder thread's prediction has one consumer, the forward pyramid of the thread's
-     context (md_pyramid): it is predicted straight into the context's picture planes and never
-     visits the host - unless somebody wants to look at it (check mode, user_mc_img). */
-  to_ctx = D.ctx != NULL && D.dec != NULL && state == &D.dec->state && !D.check
-   && D.dec->user_mc_img == NULL && img_dst->nplanes == 3 && state->frame_type == OD_P_FRAME
-   && state->quantizer[0] > 0;
-  D.pred_on_device = 0;
   if (D.mc == NULL) {
-    dev = D.device;
-    D.mc = od_hip_mc_create(dev, OD_FRAME_MAX + 1);
+    D.mc = od_hip_mc_create(D.device, OD_FRAME_MAX + 1);
     if (D.mc == NULL) return -1;
     D.mc_state = NULL;
   }
@@ -1210,20 +1201,16 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
     D.mc_state = state;
     memset(D.mc_dirty, 1, sizeof(D.mc_dirty));
   }
-  /* the image being predicted into is this frame's SELF: rewritten, and never read as a
-     reference of this frame */
-  if (img_dst >= state->ref_imgs && img_dst <= state->ref_imgs + OD_FRAME_MAX) {
+  if (img_dst != NULL && img_dst >= state->ref_imgs && img_dst <= state->ref_imgs + OD_FRAME_MAX) {
     D.mc_dirty[img_dst - state->ref_imgs] = 1;
   }
-  /* reference images that changed since their upload (src/state.c:236-300: OD_BUFFER_PADDING
-     >> dec samples of padding on every side of the frame) */
   for (k = 0; k <= OD_FRAME_MAX && rc == 0; k++) {
     int used;
     int t;
     used = 0;
     for (t = 0; t < OD_FRAME_MAX + 1; t++) used |= state->ref_imgi[t] == k && t != OD_FRAME_SELF;
     if (!used || !D.mc_dirty[k] || state->ref_imgs + k == img_dst) continue;
-    for (pli = 0; pli < img_dst->nplanes && rc == 0; pli++) {
+    for (pli = 0; pli < nplanes && rc == 0; pli++) {
       const od_img_plane *rp;
       int px;
       int py;
@@ -1235,6 +1222,58 @@ static int mc_predict_device(od_state *state, od_img *img_dst) {
     }
     if (rc == 0) D.mc_dirty[k] = 0;
   }
+  return rc;
+}
+
+/* The batch stages of the encoder's motion search (mcenc_tail.c: od_mv_est_calc_sads): the SAD
+   of the OBMC prediction of every item against the frame being coded, on this thread's
+   prediction object.  Returns 1 when sad[] was written by the device, 0 when this thread has no
+   device (the caller runs the reference's loop), < 0 when a device stage failed (the frame
+   fails, like a failed od_state_mc_predict). */
+int od_hipdec_mc_sad_items(od_state *state, const od_img *input, int nplanes,
+ const od_hip_mc_sad_item *items, int nitems, int32_t *sad) {
+  int pli;
+  int rc;
+  if (!od_hipenc_device_thread() || D.failed) return 0;
+  if (state->full_precision_references || nplanes < 1 || nplanes > 3 || input->nplanes < nplanes) return 0;
+  for (pli = 0; pli < nplanes; pli++) {
+    if (input->planes[pli].xstride != 1 || input->planes[pli].xdec > 1 || input->planes[pli].ydec > 1) return 0;
+  }
+  if (injected_failure()) rc = -1;
+  else rc = mc_refresh_refs(state, NULL, nplanes);
+  for (pli = 0; pli < nplanes && rc == 0; pli++) {
+    const od_img_plane *ip;
+    ip = input->planes + pli;
+    rc = od_hip_mc_set_src(D.mc, pli, ip->data, ip->ystride, state->frame_width >> ip->xdec,
+     state->frame_height >> ip->ydec, ip->xdec, ip->ydec);
+  }
+  if (rc == 0) {
+    rc = od_hip_mc_sad_items(D.mc, nplanes, state->info.pic_width, state->info.pic_height, items, nitems, sad);
+  }
+  if (rc != 0) {
+    D.failed = 1;
+    stage_failed("motion search SADs", rc);
+    return -1;
+  }
+  return 1;
+}
+
+static int mc_predict_device(od_state *state, od_img *img_dst) {
+  mc_list L;
+  int pli;
+  int rc;
+  int to_ctx;
+  rc = 0;
+  memset(&L, 0, sizeof(L));
+  if (state->full_precision_references) return -1;
+  /* A decoder thread's prediction has one consumer, the forward pyramid of the thread's
+     context (md_pyramid): it is predicted straight into the context's picture planes and never
+     visits the host - unless somebody wants to look at it (check mode, user_mc_img). */
+  to_ctx = D.ctx != NULL && D.dec != NULL && state == &D.dec->state && !D.check
+   && D.dec->user_mc_img == NULL && img_dst->nplanes == 3 && state->frame_type == OD_P_FRAME
+   && state->quantizer[0] > 0;
+  D.pred_on_device = 0;
+  rc = mc_refresh_refs(state, img_dst, img_dst->nplanes);
   for (pli = 0; pli < img_dst->nplanes && rc == 0; pli++) {
     od_img_plane *dp;
     int xdec;

@@ -384,6 +384,38 @@ int od_hipenc_pframe_feed(od_state *state, od_img *pred) {
   return 1;
 }
 
+/* The batch stage of od_mv_est (mcenc_tail.c: od_mv_est_calc_sads): every block SAD of the
+   fixed vector grid in one device call on this worker's prediction object (hip_dec_glue.c).
+   1: sad[] written; 0: no device on this thread, the reference's loop runs; < 0: failed frame. */
+int od_hipdec_mc_sad_items(od_state *state, const od_img *input, int nplanes,
+ const od_hip_mc_sad_item *items, int nitems, int32_t *sad);
+static int mv_dev_sads = 1;       /* HIPENC_MV_SADS=0: leave od_mv_est_calc_sads on the host */
+
+int od_hipenc_mv_sad_items(daala_enc_ctx *enc, int nplanes, const od_hip_mc_sad_item *items,
+ int nitems, int32_t *sad) {
+  double t0;
+  int rc;
+  if (!mv_dev_sads || enc == NULL || enc != T.enc) return 0;
+  t0 = now_s();
+  rc = od_hipdec_mc_sad_items(&enc->state, enc->input_img + enc->curr_frame, nplanes, items, nitems, sad);
+  if (rc > 0) {
+    T.st.mv_dev_calls++;
+    T.st.mv_dev_sads += nitems;
+    T.st.mv_dev_wait_s += now_s() - t0;
+  }
+  return rc;
+}
+
+/* check mode: the reference's loop ran beside the device call and its sad_cache differs */
+void od_hipenc_mv_check_fail(long n) {
+  T.st.mv_check_fail += n;
+}
+
+/* stage timers of od_mv_est (mcenc_tail.c) */
+void od_hipenc_mv_stage(int stage, double seconds) {
+  if (stage >= 0 && stage < 8) T.st.mv_stage_s[stage] += seconds;
+}
+
 #define FDCT_MIN_BS_DEFAULT (1)     /* 4x4 blocks: four cache misses cost more than the transform */
 
 /* fdct_2d entries of the worker's vtable (struct od_state_opt_vtbl, src/state.h:106).
@@ -508,6 +540,7 @@ void od_haar_cpu(od_coeff *y, int ystride, const od_coeff *x, int xstride, int l
 void od_hipdec_haar_notify(void);        /* hip_dec_glue.c */
 int od_hipdec_take_failure(void);
 void od_hipdec_thread_cleanup(void);
+void od_hipenc_mv_thread_cleanup(void);   /* mcenc_tail.c */
 void od_hipdec_set_device(int device);
 
 void od_haar(od_coeff *y, int ystride, const od_coeff *x, int xstride, int ln) {
@@ -773,6 +806,14 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
   a->rate_calls += b->rate_calls;
   a->frame_cpu_s += b->frame_cpu_s;
   a->pre_mc_s += b->pre_mc_s;
+  {
+    int i;
+    for (i = 0; i < 8; i++) a->mv_stage_s[i] += b->mv_stage_s[i];
+    a->mv_dev_calls += b->mv_dev_calls;
+    a->mv_dev_sads += b->mv_dev_sads;
+    a->mv_dev_wait_s += b->mv_dev_wait_s;
+    a->mv_check_fail += b->mv_check_fail;
+  }
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
 
@@ -1058,6 +1099,7 @@ static void *worker(void *arg) {
   if (enc != NULL) daala_encode_free(enc);
   od_hipenc_mc_cache_free();             /* this thread's prediction cache (hip_mc_host.c) */
   od_hipdec_thread_cleanup();            /* its resident motion-compensation object (hip_dec_glue.c) */
+  od_hipenc_mv_thread_cleanup();         /* the item list of the motion search's batch stage */
   return NULL;
 }
 
@@ -1113,6 +1155,8 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     S->pfeed_on = e == NULL || atoi(e) != 0;
     e = getenv("HIPENC_PF_THREADS");
     if (e != NULL) pf_helpers = atoi(e);
+    e = getenv("HIPENC_MV_SADS");
+    mv_dev_sads = e == NULL || atoi(e) != 0;
   }
   S->use_device = use_device;
   S->device = device;

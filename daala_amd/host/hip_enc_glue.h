@@ -53,6 +53,13 @@ typedef struct od_hipenc_stats {
   int64_t rate_calls;
   double frame_cpu_s;      /* inside daala_encode_img_in + packet_out, all frames */
   double pre_mc_s;         /* P frames: frame start -> od_state_mc_predict (input copy + od_mv_est) */
+  double mv_stage_s[8];    /* od_mv_est by stage (always on; mcenc_tail.c): EPZS initialisation of the previous
+                              reference, of the golden/next one, od_mv_est_calc_sads, the rest of od_mv_est_init_dus,
+                              the decimation loop, the refinement loop, sub-pel refinement, the whole od_mv_est */
+  int64_t mv_dev_calls;    /* batched OBMC + SAD passes of the motion search answered by the device */
+  int64_t mv_dev_sads;     /* block SADs in them */
+  double mv_dev_wait_s;    /* seconds the coding thread spent in those calls */
+  int64_t mv_check_fail;   /* check mode: device SAD != the reference's od_mv_est_calc_sads (must be 0) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* upload done -> device batch enqueued (includes t_compand_s), wall */

@@ -572,6 +572,32 @@ int od_hip_mc_predict(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int
 int od_hip_mc_predict_ctx(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int nblocks,
  od_hip_ctx *ctx, int slot);
 
+/* F3, second half: batched OBMC prediction + SAD for the motion search.  What
+ * od_mv_est_sad (src/mcenc.c:2271-2300) computes for one block - od_state_pred_block_from_setup
+ * (src/state.c:689) of every plane, od_enc_sad (src/mcenc.c:1615: the block clipped against the
+ * picture) with the chroma sums >> OD_MC_CHROMA_SCALE (:53) - for a whole list of (block,
+ * exterior corner, split state) items against the references resident in the object: the batch
+ * stages of od_mv_est, where the vector grid stands still - od_mv_est_calc_sads (:3761: every
+ * block of two sizes x four split states) and the top-level blocks of od_mv_est_init_du (:3953).
+ *   x, y, log_blk_sz: luma position and log2 size (3..6); mvx/mvy: the four corner vectors in
+ *   luma 1/8-sample units as the grid holds them (chroma vectors: OD_DIV_POW2_RE on the device);
+ *   ref[k]: index into the object's reference images; oc, s as od_mc_predict (src/mc.c:2006).
+ * od_hip_mc_set_src uploads plane pli of the frame being coded (w x h samples, the padded input
+ * plane; xdec/ydec: its decimation); od_hip_mc_sad_items writes sad[i] for every item, planes
+ * 0..nplanes-1 summed.  pic_w/pic_h: the luma picture size the SAD is clipped to. */
+typedef struct od_hip_mc_sad_item {
+  int32_t x, y;
+  int32_t log_blk_sz;
+  int32_t oc, s;
+  int32_t ref[4];
+  int32_t mvx[4], mvy[4];
+  int32_t reserved;
+} od_hip_mc_sad_item;
+int od_hip_mc_set_src(od_hip_mc *mc, int pli, const unsigned char *plane, int stride, int w, int h,
+ int xdec, int ydec);
+int od_hip_mc_sad_items(od_hip_mc *mc, int nplanes, int pic_w, int pic_h,
+ const od_hip_mc_sad_item *items, int nitems, int32_t *sad);
+
 /* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
  * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks
  * (n = 4 << bs).  dst is in/out: entries the permutation does not write (a 32x32 block

@@ -1457,6 +1457,130 @@ void orc_mc_predict(uint8_t *dst, int dystride, const uint8_t *const src[4], int
 }
 
 /* ---------------------------------------------------------------------------------
+ * F3: the batch stages of the motion search.  od_mv_est_sad (src/mcenc.c:2271-2300) of one
+ * (block, exterior corner, split state): od_state_pred_block_from_setup (src/state.c:689-734)
+ * of every plane - corner vectors scaled with OD_DIV_POW2_RE (src/odintrin.h:142) - and
+ * od_enc_sad (src/mcenc.c:1615-1681: the block clipped against the picture), chroma sums
+ * >> OD_MC_CHROMA_SCALE (:53).  An item carries what the reference reads from the vector grid.
+ * Layout == od_hip_mc_sad_item (include/daala_hip.h). */
+typedef struct orc_sad_item {
+  int32_t x, y, log_blk_sz, oc, s;
+  int32_t ref[4];
+  int32_t mvx[4], mvy[4];
+  int32_t reserved;
+} orc_sad_item;
+
+static int orc_div_pow2_re(int x, int shift) {
+  return (x + (((1 << shift) + ((x >> shift) & 1) - 1) >> 1)) >> shift;
+}
+
+/* refs[pli]: nref reference planes of ref_h[pli] x ref_stride[pli] bytes, back to back, the
+   picture origin at (org_x[pli], org_y[pli]); src[pli]: the frame being coded, src_stride[pli]
+   bytes per row. */
+void orc_mv_est_sad_items(const orc_sad_item *items, int nitems, int nplanes,
+ const uint8_t *const refs[3], const int32_t *ref_stride, const int32_t *ref_h,
+ const int32_t *org_x, const int32_t *org_y, const uint8_t *const src[3],
+ const int32_t *src_stride, const int32_t *xdec, const int32_t *ydec, int pic_w, int pic_h,
+ int32_t *sad) {
+  static __thread uint8_t pred[64*64];
+  int n;
+  for (n = 0; n < nitems; n++) {
+    const orc_sad_item *it = items + n;
+    int32_t total = 0;
+    int pli;
+    for (pli = 0; pli < nplanes; pli++) {
+      const uint8_t *at[4];
+      int32_t mvx[4], mvy[4];
+      int lx = it->log_blk_sz - xdec[pli], ly = it->log_blk_sz - ydec[pli];
+      int bx = it->x >> xdec[pli], by = it->y >> ydec[pli];
+      int w = 1 << lx, h = 1 << ly;
+      int clipw = ((pic_w + (1 << xdec[pli]) - 1) >> xdec[pli]) - bx;
+      int cliph = ((pic_h + (1 << ydec[pli]) - 1) >> ydec[pli]) - by;
+      int32_t acc = 0;
+      int i, j, k;
+      for (k = 0; k < 4; k++) {
+        mvx[k] = orc_div_pow2_re(it->mvx[k], xdec[pli]);
+        mvy[k] = orc_div_pow2_re(it->mvy[k], ydec[pli]);
+        at[k] = refs[pli] + (size_t)it->ref[k]*ref_stride[pli]*ref_h[pli]
+         + (size_t)(org_y[pli] + by)*ref_stride[pli] + org_x[pli] + bx;
+      }
+      orc_mc_predict(pred, w, at, ref_stride[pli], mvx, mvy, it->oc, it->s, lx, ly);
+      if (clipw < w) w = clipw;
+      if (cliph < h) h = cliph;
+      for (j = 0; j < h; j++) {
+        for (i = 0; i < w; i++) {
+          acc += abs((int)pred[(j << lx) + i] - (int)src[pli][(size_t)(by + j)*src_stride[pli] + bx + i]);
+        }
+      }
+      total += pli > 0 ? acc >> 2 : acc;
+    }
+    sad[n] = total;
+  }
+}
+
+/* OD_VERT_D / OD_VERT_SETUP_DX / OD_VERT_SETUP_DY (src/state.c:645-687): the grid offsets, in
+   units of the block size, of the four vectors a block is predicted from, by exterior corner
+   and split state. */
+static const int ORC_VERT_D[22] = {0, 0, 1, 1, 0, 0, 1, 2, 0, 0, 2, 1, 0, -1, 1, 1, 0, -1, 0, 1, 1, -1};
+static const int ORC_SETUP_DX[4][4] = {{9, 1, 9, 1}, {13, 13, 1, 1}, {18, 1, 18, 1}, {5, 5, 1, 1}};
+static const int ORC_SETUP_DY[4][4] = {{4, 4, 0, 0}, {8, 0, 8, 0}, {12, 12, 0, 0}, {17, 0, 17, 0}};
+
+/* One item from the grid: what od_state_pred_block_from_setup reads (P frames: mv, ref).
+   gmvx/gmvy/gref: (nvmvbs + 1) x (nhmvbs + 1), gref already mapped to an image index. */
+static void orc_mv_est_item(orc_sad_item *it, int nhmvbs, const int32_t *gmvx, const int32_t *gmvy,
+ const int32_t *gref, int vx, int vy, int oc, int s, int log_mvb_sz) {
+  const int *dxp = ORC_VERT_D + ORC_SETUP_DX[oc][s];
+  const int *dyp = ORC_VERT_D + ORC_SETUP_DY[oc][s];
+  int k;
+  memset(it, 0, sizeof(*it));
+  it->x = vx << 3;                  /* OD_LOG_MVBSIZE_MIN (src/internal.h:67) */
+  it->y = vy << 3;
+  it->log_blk_sz = log_mvb_sz + 3;
+  it->oc = oc;
+  it->s = s;
+  for (k = 0; k < 4; k++) {
+    int g = (vy + dyp[k]*(1 << log_mvb_sz))*(nhmvbs + 1) + vx + dxp[k]*(1 << log_mvb_sz);
+    it->mvx[k] = gmvx[g];
+    it->mvy[k] = gmvy[g];
+    it->ref[k] = gref[g];
+  }
+}
+
+/* od_mv_est_calc_sads (src/mcenc.c:3761-3823), the SAD part: for every block size the level
+   limits admit, every block, split states 0 .. smax - 1, in the reference's loop order.  Writes
+   the items; sizes[l] receives the number of items of log_mvb_sz l (0 when the size is not
+   evaluated), smax_out[l] its smax.  Returns the item count (items may be NULL to count). */
+int orc_mv_est_calc_sads_items(int nhmvbs, int nvmvbs, int level_min, int level_max,
+ const int32_t *gmvx, const int32_t *gmvy, const int32_t *gref, orc_sad_item *items,
+ int32_t *sizes, int32_t *smax_out) {
+  int n = 0;
+  int nh = nhmvbs, nv = nvmvbs;
+  int l;
+  for (l = 0; l < 3; l++) {         /* OD_LOG_MVB_DELTA0 (src/internal.h:87) */
+    sizes[l] = 0;
+    smax_out[l] = 0;
+    if (level_max >= 6 - 1 - 2*l && level_min <= 6 - 2*l) {     /* OD_MC_LEVEL_MAX = 6 */
+      int smax = level_max >= 6 - 2*l ? 4 : 1;
+      int vx, vy, s;
+      smax_out[l] = smax;
+      for (vy = 0; vy < nv; vy++) {
+        for (vx = 0; vx < nh; vx++) {
+          int oc = (vx & 1) ^ ((vy & 1) << 1 | (vy & 1));
+          for (s = 0; s < smax; s++) {
+            if (items != NULL) orc_mv_est_item(items + n, nhmvbs, gmvx, gmvy, gref, vx << l, vy << l, oc, s, l);
+            n++;
+            sizes[l]++;
+          }
+        }
+      }
+    }
+    nh >>= 1;
+    nv >>= 1;
+  }
+  return n;
+}
+
+/* ---------------------------------------------------------------------------------
  * F3: SAD and SATD of a block pair (the C entries of od_enc_opt_vtbl, src/encint.h:61-82).
  * orc_mc_sad8: sum |ref - src| over the block (od_mc_compute_sad8_c, src/mcenc.c:1333-1347).
  * orc_mc_satd8: od_mc_compute_satd8 (src/mcenc.c:1464-1489): difference block, n-point

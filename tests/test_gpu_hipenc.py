@@ -32,6 +32,18 @@ def reference_packets(buf, w, h, nf, masking):
     return H.split_packets(out, nf)
 
 
+def ref_encode(w, h, buf, nf, keyrate, quant=20):
+    """Packets of the PURE reference encoder (oracle/_ref/enc_probe.so) for an inter stream."""
+    lib = ref('enc_probe')
+    lib.probe_encode_frames.restype = ctypes.c_long
+    out = np.zeros(max(1 << 22, buf.size), np.uint8)
+    fnv, sec = ctypes.c_uint(), ctypes.c_double()
+    n = lib.probe_encode_frames(w, h, nf, quant, 7, 1, keyrate, pu8(buf), ctypes.byref(fnv),
+                                ctypes.byref(sec), pu8(out), out.size)
+    assert n > 0
+    return H.split_packets(out, nf)
+
+
 @pytest.mark.parametrize('masking', [1, 0])
 def test_device_feed_equals_oracle_feed(masking):
     import daala_amd.binding as b
@@ -398,6 +410,9 @@ def test_inter_stream_encoded_through_the_seam():
     # the P frames' bands took the complete candidate lists of the P-frame feed (4d): in check
     # mode every candidate taken from it was searched again on the host and compared
     assert st.pfeed_frames == 3 and st.resampled > 1000
+    # od_mv_est_calc_sads of every P frame came from the device (one fused OBMC + SAD call per
+    # frame); in check mode the reference's own loop ran beside it on the same grid
+    assert st.mv_dev_calls == 3 and st.mv_dev_sads > 0 and st.mv_check_fail == 0
 
 
 def test_inter_stream_1080p_pframe_feed_packets_identical():
@@ -418,11 +433,45 @@ def test_inter_stream_1080p_pframe_feed_packets_identical():
     n, pk, st = H.encode(prm, buf, nf, use_device=1)
     assert n > 0 and pk == want
     assert st.pfeed_frames == 2 and st.lost_sync == st1.lost_sync
+    assert st.mv_dev_calls == 2 and st.mv_dev_sads == 2*4*(240*135 + 120*67)
     host_p = (st.cpu_other + st.cpu_noref_luma) - (st1.cpu_other + st1.cpu_noref_luma)
     dev_p = st.dev_hits - st1.dev_hits
     print('1080p I P P: P-frame searches from the feed %d, on the host %d; feed wait %.3f s; total %.2f s'
           % (dev_p, host_p, st.t_pfeed_s, st.t_total_s))
     assert host_p < 0.1*(host_p + dev_p)
+
+
+def test_inter_gop_golden_frames_and_second_keyframe():
+    """configs[3] over a whole GOP and beyond: 33 frames of 176x144, keyframe rate 30, one worker,
+    check mode.  The stream crosses the golden P frames 10 and 20 (ip_frame_count % 10 == 0,
+    src/encode.c:2958-2963: quantizer boost, the golden reference is replaced -> the resident
+    reference set's dirty marking), the second keyframe (frame 30) and the first P frames after
+    it (whose EPZS candidates still hold the previous GOP's vectors, src/mcenc.c:2757-2762).
+    Encoder seam: packets == the pure reference encoder's, every check counter 0; decoder seam
+    (check mode too): pictures == the reference decoder's for every frame."""
+    from test_hipenc_cpu import inter_stream_frames
+    w, h, nf = 176, 144, 33
+    buf = inter_stream_frames(w, h, nf)
+    want = ref_encode(w, h, buf, nf, keyrate=30)
+    prm = H.Params(w, h, 20, 7, 1, 1, 1, 0, 30)
+    n, pk, st = H.encode(prm, buf, nf, use_device=1)
+    assert n > 0
+    bad = [f for f in range(nf) if pk[f] != want[f]]
+    assert not bad, bad
+    assert st.pvq_check_fail == 0 and st.check_fail == 0 and st.fdct_check_fail == 0
+    assert st.dering_check_fail == 0 and st.dist_check_fail == 0 and st.mv_check_fail == 0
+    assert st.pfeed_frames == nf - 2 and st.mv_dev_calls == nf - 2
+    hdr = H.headers(prm)
+    n0, pics0, _, _ = H.decode(prm, hdr, want, use_device=0)
+    n1, pics1, _, _ = H.decode(prm, hdr, want, use_device=1)
+    assert n0 == nf and n1 == nf
+    diff = [f for f in range(nf) if not np.array_equal(pics0[f], pics1[f])]
+    assert not diff, diff
+    frames, mism = H.mc_stats()
+    assert frames == nf - 2 and mism == 0
+    done, smis = H.synth_stats()
+    assert smis == 0
+    assert H.tail_frames() == nf
 
 
 def test_haar_frames_with_a_quantizer_decode_on_the_host_path(monkeypatch):

@@ -634,6 +634,67 @@ def test_obmc_prediction_blocks(hip):
     assert np.array_equal(got, want)
 
 
+def test_mvest_calc_sads_fused_obmc_sad(hip):
+    """F3, second half: od_hip_mc_sad_items (k_mc_sad_items: OBMC prediction of every plane fused
+    with the clipped SAD, one wave per item, nothing written but the sums) against sad_cache as the
+    REAL od_mv_est_calc_sads wrote it inside a reference encoder (tests/golden/mvest_sads.npz) and
+    against the oracle on a random item list: all four block sizes, every (oc, s), one to three
+    references, vectors that reach into the padding, picture sizes that clip blocks, luma only and
+    three planes."""
+    from testlib import mvest_items, mvest_oracle_sads, mvest_split, SAD_ITEM
+    g = golden('mvest_sads.npz')
+    o = oracle()
+    dims = g['dims']
+    items, sizes, smax = mvest_items(o, g)
+    refs = [g['refs%d' % p] for p in range(3)]
+    src = [g['src%d' % p] for p in range(3)]
+    ox = [int(dims[9 + 4*p]) for p in range(3)]
+    oy = [int(dims[10 + 4*p]) for p in range(3)]
+    mc = hip.McSad(refs, ox, oy, src, [(0, 0), (1, 1), (1, 1)])
+    got = mvest_split(mc.sad_items(items, int(g['pic'][0]), int(g['pic'][1])), sizes, smax, dims)
+    assert np.array_equal(got[1], g['sad1']) and np.array_equal(got[2], g['sad2'])
+    # random items vs the oracle
+    rng = np.random.default_rng(31)
+    fw, fh = src[0].shape[1], src[0].shape[0]
+    nimg = refs[0].shape[0]
+    for pic_w, pic_h, nplanes in ((int(g['pic'][0]), int(g['pic'][1]), 3), (fw - 21, fh - 37, 3), (fw, fh, 1)):
+        it = np.zeros(700, SAD_ITEM)
+        for i in range(len(it)):
+            lg = int(rng.integers(3, 7))
+            n = 1 << lg
+            it[i]['log_blk_sz'] = lg
+            it[i]['x'] = int(rng.integers(0, (fw - n)//8 + 1))*8
+            it[i]['y'] = int(rng.integers(0, (fh - n)//8 + 1))*8
+            it[i]['oc'], it[i]['s'] = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            one = rng.random() < .3
+            it[i]['ref'] = int(rng.integers(0, nimg)) if one else rng.integers(0, nimg, size=4)
+            reach = 8*(ox[0] - 8)
+            it[i]['mvx'] = rng.integers(-reach, reach, size=4)
+            it[i]['mvy'] = rng.integers(-reach, reach, size=4)
+            if rng.random() < .25:
+                it[i]['mvx'] &= ~7
+            if rng.random() < .25:
+                it[i]['mvy'] &= ~7
+            if rng.random() < .2:
+                it[i]['mvx'] = it[i]['mvx'][0]
+                it[i]['mvy'] = it[i]['mvy'][0]
+        gg = dict(g)
+        gg['pic'] = np.array([pic_w, pic_h], np.int32)
+        want = mvest_oracle_sads(o, gg, it, nplanes)
+        got = mc.sad_items(it, pic_w, pic_h, nplanes)
+        assert np.array_equal(got, want), (pic_w, pic_h, nplanes, np.flatnonzero(got != want)[:5])
+    # bad operands are refused before anything is launched
+    bad = it[:1].copy()
+    bad[0]['x'] = fw
+    with pytest.raises(hip.HipError):
+        mc.sad_items(bad, fw, fh)
+    bad = it[:1].copy()
+    bad[0]['ref'][2] = nimg
+    with pytest.raises(hip.HipError):
+        mc.sad_items(bad, fw, fh)
+    mc.close()
+
+
 def test_superblock_row_strips_in_c_equal_the_full_frame(hip):
     """SURVEY 8e in C: od_hip_set_strip restricts the forward pyramid and the PVQ passes to a
     strip of superblock rows (the kernels read their lapping halo from the pixels: no halo

@@ -243,3 +243,17 @@ def test_sad_satd_pairs_golden():
         got.append(f(ctypes.cast(src.ctypes.data + int(sy)*W + int(sx), U8P), W,
                      ctypes.cast(rf.ctypes.data + int(ry)*W + int(rx), U8P), W, int(lg)))
     assert np.array_equal(np.array(got, np.int32), g['out'])
+
+
+def test_mvest_calc_sads_golden():
+    """F3, second half: the oracle's od_mv_est_calc_sads (grid -> items -> OBMC of every plane +
+    clipped SAD, chroma scaled) against sad_cache as the REAL od_mv_est_calc_sads wrote it inside a
+    reference encoder (tests/golden/mvest_sads.npz, oracle/ref_probe/mcenc_probe.c)."""
+    from testlib import mvest_items, mvest_oracle_sads, mvest_split
+    g = load('mvest_sads.npz')
+    o = oracle()
+    items, sizes, smax = mvest_items(o, g)
+    assert list(sizes) == [0, g['sad1'].size, g['sad2'].size] and list(smax) == [0, 4, 4]
+    got = mvest_split(mvest_oracle_sads(o, g, items), sizes, smax, g['dims'])
+    assert np.array_equal(got[1], g['sad1']) and np.array_equal(got[2], g['sad2'])
+    assert g['sad1'].max() > 0

@@ -489,3 +489,42 @@ def test_sad_satd_match_reference():
             g.restype = ctypes.c_int32
             want = g(a.ctypes.data_as(U8P), ss, bb.ctypes.data_as(U8P), rs)
             assert f(a.ctypes.data_as(U8P), ss, bb.ctypes.data_as(U8P), rs, lg) == want, (trial, kind, n)
+
+
+def test_mvest_calc_sads_matches_reference():
+    """F3, second half: the oracle's restatement of od_mv_est_calc_sads against the reference's own
+    function (oracle/ref_probe/mcenc_probe.c #includes src/mcenc.c) on the motion estimation
+    context of a live encoder - another stream than the committed fixture (picture size that is
+    not a multiple of the block sizes: the SAD's clip against the picture is exercised)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from configs_round import frames_of
+    import daala_amd.hipenc as H
+    from testlib import mvest_items, mvest_oracle_sads, mvest_split
+    mp = ref('mcenc_probe')
+    if mp is None:
+        pytest.skip('oracle/_ref/mcenc_probe.so not built')
+    o = oracle()
+    U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+    w, h, nf = 150, 100, 3
+    buf = H.pack_frames(frames_of(w, h, nf, 5, step=(1, 2)), w, h)
+    assert mp.probe_mvest_open(w, h, nf, 30, 30, pu8(buf)) == 0
+    dims = np.zeros(19, np.int32)
+    assert mp.probe_mvest_dims(p32(dims)) == 0
+    nh, nv, nimg, fw, fh = int(dims[0]), int(dims[1]), int(dims[4]), int(dims[5]), int(dims[6])
+    g = {'dims': dims, 'pic': np.array([w, h], np.int32)}
+    for k in ('gmvx', 'gmvy', 'gref'):
+        g[k] = np.zeros((nv + 1, nh + 1), np.int32)
+    for p in range(3):
+        g['refs%d' % p] = np.zeros((nimg, int(dims[8 + 4*p]), int(dims[7 + 4*p])), np.uint8)
+        g['src%d' % p] = np.zeros((fh >> (p > 0), fw >> (p > 0)), np.uint8)
+    sad = [np.zeros((nv >> l, nh >> l, 4), np.int32) for l in range(3)]
+    assert mp.probe_mvest_get(p32(g['gmvx']), p32(g['gmvy']), p32(g['gref']),
+                              (U8P*3)(*[pu8(g['refs%d' % p]) for p in range(3)]),
+                              (U8P*3)(*[pu8(g['src%d' % p]) for p in range(3)]),
+                              (I32P*3)(*[p32(a) for a in sad])) == 0
+    mp.probe_mvest_close()
+    items, sizes, smax = mvest_items(o, g)
+    got = mvest_split(mvest_oracle_sads(o, g, items), sizes, smax, dims)
+    assert np.array_equal(got[1], sad[1]) and np.array_equal(got[2], sad[2])

@@ -236,3 +236,54 @@ def decide_pvq_theta(o, rate_fn, t, y_ref, y_noref, x0, r0, n, q0, beta, is_keyf
         ret = qg - 1 if noref else neg_interleave(qg + 1, t.icgr + 1)
     decide_pvq_theta.best_dist = best_dist          # for the skip_diff identity
     return ret, itheta, max_theta, best_k, y, out
+
+
+# ---------------------------------------------------------------------------
+# F3, second half: od_mv_est_calc_sads through the oracle (orc_mv_est_calc_sads_items +
+# orc_mv_est_sad_items) on a fixture of the mcenc probe's layout (tests/golden/mvest_sads.npz).
+SAD_ITEM = np.dtype([('x', np.int32), ('y', np.int32), ('log_blk_sz', np.int32), ('oc', np.int32),
+                     ('s', np.int32), ('ref', np.int32, 4), ('mvx', np.int32, 4), ('mvy', np.int32, 4),
+                     ('reserved', np.int32)])
+
+
+def mvest_items(o, g):
+    """The item list of od_mv_est_calc_sads for the fixture's grid, and per block size the
+    (count, smax) the reference's loops give."""
+    dims = g['dims']
+    nh, nv, lmin, lmax = (int(v) for v in dims[:4])
+    gx, gy, gr = (np.ascontiguousarray(g[k], dtype=np.int32) for k in ('gmvx', 'gmvy', 'gref'))
+    sizes, smax = np.zeros(3, np.int32), np.zeros(3, np.int32)
+    n = o.orc_mv_est_calc_sads_items(nh, nv, lmin, lmax, p32(gx), p32(gy), p32(gr), None, p32(sizes), p32(smax))
+    items = np.zeros(n, SAD_ITEM)
+    assert o.orc_mv_est_calc_sads_items(nh, nv, lmin, lmax, p32(gx), p32(gy), p32(gr),
+                                        ctypes.c_void_p(items.ctypes.data), p32(sizes), p32(smax)) == n
+    return items, sizes, smax
+
+
+def mvest_oracle_sads(o, g, items, nplanes=3):
+    dims = g['dims']
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    refs = [np.ascontiguousarray(g['refs%d' % p]) for p in range(3)]
+    src = [np.ascontiguousarray(g['src%d' % p]) for p in range(3)]
+    rs = np.array([dims[7 + 4*p] for p in range(3)], np.int32)
+    rh = np.array([dims[8 + 4*p] for p in range(3)], np.int32)
+    ox = np.array([dims[9 + 4*p] for p in range(3)], np.int32)
+    oy = np.array([dims[10 + 4*p] for p in range(3)], np.int32)
+    ss = np.array([s.shape[1] for s in src], np.int32)
+    dec = np.array([0, 1, 1], np.int32)
+    out = np.zeros(len(items), np.int32)
+    o.orc_mv_est_sad_items(ctypes.c_void_p(items.ctypes.data), len(items), nplanes, (U8P*3)(*[pu8(r) for r in refs]),
+                           p32(rs), p32(rh), p32(ox), p32(oy), (U8P*3)(*[pu8(s) for s in src]), p32(ss),
+                           p32(dec), p32(dec), int(g['pic'][0]), int(g['pic'][1]), p32(out))
+    return out
+
+
+def mvest_split(sad, sizes, smax, dims):
+    """Item-order SADs -> {log_mvb_sz: [rows, cols, smax]} like est->sad_cache."""
+    nh, nv = int(dims[0]), int(dims[1])
+    out, o = {}, 0
+    for l in range(3):
+        if sizes[l]:
+            out[l] = sad[o:o + sizes[l]].reshape(nv >> l, nh >> l, smax[l])
+            o += int(sizes[l])
+    return out

@@ -335,6 +335,46 @@ def mc_sad_pairs():
     print('mc_sad_pairs:', len(pairs), 'pairs')
 
 
+def mvest_sads():
+    """F3, second half: the reference's od_mv_est_calc_sads (src/mcenc.c:3761) run by
+    oracle/ref_probe/mcenc_probe.c on the motion estimation context of a real encoder after an
+    I P P stream (176x144, moving content): what the call read - the vector grid (1/8-sample
+    vectors, image index per vertex), every reference image of every plane with its padding, the
+    encoder's padded input frame - and what it wrote, sad_cache of both evaluated block sizes."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    sys.path.insert(0, ROOT)
+    from configs_round import frames_of
+    import daala_amd.hipenc as H
+    mp = ref('mcenc_probe')
+    U8P, I32P = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+    w, h, nf = 176, 144, 3
+    fr = frames_of(w, h, nf, 77, step=(2, 3))
+    g = np.random.default_rng(99)
+    for f in range(nf):       # local motion on top of the global pan, and some noise
+        fr[f] = [p.copy() for p in fr[f]]
+        fr[f][0][40:90, 60 + 5*f:120 + 5*f] = fr[0][0][30:80, 20:80]
+        fr[f][0] = np.clip(fr[f][0].astype(np.int32) + g.integers(-3, 4, size=fr[f][0].shape), 0, 255).astype(np.uint8)
+    buf = H.pack_frames(fr, w, h)
+    assert mp.probe_mvest_open(w, h, nf, 20, 30, pu8(buf)) == 0
+    dims = np.zeros(19, np.int32)
+    assert mp.probe_mvest_dims(p32(dims)) == 0
+    nh, nv, nimg, fw, fh = int(dims[0]), int(dims[1]), int(dims[4]), int(dims[5]), int(dims[6])
+    gmvx = np.zeros((nv + 1, nh + 1), np.int32)
+    gmvy = np.zeros_like(gmvx)
+    gref = np.zeros_like(gmvx)
+    refs = [np.zeros((nimg, int(dims[8 + 4*p]), int(dims[7 + 4*p])), np.uint8) for p in range(3)]
+    src = [np.zeros((fh >> (p > 0), fw >> (p > 0)), np.uint8) for p in range(3)]
+    sad = [np.zeros((nv >> l, nh >> l, 4), np.int32) for l in range(3)]
+    assert mp.probe_mvest_get(p32(gmvx), p32(gmvy), p32(gref), (U8P*3)(*[pu8(a) for a in refs]),
+                              (U8P*3)(*[pu8(a) for a in src]), (I32P*3)(*[p32(a) for a in sad])) == 0
+    mp.probe_mvest_close()
+    assert len(np.unique(gref)) >= 2 and np.any(gmvx & 7) and np.any(gmvy & 7), 'grid too tame'
+    np.savez_compressed(os.path.join(G, 'mvest_sads.npz'), dims=dims, pic=np.array([w, h], np.int32), gmvx=gmvx,
+                        gmvy=gmvy, gref=gref, refs0=refs[0], refs1=refs[1], refs2=refs[2], src0=src[0],
+                        src1=src[1], src2=src[2], sad1=sad[1], sad2=sad[2])
+    print('mvest_sads: grid', gmvx.shape, 'images used', np.unique(gref), 'sad1', sad[1].shape, 'sad2', sad[2].shape)
+
+
 def dcttest_md5():
     out = subprocess.run([os.path.join(ROOT, 'oracle', '_ref', 'dcttest')], capture_output=True)
     assert out.returncode == 0
@@ -346,6 +386,11 @@ def dcttest_md5():
 
 
 if __name__ == '__main__':
+    only = [a for a in sys.argv[1:] if not a.startswith('--')]
+    if only:       # python tools/gen_golden.py mvest_sads: just the named fixtures
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     dct_vectors()
     filter_vectors()
     filter_n_vectors()
@@ -358,6 +403,7 @@ if __name__ == '__main__':
     compute_dist_vectors()
     mc_blocks()
     mc_sad_pairs()
+    mvest_sads()
     if '--dcttest' in sys.argv:
         dcttest_md5()
     print('golden fixtures written to', G)
