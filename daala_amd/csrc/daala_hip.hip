@@ -201,7 +201,9 @@ struct od_hip_ctx {
   // forward pyramid and the PVQ passes; the whole frame by default
   int strip0 = 0, strip1 = 0;
   unsigned long long *pvq_stats = nullptr;   // od_hip_pvq_stats: device work counters (measurement)
+  struct StripCache *strips = nullptr;       // comm.hpp: segment lists and the staging buffer of strip transfers
 };
+static void strip_cache_free(od_hip_ctx *ctx);   // comm.hpp
 
 namespace {
 
@@ -996,6 +998,7 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
   }
   for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
   if (ctx->pvq_stats) (void)hipFree(ctx->pvq_stats);
+  strip_cache_free(ctx);
   if (ctx->bsize) (void)hipFree(ctx->bsize);
   if (ctx->dflags) (void)hipFree(ctx->dflags);
   for (int i = 0; i < od_hip_ctx::NAUX; i++) {
@@ -2052,7 +2055,7 @@ int od_hip_decode_tail(od_hip_ctx *ctx, int slot0, int nslots, const int32_t *th
   t.is_keyframe = is_keyframe;
   {
     Timed tm(ctx, "k_decode_tail");
-    hipLaunchKernelGGL(k_decode_tail, dim3(ctx->nhsb, ctx->nvsb, nslots), dim3(256), 0, ctx->stream, t);
+    hipLaunchKernelGGL(k_decode_tail, dim3(ctx->nhsb, ctx->nvsb, nslots), dim3(TAIL_THREADS), 0, ctx->stream, t);
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -2,12 +2,15 @@
 // bilinear smoothing between the frame post-filter and the 8-bit clamp
 // (reference src/decode.c:1040-1155, src/filter.c:1655-2040).
 //
-// One workgroup per 32x32 deringing superblock, all planes of the superblock in
-// turn (chroma reuses the directions found on luma).  Deringing reads only the
-// unfiltered post-filter output (the reference's etmp copy, :1046-1056) and every
-// superblock writes its own region, so superblocks are independent; smoothing
-// works inside one 32x32 block.  Dering + smoothing + clamp are fused: the tile is
-// read once (int32) and written once (u8).
+// One WAVE per 32x32 deringing superblock (round 4; rounds 1-3: one workgroup of four waves
+// with ~30 workgroup barriers per superblock, waves parked half of their time), all planes
+// of the superblock in turn (chroma reuses the directions found on luma).  A single-wave
+// workgroup never waits at an s_barrier: its LDS hand-overs only drain its own LDS queue.
+// Deringing reads only the unfiltered post-filter output (the reference's etmp copy,
+// :1046-1056) and every superblock writes its own region, so superblocks are independent;
+// smoothing works inside one 32x32 block.  Dering + smoothing + clamp are fused: the tile is
+// read once (int32) and written once (u8); the filtered samples stay in registers between
+// the orthogonal filter, the smoothing and the clamp.
 #pragma once
 #include "xform_kernels.hpp"
 
@@ -44,55 +47,62 @@ __constant__ int8_t TAIL_DIR[8][3][2] = {
 __constant__ int16_t TAIL_THRESH_Q8[18] = {128, 134, 150, 168, 188, 210, 234, 262, 292,
   327, 365, 408, 455, 509, 569, 635, 710, 768};
 
-// od_dir_find8 (src/filter.c:1655-1708) for the 16 8x8 blocks of a 32x32 luma tile, by
-// the whole workgroup.  The reference accumulates, per block and direction d, the sums of
-// the pixels along the <= 15 lines of that direction (partial[d][line]); integer sums are
-// associative, so they are built here by 1024 (block, direction, row) work items - 4 per
-// thread - that add their row's 8 pixels into LDS counters (pixels that fall on the same
-// line are merged in registers first), instead of 16 threads walking 64 pixels x 8
-// directions with a 120-entry private array.  part: [16][8][16] zero-initialised.
-__device__ __forceinline__ void tail_dir_accumulate(const int16_t *in, int32_t *part, int t) {
+#define TAIL_PSTRIDE 72                    /* line sums of one block: 4 directions x 16 lines, padded
+                                              so that the 8 blocks of a wave instruction spread over the banks */
+
+// od_dir_find8 (src/filter.c:1655-1708) for the 16 8x8 blocks of a 32x32 luma tile by one
+// wave.  The reference accumulates, per block and direction d, the sums of the pixels along
+// the <= 15 lines of that direction (partial[d][line]); integer sums are associative, so a
+// lane owns one row of one block (8 pixels, read once, kept in registers for all eight
+// directions) and adds it into LDS counters; the direction is uniform across the wave (no
+// divergence).  Four directions at a time fit the scratch area: D0 = 0 or 4.
+template <int D0>
+__device__ __forceinline__ void tail_dir_accumulate(const int (&x)[8], int32_t *p, int i) {
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int item = t + 256*r;
-    const int blk = item >> 6, d = (item >> 3) & 7, i = item & 7;
-    const int16_t *row = in + (8*(blk >> 2) + i)*TAIL_BSTRIDE + 8*(blk & 3);
-    int x[8];
+  for (int dd = 0; dd < 4; dd++) {
+    const int d = D0 + dd;
+    int32_t *q = p + dd*16;
+    if (d == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = row[j] >> 4;
-    int32_t *p = part + (blk*8 + d)*16;
-    switch (d) {
-      case 0:
+      for (int j = 0; j < 8; j++) atomicAdd(&q[i + j], x[j]);
+    }
+    else if (d == 1) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&p[i + j], x[j]);
-        break;
-      case 1:
+      for (int j = 0; j < 4; j++) atomicAdd(&q[i + j], x[2*j] + x[2*j + 1]);
+    }
+    else if (d == 2) q[i] = x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7];   // a line per row: no other writer
+    else if (d == 3) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) atomicAdd(&p[i + j], x[2*j] + x[2*j + 1]);
-        break;
-      case 2:
-        atomicAdd(&p[i], x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7]);
-        break;
-      case 3:
+      for (int j = 0; j < 4; j++) atomicAdd(&q[3 + i - j], x[2*j] + x[2*j + 1]);
+    }
+    else if (d == 4) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) atomicAdd(&p[3 + i - j], x[2*j] + x[2*j + 1]);
-        break;
-      case 4:
+      for (int j = 0; j < 8; j++) atomicAdd(&q[7 + i - j], x[j]);
+    }
+    else if (d == 5) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&p[7 + i - j], x[j]);
-        break;
-      case 5:
+      for (int j = 0; j < 8; j++) atomicAdd(&q[3 - i/2 + j], x[j]);
+    }
+    else if (d == 6) {
+      // line j = column j: the 8 rows of a block sit in 8 neighbouring lanes - summed
+      // there (three butterfly steps per column), one lane writes
+      int c[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&p[3 - i/2 + j], x[j]);
-        break;
-      case 6:
+      for (int j = 0; j < 8; j++) {
+        int v = x[j];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        c[j] = v;
+      }
+      if (i == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&p[j], x[j]);
-        break;
-      default:
+        for (int j = 0; j < 8; j++) q[j] = c[j];
+      }
+    }
+    else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) atomicAdd(&p[i/2 + j], x[j]);
-        break;
+      for (int j = 0; j < 8; j++) atomicAdd(&q[i/2 + j], x[j]);
     }
   }
 }
@@ -124,19 +134,250 @@ __device__ __forceinline__ int tail_dir_cost(const int32_t *p, int d) {
   return cost;
 }
 
-#ifndef TAIL_WAVES
-#define TAIL_WAVES 6           /* min waves per SIMD asked of the compiler (VGPR cap): 92 -> <= 85 VGPRs, tail 1.61 -> 1.52 ms */
-#endif
-__global__ __launch_bounds__(256, TAIL_WAVES) void k_decode_tail(TailArgs a) {
-  __shared__ int16_t in0[TAIL_BSTRIDE*TAIL_BSTRIDE];   // unfiltered tile + border
-  __shared__ int16_t in1[TAIL_BSTRIDE*TAIL_BSTRIDE];   // border + direction-filtered interior
-  __shared__ int32_t out[32*32];
-  __shared__ int32_t rowsum[32];
-  __shared__ int32_t part[16*8*16];                    // line sums, then costs in [..][0]
-  __shared__ int dirs[16], vars[16], thresh[16];
-  __shared__ int doff[16*3];                           // tap offsets of each block's direction
-  __shared__ int sh_w;
-  const int t = threadIdx.x;
+struct TailShared {
+  int16_t in0[TAIL_BSTRIDE*TAIL_BSTRIDE];   // unfiltered tile + border
+  int16_t in1[TAIL_BSTRIDE*TAIL_BSTRIDE];   // border + direction-filtered interior
+  int32_t scratch[16*TAIL_PSTRIDE];         // line sums (four directions at a time); later the packed bytes
+  int32_t cost[128];                        // [block][direction]
+  int dirs[16], vars[16], thresh[16];
+  int doff[16*3];                           // tap offsets of each block's direction
+};
+
+// One plane of one superblock.  LN = 5: 32x32 samples (luma, 4:4:4 chroma), LN = 4: 16x16.
+// A lane owns the samples e = lane + 64 r: column j = lane & (n - 1), rows (64 >> LN) apart.
+template <int LN>
+__device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int pli, int sbx, int sby, int f,
+                                           bool enc_mode, bool dering_on, bool smooth_on, int lane) {
+  constexpr int n = 1 << LN, NPX = n*n/64, RSTEP = 64 >> LN;   // rows covered by one wave pass
+  constexpr int xdec = 5 - LN, bsz = 3 - xdec, tw = n + 6;
+  const int w = a.fw >> xdec;
+  const size_t porg = (size_t)f*a.fstride[pli] + (size_t)(sby << LN)*w + (sbx << LN);
+  const int32_t *P = enc_mode ? nullptr : a.p[pli] + porg;
+  const int16_t *P16 = enc_mode ? a.p16[pli] + porg : nullptr;
+  const int j = lane & (n - 1), i0 = lane >> LN;
+  int o[NPX];
+  if (dering_on) {
+    // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE
+    const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
+    const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
+    for (int e = lane; e < tw*tw; e += 64) {
+      const int r = e/tw;
+      const int ii = r - 3, jj = e - r*tw - 3;
+      int16_t v = TAIL_VERY_LARGE;
+      if (ii >= lo_i && ii < hi_i && jj >= lo_j && jj < hi_j) {
+        v = enc_mode ? P16[(ptrdiff_t)ii*w + jj] : (int16_t)P[(ptrdiff_t)ii*w + jj];
+      }
+      S.in0[r*TAIL_BSTRIDE + jj + 3] = v;
+      if ((unsigned)ii >= (unsigned)n || (unsigned)jj >= (unsigned)n) S.in1[r*TAIL_BSTRIDE + jj + 3] = v;
+    }
+    __syncthreads();
+    const int16_t *in = S.in0 + 3*TAIL_BSTRIDE + 3;
+    if (pli == 0) {
+      // two rows of the 16 blocks' 128 per lane: block (lane >> 3) + 8 q, row lane & 7
+      int x[2][8];
+      const int bi = lane & 7;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int blk = (lane >> 3) + 8*q;
+        const int16_t *row = in + (8*(blk >> 2) + bi)*TAIL_BSTRIDE + 8*(blk & 3);
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) x[q][jj] = row[jj] >> 4;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        for (int e = lane; e < 16*TAIL_PSTRIDE; e += 64) S.scratch[e] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          int32_t *p = S.scratch + ((lane >> 3) + 8*q)*TAIL_PSTRIDE;
+          if (h == 0) tail_dir_accumulate<0>(x[q], p, bi);
+          else tail_dir_accumulate<4>(x[q], p, bi);
+        }
+        __syncthreads();
+        {
+          // 64 (block, direction) costs of this half, one per lane
+          const int blk = lane >> 2, dd = lane & 3;
+          S.cost[blk*8 + 4*h + dd] = tail_dir_cost(S.scratch + blk*TAIL_PSTRIDE + dd*16, dd);   // the cost's form repeats with period 4
+        }
+        __syncthreads();
+      }
+      if (lane < 16) {
+        // first direction with the largest cost (strict '>' scan from best_cost = 0)
+        int best_cost = 0, best_dir = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          const int c = S.cost[lane*8 + d];
+          if (c > best_cost) { best_cost = c; best_dir = d; }
+        }
+        S.dirs[lane] = best_dir;
+        S.vars[lane] = best_cost - S.cost[lane*8 + ((best_dir + 4) & 7)];
+      }
+      __syncthreads();
+      // the three tap offsets of every block's direction, once per superblock (chroma
+      // reuses them): keeps the per-pixel loop free of constant-memory gathers
+      if (lane < 48) {
+        const int blk = lane/3, k = lane - 3*blk;
+        S.doff[lane] = TAIL_DIR[S.dirs[blk]][k][0]*TAIL_BSTRIDE + TAIL_DIR[S.dirs[blk]][k][1];
+      }
+      if (lane < 16) {
+        int varsum = 0;
+        for (int k = 0; k < 16; k++) varsum += S.vars[k];
+        int v1 = S.vars[lane] >> 6, v2 = varsum/1024;
+        v1 = v1 > 32767 ? 32767 : v1;
+        v2 = v2 > 32767 ? 32767 : v2;
+        const uint32_t pr = (uint32_t)(v1*v2);
+        int il = pr ? 32 - __clz(pr) : 0;
+        il = il - 9;
+        il = il < 0 ? 0 : il > 17 ? 17 : il;
+        S.thresh[lane] = a.thr[0]*TAIL_THRESH_Q8[il] >> 8;
+      }
+    }
+    else if (lane < 16) S.thresh[lane] = a.thr[pli];
+    if (lane < 16) {
+      // skipped neighbourhood => no filtering (src/filter.c:1898-1917); a lane only rewrites its own entry
+      const int by = lane >> 2, bx = lane & 3;
+      const int sstride = a.fw/4;
+      const uint8_t *bs = a.bskip[pli] + (size_t)f*a.bskip_fstride +
+                          (size_t)(sby << (3 - xdec))*sstride + (sbx << (3 - xdec));
+      const int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
+      const int xend = (2 >> xdec) + (sbx != a.nhsb - 1), yend = (2 >> xdec) + (sby != a.nvsb - 1);
+      int skip = 1;
+      for (int ii = ystart; ii < yend; ii++) {
+        for (int jj = xstart; jj < xend; jj++) {
+          skip = skip && bs[(ptrdiff_t)((by << 1 >> xdec) + ii)*sstride + (bx << 1 >> xdec) + jj];
+        }
+      }
+      if (skip) S.thresh[lane] = 0;
+    }
+    __syncthreads();
+    // direction filter (src/filter.c:1714-1740); a lane stays in one block column, and in one
+    // block for n/8 consecutive passes: its parameters are read once per block row
+    constexpr int PER_BROW = NPX/4;          // passes per block row
+    const int bcol = j >> bsz;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+      const int blk = rb*4 + bcol;
+      const int th = S.thresh[blk];
+      const int off0 = S.doff[blk*3], off1 = S.doff[blk*3 + 1], off2 = S.doff[blk*3 + 2];
+#pragma unroll
+      for (int k = 0; k < PER_BROW; k++) {
+        const int i = (rb*PER_BROW + k)*RSTEP + i0;
+        const int16_t *c = in + i*TAIL_BSTRIDE + j;
+        const int xx = c[0];
+        int sum = 0, p0, p1;
+        p0 = c[off0] - xx;  p1 = c[-off0] - xx;
+        if (abs(p0) < th) sum += 3*p0;
+        if (abs(p1) < th) sum += 3*p1;
+        p0 = c[off1] - xx;  p1 = c[-off1] - xx;
+        if (abs(p0) < th) sum += 2*p0;
+        if (abs(p1) < th) sum += 2*p1;
+        p0 = c[off2] - xx;  p1 = c[-off2] - xx;
+        if (abs(p0) < th) sum += 2*p0;
+        if (abs(p1) < th) sum += 2*p1;
+        S.in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)(xx + ((sum + 8) >> 4));
+      }
+    }
+    __syncthreads();
+    // orthogonal filter (src/filter.c:1753-1793)
+    const int16_t *inf = S.in1 + 3*TAIL_BSTRIDE + 3;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+      const int blk = rb*4 + bcol;
+      const int th = S.thresh[blk];
+      const int offset = S.dirs[blk] <= 4 ? TAIL_BSTRIDE : 1;
+#pragma unroll
+      for (int k = 0; k < PER_BROW; k++) {
+        const int r = rb*PER_BROW + k;
+        const int i = r*RSTEP + i0;
+        const int16_t *c = inf + i*TAIL_BSTRIDE + j;
+        const int yy = c[0];
+        int athresh = th/3 + abs(yy - in[i*TAIL_BSTRIDE + j]);
+        athresh = th < athresh ? th : athresh;
+        int sum = 0, p;
+        p = c[offset] - yy;    if (abs(p) < athresh) sum += p;
+        p = c[-offset] - yy;   if (abs(p) < athresh) sum += p;
+        p = c[2*offset] - yy;  if (abs(p) < athresh) sum += p;
+        p = c[-2*offset] - yy; if (abs(p) < athresh) sum += p;
+        o[r] = (int16_t)(yy + ((3*sum + 8) >> 4));
+      }
+    }
+    __syncthreads();           // the tiles are rewritten by the next plane
+  }
+  else {
+#pragma unroll
+    for (int r = 0; r < NPX; r++) {
+      const int i = r*RSTEP + i0;
+      o[r] = enc_mode ? (int32_t)P16[(size_t)i*w + j] : P[(size_t)i*w + j];
+    }
+  }
+  if (smooth_on) {
+    // od_bilinear_smooth (src/filter.c:1952-2008) on the whole n x n tile: corners from the
+    // lanes that hold them
+    const int32_t x00 = __shfl(o[0], 0), x01 = __shfl(o[0], n - 1);
+    const int32_t x10 = __shfl(o[NPX - 1], 64 - n), x11 = __shfl(o[NPX - 1], 63);
+    const int32_t a00 = x00;
+    int32_t a01 = x01 - x00, a10 = x10 - x00, a11 = x11 + x00 - x10 - x01;
+    a01 += (a01 + n/2) >> LN;
+    a10 += (a10 + n/2) >> LN;
+    a11 += (2*a10 + n/2) >> LN;
+    int shift = 2*4 + 2*LN - 16;
+    shift = shift < 0 ? 0 : shift;
+    // per row: sum of squared differences >> shift (the row sits in n neighbouring lanes)
+    int32_t dist = 0;
+#pragma unroll
+    for (int r = 0; r < NPX; r++) {
+      const int i = r*RSTEP + i0;
+      const int32_t yv = a00 + ((j*a01 + i*a10 + (j*i*a11 >> LN) + n/2) >> LN);
+      const int32_t dd = yv - o[r];
+      int32_t part = dd*dd;
+#pragma unroll
+      for (int m = 1; m < n; m <<= 1) part += __shfl_xor(part, m);
+      if (j == 0) dist += part >> shift;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) dist += __shfl_xor(dist, m);
+    dist += n/2;
+    dist >>= 2*LN - shift;
+    const int strength = (pli == 1 || pli == 2) ? 20 : 5;
+    int wq = strength*a.q[pli]*a.q[pli]/(1 + 12*dist);
+    wq = wq > 1024 ? 1024 : wq;
+    wq = wq*wq >> 12;
+#pragma unroll
+    for (int r = 0; r < NPX; r++) {
+      const int i = r*RSTEP + i0;
+      const int32_t yv = a00 + ((j*a01 + i*a10 + (j*i*a11 >> LN) + n/2) >> LN);
+      o[r] = o[r] - ((wq*(o[r] - yv) + 128) >> 8);
+    }
+  }
+  if (enc_mode) {
+    int16_t *O = a.o16[pli] + porg;
+#pragma unroll
+    for (int r = 0; r < NPX; r++) O[(size_t)(r*RSTEP + i0)*w + j] = (int16_t)o[r];
+    return;
+  }
+  // od_coeff_to_ref_buf (src/state.c:1274-1300); the bytes of four neighbouring samples are
+  // gathered through LDS so that the plane is written as dwords
+  uint8_t *bytes = reinterpret_cast<uint8_t *>(S.scratch);
+#pragma unroll
+  for (int r = 0; r < NPX; r++) {
+    int v = ((o[r] + 8) >> 4) + 128;
+    v = v < 0 ? 0 : v > 255 ? 255 : v;
+    bytes[(r*RSTEP + i0)*n + j] = (uint8_t)v;
+  }
+  __syncthreads();
+  uint8_t *R = a.rec[pli] + porg;
+#pragma unroll
+  for (int q = 0; q < n*n/256; q++) {
+    const int e4 = 4*(lane + 64*q);
+    *reinterpret_cast<uint32_t *>(R + (size_t)(e4 >> LN)*w + (e4 & (n - 1))) = S.scratch[lane + 64*q];
+  }
+  __syncthreads();
+}
+
+#define TAIL_THREADS 64
+__global__ __launch_bounds__(TAIL_THREADS) void k_decode_tail(TailArgs a) {
+  __shared__ TailShared S;
+  const int lane = threadIdx.x;
   int sbx, sby, f;
   xcd_tile_coords(sbx, sby, f);        // 3-sample borders: neighbours share lines
   const bool enc_mode = a.flags == nullptr;
@@ -145,199 +386,7 @@ __global__ __launch_bounds__(256, TAIL_WAVES) void k_decode_tail(TailArgs a) {
   const int sb_bsize = enc_mode ? 0 : a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];
   const bool smooth_on = !enc_mode && a.q[0] > 0 && a.is_keyframe && sb_bsize == 3;
   for (int pli = 0; pli < a.nplanes; pli++) {
-    const int xdec = a.xdec[pli], ln = 5 - xdec, n = 1 << ln;
-    const int w = a.fw >> xdec;
-    const size_t porg = (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);
-    const int32_t *P = enc_mode ? nullptr : a.p[pli] + porg;
-    const int16_t *P16 = enc_mode ? a.p16[pli] + porg : nullptr;
-    if (dering_on) {
-      const int bsz = 3 - xdec, nb = n >> bsz;            // 4 blocks per side
-      // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE
-      const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
-      const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
-      // only the (n + 6)^2 corner of the 38 x 38 buffers is ever read: a chroma tile loads
-      // 22 x 22 cells, not 38 x 38
-      const int tw = n + 6;
-      for (int e = t; e < tw*tw; e += 256) {
-        const int r = xdec ? e/22 : e/38;
-        const int i = r - 3, j = e - r*tw - 3;
-        int16_t v = TAIL_VERY_LARGE;
-        if (i >= lo_i && i < hi_i && j >= lo_j && j < hi_j) {
-          v = enc_mode ? P16[(ptrdiff_t)i*w + j] : (int16_t)P[(ptrdiff_t)i*w + j];
-        }
-        in0[r*TAIL_BSTRIDE + j + 3] = v;
-        in1[r*TAIL_BSTRIDE + j + 3] = v;
-      }
-      __syncthreads();
-      const int16_t *in = in0 + 3*TAIL_BSTRIDE + 3;
-      if (pli == 0) {
-        for (int e = t; e < 16*8*16; e += 256) part[e] = 0;
-        __syncthreads();
-        tail_dir_accumulate(in, part, t);
-        __syncthreads();
-        int cost = 0;
-        if (t < 128) cost = tail_dir_cost(part + t*16, t & 7);
-        __syncthreads();
-        if (t < 128) part[t*16] = cost;
-        __syncthreads();
-        if (t < 16) {
-          // first direction with the largest cost (strict '>' scan from best_cost = 0)
-          int best_cost = 0, best_dir = 0;
-#pragma unroll
-          for (int d = 0; d < 8; d++) {
-            const int c = part[(t*8 + d)*16];
-            if (c > best_cost) { best_cost = c; best_dir = d; }
-          }
-          dirs[t] = best_dir;
-          vars[t] = best_cost - part[(t*8 + ((best_dir + 4) & 7))*16];
-        }
-        __syncthreads();
-        // the three tap offsets of every block's direction, once per superblock (chroma
-        // reuses them): keeps the per-pixel loop free of constant-memory gathers
-        if (t < 48) {
-          const int blk = t/3, k = t - 3*blk;
-          doff[t] = TAIL_DIR[dirs[blk]][k][0]*TAIL_BSTRIDE + TAIL_DIR[dirs[blk]][k][1];
-        }
-        if (t < 16) {
-          int varsum = 0;
-          for (int k = 0; k < 16; k++) varsum += vars[k];
-          int v1 = vars[t] >> 6, v2 = varsum/1024;
-          v1 = v1 > 32767 ? 32767 : v1;
-          v2 = v2 > 32767 ? 32767 : v2;
-          const uint32_t pr = (uint32_t)(v1*v2);
-          int il = pr ? 32 - __clz(pr) : 0;
-          il = il - 9;
-          il = il < 0 ? 0 : il > 17 ? 17 : il;
-          thresh[t] = a.thr[0]*TAIL_THRESH_Q8[il] >> 8;
-        }
-      }
-      else if (t < 16) thresh[t] = a.thr[pli];
-      __syncthreads();
-      if (t < nb*nb) {
-        // skipped neighbourhood => no filtering (src/filter.c:1898-1917)
-        const int by = t/nb, bx = t%nb;
-        const int sstride = a.fw/4;
-        const uint8_t *bs = a.bskip[pli] + (size_t)f*a.bskip_fstride +
-                            (size_t)(sby << (3 - xdec))*sstride + (sbx << (3 - xdec));
-        const int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
-        const int xend = (2 >> xdec) + (sbx != a.nhsb - 1), yend = (2 >> xdec) + (sby != a.nvsb - 1);
-        int skip = 1;
-        for (int i = ystart; i < yend; i++) {
-          for (int j = xstart; j < xend; j++) {
-            skip = skip && bs[(ptrdiff_t)((by << 1 >> xdec) + i)*sstride + (bx << 1 >> xdec) + j];
-          }
-        }
-        if (skip) thresh[by*4 + bx] = 0;
-      }
-      __syncthreads();
-      // direction filter (src/filter.c:1714-1740)
-      for (int e = t; e < n*n; e += 256) {
-        const int i = e >> ln, j = e & (n - 1);
-        const int blk = (i >> bsz)*4 + (j >> bsz);
-        const int th = thresh[blk];
-        const int xx = in[i*TAIL_BSTRIDE + j];
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int off = doff[blk*3 + k];
-          const int tap = k == 0 ? 3 : 2;
-          const int p0 = in[i*TAIL_BSTRIDE + j + off] - xx;
-          const int p1 = in[i*TAIL_BSTRIDE + j - off] - xx;
-          if (abs(p0) < th) sum += tap*p0;
-          if (abs(p1) < th) sum += tap*p1;
-        }
-        in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)(xx + ((sum + 8) >> 4));
-      }
-      __syncthreads();
-      // orthogonal filter (src/filter.c:1753-1793)
-      const int16_t *inf = in1 + 3*TAIL_BSTRIDE + 3;
-      for (int e = t; e < n*n; e += 256) {
-        const int i = e >> ln, j = e & (n - 1);
-        const int blk = (i >> bsz)*4 + (j >> bsz);
-        const int th = thresh[blk], dir = dirs[blk];
-        const int offset = dir <= 4 ? TAIL_BSTRIDE : 1;
-        const int yy = inf[i*TAIL_BSTRIDE + j];
-        int athresh = th/3 + abs(yy - in[i*TAIL_BSTRIDE + j]);
-        athresh = th < athresh ? th : athresh;
-        int sum = 0, p;
-        p = inf[i*TAIL_BSTRIDE + j + offset] - yy;   if (abs(p) < athresh) sum += p;
-        p = inf[i*TAIL_BSTRIDE + j - offset] - yy;   if (abs(p) < athresh) sum += p;
-        p = inf[i*TAIL_BSTRIDE + j + 2*offset] - yy; if (abs(p) < athresh) sum += p;
-        p = inf[i*TAIL_BSTRIDE + j - 2*offset] - yy; if (abs(p) < athresh) sum += p;
-        out[e] = (int16_t)(yy + ((3*sum + 8) >> 4));
-      }
-    }
-    else {
-      for (int e = t; e < n*n; e += 256) {
-        const int i = e >> ln, j = e & (n - 1);
-        out[e] = enc_mode ? (int32_t)P16[(size_t)i*w + j] : P[(size_t)i*w + j];
-      }
-    }
-    __syncthreads();
-    if (smooth_on) {
-      // od_bilinear_smooth (src/filter.c:1952-2008) on the whole n x n tile
-      const int32_t x00 = out[0], x01 = out[n - 1], x10 = out[(n - 1)*n];
-      const int32_t x11 = out[(n - 1)*n + n - 1];
-      const int32_t a00 = x00;
-      int32_t a01 = x01 - x00, a10 = x10 - x00, a11 = x11 + x00 - x10 - x01;
-      a01 += (a01 + n/2) >> ln;
-      a10 += (a10 + n/2) >> ln;
-      a11 += (2*a10 + n/2) >> ln;
-      int shift = 2*4 + 2*ln - 16;
-      shift = shift < 0 ? 0 : shift;
-      __syncthreads();
-      if (t < n) {
-        int32_t partial = 0;
-        for (int j = 0; j < n; j++) {
-          const int32_t yv = a00 + ((j*a01 + t*a10 + (j*t*a11 >> ln) + n/2) >> ln);
-          const int32_t dd = yv - out[t*n + j];
-          partial += dd*dd;
-        }
-        rowsum[t] = partial >> shift;
-      }
-      __syncthreads();
-      if (t == 0) {
-        int32_t dist = 0;
-        for (int i = 0; i < n; i++) dist += rowsum[i];
-        dist += n/2;
-        dist >>= 2*ln - shift;
-        const int strength = (pli == 1 || pli == 2) ? 20 : 5;
-        int wq = strength*a.q[pli]*a.q[pli]/(1 + 12*dist);
-        wq = wq > 1024 ? 1024 : wq;
-        sh_w = wq*wq >> 12;
-      }
-      __syncthreads();
-      const int wq = sh_w;
-      for (int e = t; e < n*n; e += 256) {
-        const int i = e >> ln, j = e & (n - 1);
-        const int32_t yv = a00 + ((j*a01 + i*a10 + (j*i*a11 >> ln) + n/2) >> ln);
-        const int32_t xv = out[e];
-        out[e] = xv - ((wq*(xv - yv) + 128) >> 8);
-      }
-      __syncthreads();
-    }
-    if (enc_mode) {
-      int16_t *O = a.o16[pli] + (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);
-      for (int e = t; e < n*n; e += 256) {
-        const int i = e >> ln, j = e & (n - 1);
-        O[(size_t)i*w + j] = (int16_t)out[e];
-      }
-      __syncthreads();
-      continue;
-    }
-    // od_coeff_to_ref_buf (src/state.c:1274-1300)
-    uint8_t *R = a.rec[pli] + (size_t)f*a.fstride[pli] + (size_t)(sby << ln)*w + (sbx << ln);
-    for (int e = t; e < n*n/4; e += 256) {
-      const int i = (e*4) >> ln, j = (e*4) & (n - 1);
-      uint32_t pk = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int v = ((out[i*n + j + k] + 8) >> 4) + 128;
-        v = v < 0 ? 0 : v > 255 ? 255 : v;
-        pk |= (uint32_t)v << (8*k);
-      }
-      *reinterpret_cast<uint32_t *>(R + (size_t)i*w + j) = pk;
-    }
-    __syncthreads();
+    if (a.xdec[pli]) tail_plane<4>(a, S, pli, sbx, sby, f, enc_mode, dering_on, smooth_on, lane);
+    else tail_plane<5>(a, S, pli, sbx, sby, f, enc_mode, dering_on, smooth_on, lane);
   }
 }

@@ -112,6 +112,9 @@ def hipenc():
 def pack_frames(frames, w, h):
     """frames: list of [Y, U, V] arrays (at least picture size) -> dense 4:2:0 buffer."""
     cw, ch = (w + 1)//2, (h + 1)//2
+    for f in frames:     # a short plane would make every later frame start at the wrong offset
+        assert f[0].shape[0] >= h and f[0].shape[1] >= w and min(f[1].shape[0], f[2].shape[0]) >= ch \
+            and min(f[1].shape[1], f[2].shape[1]) >= cw, 'frame planes smaller than the picture'
     return np.ascontiguousarray(np.concatenate(
         [np.concatenate([f[0][:h, :w].ravel(), f[1][:ch, :cw].ravel(), f[2][:ch, :cw].ravel()])
          for f in frames]))

@@ -1100,7 +1100,7 @@ static void *dworker(void *arg) {
    inter frame.  It is a pure function of the motion vector grid and the reference frames,
    both final when the decoder (src/decode.c:1248) or the encoder (src/encode.c:2219) asks
    for it, so every leaf of the grid's quadtree (od_state_pred_block, :735-786) becomes one
-   entry of a block list and od_hip_mc_predict_blocks predicts each plane in one launch. */
+   entry of a block list and od_hip_mc_predict predicts each plane in one launch. */
 typedef struct mc_list {
   od_hip_mc_block *b;
   int n;

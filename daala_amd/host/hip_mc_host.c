@@ -5,7 +5,7 @@
  * their SAD, and the next candidate depends on the outcome.  One such prediction is a few
  * hundred pixels - far below what a kernel launch and a PCIe round trip cost - so inside the
  * search the two leaves stay host code; whole-frame predictions (od_state_mc_predict, the
- * frame the residual is taken from) go to the device (od_hip_mc_predict_blocks).
+ * frame the residual is taken from) go to the device (od_hip_mc_predict).
  *
  * A profile of two 1080p P frames on one worker puts 37 % of all host time in the blend and
  * 20 % in the sub-pel predictor as the reference's scalar C compiles them, so both are bound

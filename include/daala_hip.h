@@ -21,6 +21,30 @@
  * streams; one thread at a time per object, different objects concurrently.  The
  * exceptions, safe from several threads on one object: od_hip_upload_planes (different
  * slots), od_hip_enc_feed_compand (different slots), od_hip_enc_feed_view.
+ *
+ * EXPORT MAP - who binds what (kept current by tests/test_cabi_cpu.py::test_export_map):
+ *   SEAM 1, the per-call vtable (installed into a live reference encoder by
+ *     tests/test_gpu_vtable_seam.py): od_hip_bin_{f,i}dct{4x4,8x8,16x16,32x32}, od_hip_vtbl_fill.
+ *   SEAM 2, the batched frame seam - bound by the integration library (daala_amd/host) behind
+ *     daala_encode_img_in() / daala_decode_packet_in(): od_hip_ctx_*, od_hip_upload_planes /
+ *     _coeffs / set_bsize / set_decode_info, od_hip_forward_pyramid, od_hip_forward_haar is the
+ *     feed's, od_hip_inverse_haar, od_hip_decode_tail, od_hip_download_*, od_hip_enc_feed_*
+ *     (4b), od_hip_dering_* (4c), od_hip_pfeed_* (4d), od_hip_dsynth_* (4e), od_hip_mc_create /
+ *     destroy / set_ref / set_src / predict / predict_ctx / sad_items, od_hip_pvq_compand,
+ *     od_hip_host_register / _unregister, od_hip_last_error, od_hip_device_count.
+ *   DRIVER - the device-only path of bench.py and the multi-GPU drivers: od_hip_forward_known,
+ *     od_hip_inverse, od_hip_pvq_gains / _compand_level / _search / _noref_search / _nblocks /
+ *     _download / _stats, od_hip_enc_feed_run / _refresh, od_hip_set_strip, od_hip_comm_*,
+ *     od_hip_gather_strips, od_hip_strip_bytes / _export / _import, od_hip_sync,
+ *     od_hip_timing_reset / _get, od_hip_calibrate_traffic, od_hip_version.
+ *   VECTOR - dense batches on host memory, the form the reference's own tools and unit tests
+ *     use (dcttest, filter.c -DTEST, test_coef_coder); they exist for PARITY TESTS and are bound
+ *     by no seam: od_hip_fdct_blocks, od_hip_idct_blocks, od_hip_haar_blocks,
+ *     od_hip_filter4_vectors, od_hip_filter_vectors, od_hip_resample_luma(_420),
+ *     od_hip_hv_intra_pred_blocks, od_hip_coding_order_blocks, od_hip_compute_dist_blocks,
+ *     od_hip_band_offsets, od_hip_pvq_search_vectors, od_hip_pvq_theta_vectors,
+ *     od_hip_pvq_synthesis_noref, od_hip_pvq_synthesis_vectors, od_hip_mc_predict_blocks,
+ *     od_hip_libm_probe.
  */
 #ifndef DAALA_HIP_H
 #define DAALA_HIP_H

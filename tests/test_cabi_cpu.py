@@ -81,3 +81,25 @@ def test_product_never_imports_the_oracle():
                 if f.endswith(('.py', '.h', '.hpp', '.hip', '.c', '.cpp', 'Makefile')):
                     txt = open(os.path.join(dirpath, f), errors='ignore').read()
                     assert 'oracle' not in txt.lower() or f == 'sharding.py', os.path.join(dirpath, f)
+
+
+def test_export_map():
+    """include/daala_hip.h's EXPORT MAP: the entries it lists as VECTOR (parity tests only) are
+    bound by no seam - nothing under daala_amd/host references them - and every one of them is a
+    real export."""
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'daala_hip.h')).read()
+    m = re.search(r'\*   VECTOR - (.*?)\n \*/', hdr, re.S)
+    assert m
+    names = set(re.findall(r'od_hip_[a-z0-9_]+', m.group(1)))
+    names.add('od_hip_resample_luma_420')
+    assert len(names) >= 16
+    decl = set(re.findall(r'\b(od_hip_[a-z0-9_]+)\(', hdr))
+    assert names <= decl, names - decl
+    host = ''
+    hd = os.path.join(ROOT, 'daala_amd', 'host')
+    for f in os.listdir(hd):
+        if f.endswith(('.c', '.h')):
+            host += open(os.path.join(hd, f), errors='ignore').read()
+    used = set(re.findall(r'od_hip_[a-z0-9_]+', host))
+    assert not (names & used), names & used

@@ -262,14 +262,16 @@ def test_host_codeword_search_equals_reference_search():
 def inter_stream_frames(w, h, nf):
     """nf dense 4:2:0 frames of content that pans (2, 3) samples per frame over a larger synthetic
     picture and jumps back every 30 frames (a scene cut inside the stream)."""
-    base = [synth_plane(w + 64, h + 64, 31), synth_plane(w//2 + 32, h//2 + 32, 32, 1),
-            synth_plane(w//2 + 32, h//2 + 32, 33, 1)]
+    base = [synth_plane(w + 96, h + 64, 31), synth_plane(w//2 + 48, h//2 + 32, 32, 1),
+            synth_plane(w//2 + 48, h//2 + 32, 33, 1)]
     frames = []
     for f in range(nf):
         dy, dx = 2*(f % 30), 3*(f % 30)//2*2
         frames.append([base[0][dy:dy + h, dx:dx + w], base[1][dy//2:dy//2 + h//2, dx//2:dx//2 + w//2],
                        base[2][dy//2:dy//2 + h//2, dx//2:dx//2 + w//2]])
-    return H.pack_frames(frames, w, h)
+    buf = H.pack_frames(frames, w, h)
+    assert buf.size == nf*(w*h + 2*((w + 1)//2)*((h + 1)//2))
+    return buf
 
 
 def inter_stream(w, h, nf, keyrate=4):
