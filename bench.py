@@ -108,6 +108,46 @@ def reference_packets(frames, nframes, masking=1, after_frame=None):
             'packets': H.split_packets(out, nframes), 'packet_bytes': int(nbytes)}
 
 
+def single_frame_sample(H, device):
+    """What the device buys for ONE frame (no frame-level parallelism to hide behind): a 1080p
+    and a 4K keyframe, one host worker, through the session with the device on, with the device
+    off (the same host build) and through the pure reference encoder, seconds per frame."""
+    from testlib import synth_plane
+    so = os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so')
+    lib = ctypes.CDLL(so) if os.path.exists(so) else None
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    res = {'what': 'one keyframe, one host worker: session with the device, the same build with the device '
+                   'off, the pure reference encoder; seconds per frame (second call of a warm session)'}
+    for tag, w, h in (('1080p', 1920, 1080), ('2160p', 3840, 2160)):
+        fw, fh = (w + 31) & ~31, (h + 31) & ~31
+        fr = [[synth_plane(fw, fh, 7)[:h, :w], synth_plane(fw//2, fh//2, 7, 1)[:h//2, :w//2],
+               synth_plane(fw//2, fh//2, 8, 1)[:h//2, :w//2]]]
+        buf = H.pack_frames(fr, w, h)
+        prm = H.Params(w, h, 20, 7, 1, 1, 0, 1)
+        t = {}
+        pk = {}
+        for mode, dev in (('device_on', 1), ('device_off', 0)):
+            with H.Session(prm, use_device=dev, device=device) as ses:
+                ses.encode(buf, 1)
+                t0 = time.perf_counter()
+                n, pk[mode], st = ses.encode(buf, 1)
+                t[mode] = time.perf_counter() - t0
+        entry = {'device_on_s': round(t['device_on'], 4), 'device_off_s': round(t['device_off'], 4),
+                 'device_gain': round(t['device_off']/t['device_on'], 3),
+                 'packets_equal_device_off': bool(pk['device_on'] == pk['device_off'])}
+        if lib is not None:
+            lib.probe_encode_frames.restype = ctypes.c_long
+            out = np.zeros(max(1 << 22, buf.size), np.uint8)
+            fnv, sec = ctypes.c_uint(), ctypes.c_double()
+            nb = lib.probe_encode_frames(w, h, 1, 20, 7, 1, 1, buf.ctypes.data_as(U8P), ctypes.byref(fnv),
+                                         ctypes.byref(sec), out.ctypes.data_as(U8P), out.size)
+            entry['pure_reference_s'] = round(sec.value, 3)
+            entry['x_pure_reference'] = round(sec.value/t['device_on'], 2)
+            entry['packet_equals_pure_reference_build'] = bool(nb > 0 and H.split_packets(out, 1) == pk['device_on'])
+        res[tag] = entry
+    return res
+
+
 def inter_sample(H, frames, device, nframes=3):
     so = os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so')
     if not os.path.exists(so):
@@ -487,6 +527,14 @@ def strong_step_setup(H, b, local_rank, rank, world, nframes, rehearse, dist):
     return step, close, what, (w, h, buf)
 
 
+def profiler_preloaded():
+    """rocprofv3 preloads a library that initialises the GPU before this program runs; a process
+    in that state must not start another program (the pool refuses the exec): no helper child
+    then, the first packets are pinned in-process instead."""
+    env = os.environ
+    return any('rocprof' in env.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
+
+
 def ref_helper_main(path):
     """Child process of the default N = 1 run (started before anything touches the GPU: a
     process that has initialised it must not exec): the pure reference encoder over ALL 30
@@ -496,7 +544,8 @@ def ref_helper_main(path):
     the other 20 run at the lowest priority.  Writes all 30 packets to `path`."""
     sys.path.insert(0, ROOT)
     frames = make_frames(FRAMES, seed0=1)
-    sys.stdin.readline()                      # "go": the timed region is over
+    if sys.stdin.readline() != 'go\n':        # EOF: the parent went away before its timed region ended
+        return
     nref = 10
 
     def after_frame(f, seconds):
@@ -540,7 +589,8 @@ def main():
 
     helper = helper_path = None
     if (int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline and not args.strong
-            and not args.device_only and os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so'))):
+            and not args.device_only and os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'enc_probe.so'))
+            and not profiler_preloaded()):
         # every packet of the step is pinned to the PURE reference build: a child runs it over all
         # 30 frames after the timed region (ref_helper_main); exec'd here, before the GPU is touched
         import subprocess
@@ -786,6 +836,10 @@ def main():
                 line['inter'] = inter_sample(H, frames, local_rank)
             except Exception as e:                       # an extra key must not take the headline down
                 line['inter'] = {'error': repr(e)}
+            try:
+                line['single_frame'] = single_frame_sample(H, local_rank)
+            except Exception as e:
+                line['single_frame'] = {'error': repr(e)}
             # decoder side of the seam on the packets just produced
             hdr = H.headers(prm)
             nd, pics, sec, dsec = H.decode(prm, hdr, packets, use_device=1, device=local_rank)
@@ -802,23 +856,31 @@ def main():
     if helper is not None and rank == 0 and line is not None:
         # the child's 30 packets of the pure reference build (single thread, niced, started after
         # the timed region; it has had the whole post-processing above to finish)
+        key = 'all_%d_packets_equal_pure_reference_build' % FRAMES
+        bx = line.setdefault('bit_exact', {})
         try:
             helper.stdin.close()
-            helper.wait(timeout=120)
+            helper.wait(timeout=180)
             blob = open(helper_path, 'rb').read()
             ref_all, o = [], 0
             while o + 4 <= len(blob):
                 n = int.from_bytes(blob[o:o + 4], 'little')
                 ref_all.append(blob[o + 4:o + 4 + n])
                 o += 4 + n
-            line.setdefault('bit_exact', {})['all_%d_packets_equal_pure_reference_build' % FRAMES] = \
-                bool(len(ref_all) == FRAMES and ref_all == [bytes(p) for p in packets])
+            if len(ref_all) != FRAMES:
+                raise RuntimeError('the reference child wrote %d packets' % len(ref_all))
+            bx[key] = bool(ref_all == [bytes(p) for p in packets])
         except Exception as e:
-            line.setdefault('bit_exact', {})['all_%d_packets_equal_pure_reference_build' % FRAMES] = 'not checked: %r' % (e,)
+            # not checked is not "equal": the key says so, the reason sits beside it, and the
+            # first packets are pinned in this process instead
+            bx[key] = None
+            bx['pure_reference_child'] = 'unusable: %r' % (e,)
             try:
                 helper.kill()
             except OSError:
                 pass
+            ref10 = reference_packets(frames, 10)
+            bx['first_10_packets_equal_pure_reference_build'] = bool(ref10 is not None and packets[:10] == ref10['packets'])
         finally:
             try:
                 os.remove(helper_path)

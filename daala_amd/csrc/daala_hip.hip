@@ -461,6 +461,38 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
 }  // extern "C"
 
 // ---------------------------------------------------------------------------
+// Streams of the per-worker objects (od_hip_mc, od_hip_dering).  A session has one such object
+// per host worker (30 in the bench); with a stream each the process held 30+ streams and every
+// launch issued afterwards - on ANY stream of the process - showed 60-100 us more between its
+// bracketing events (profiles/r04_launch_gaps.md has the experiment).  The
+// objects' device work is short and each call ends with a synchronisation, so they lease a
+// stream from a small per-device pool instead (OD_HIP_STREAM_POOL streams, default 4;
+// 0 = one stream per object as before).  Pooled streams live as long as the process.
+namespace {
+std::mutex g_spool_mu;
+std::map<int, std::vector<hipStream_t>> g_spool;
+unsigned g_spool_rr = 0;
+hipStream_t lease_stream(int device, bool &owned) {
+  static const int pool = [] { const char *e = getenv("OD_HIP_STREAM_POOL"); return e ? atoi(e) : 4; }();
+  hipStream_t st = nullptr;
+  if (pool <= 0) {
+    owned = true;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return st;
+  }
+  owned = false;
+  std::lock_guard<std::mutex> lk(g_spool_mu);
+  auto &v = g_spool[device];
+  if ((int)v.size() < pool) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    v.push_back(st);
+    return st;
+  }
+  return v[g_spool_rr++ % v.size()];
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------
 // Resident motion-compensation object (one per host thread that predicts frames): own
 // stream, page-locked staging, the reference frames of every plane resident in HBM - a
 // reference image is uploaded when it changes, not once per predicted plane - block list and
@@ -468,6 +500,7 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
 struct od_hip_mc {
   int device = 0, nref = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = false;          // false: leased from the per-device pool
   struct Plane {
     int ref_stride = 0, ref_h = 0, org_x = 0, org_y = 0;
     size_t plane = 0;                 // bytes of one reference plane
@@ -479,6 +512,7 @@ struct od_hip_mc {
   McBlock *d_blocks = nullptr, *h_blocks = nullptr;
   size_t blocks_cap = 0;
   hipEvent_t done = nullptr;        // od_hip_mc_predict_ctx: the prediction is in the context's plane
+  hipEvent_t ctx_ready = nullptr;   // ... and: the context's stream has reached the call (its planes may be touched)
   // od_hip_mc_sad_items: the frame being coded (one dense plane each) and the item / result lists
   struct Src {
     uint8_t *d = nullptr, *h = nullptr;
@@ -513,7 +547,8 @@ void od_hip_mc_destroy(od_hip_mc *m) {
   if (m->d_sad) (void)hipFree(m->d_sad);
   if (m->h_sad) (void)hipHostFree(m->h_sad);
   if (m->done) (void)hipEventDestroy(m->done);
-  if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->ctx_ready) (void)hipEventDestroy(m->ctx_ready);
+  if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }
 
@@ -524,7 +559,8 @@ od_hip_mc *od_hip_mc_create(int device, int nref) {
   od_hip_mc *m = new od_hip_mc();
   m->device = device;
   m->nref = nref;
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+  m->stream = lease_stream(device, m->own_stream);
+  if (!m->stream) {
     fail(OD_HIP_ENODEV, "stream creation failed");
     delete m;
     return nullptr;
@@ -652,8 +688,63 @@ int od_hip_mc_predict_ctx(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, 
   long area = 0;
   for (int b = 0; blocks && b < nblocks; b++) area += 1L << (blocks[b].log_xblk_sz + blocks[b].log_yblk_sz);
   if (area != (long)ctx->pw[pli]*ctx->ph[pli]) return fail(OD_HIP_EINVAL, "the blocks do not tile the context's plane");
+  // work still queued on the context's stream may read or write that picture plane (the forward
+  // pyramid or the tail of the previous frame): the prediction is ordered behind it
+  if (!m->ctx_ready) HIPCHK(hipEventCreateWithFlags(&m->ctx_ready, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(m->ctx_ready, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(m->stream, m->ctx_ready, 0));
   if (int rc = mc_predict_impl(m, pli, blocks, nblocks, nullptr, ctx->pw[pli], ctx->pw[pli], ctx->ph[pli],
                                ctx->pix[pli] + (size_t)slot*ctx->psz[pli])) return rc;
+  if (!m->done) HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(m->done, m->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, m->done, 0));
+  return 0;
+}
+
+// Reference image k of plane pli taken from the reconstruction plane of a context on the same
+// device (what od_hip_decode_tail / od_hip_inverse left in slot `slot`): the frame never visits
+// the host on its way to becoming a reference.  Geometry as od_hip_mc_set_ref; the padding is
+// filled on the device as od_img_edge_ext fills it (src/state.c:1100-1171).
+int od_hip_mc_set_ref_ctx(od_hip_mc *m, int pli, int k, od_hip_ctx *ctx, int slot, int ref_stride, int ref_h,
+                          int org_x, int org_y) {
+  if (!m || !ctx) return fail(OD_HIP_EFAULT, "null pointer");
+  if (int rc = check_plane(ctx, slot, pli)) return rc;
+  if (ctx->device != m->device) return fail(OD_HIP_EINVAL, "prediction object and context live on different devices");
+  if (pli > 2 || k < 0 || k >= m->nref || org_x < 0 || org_y < 0 || ref_stride < org_x + ctx->pw[pli]
+      || ref_h < org_y + ctx->ph[pli]) return fail(OD_HIP_EINVAL, "bad reference plane");
+  HIPCHK(hipSetDevice(m->device));
+  auto &P = m->pl[pli];
+  const size_t bytes = (size_t)ref_stride*ref_h;
+  if (P.plane != bytes || P.ref_stride != ref_stride) {
+    // geometry (re)defined: every reference of this plane has to be set again by the caller
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (P.d_refs) (void)hipFree(P.d_refs);
+    if (P.h_ref) (void)hipHostFree(P.h_ref);
+    P.d_refs = P.h_ref = nullptr;
+    HIPCHK(hipMalloc((void **)&P.d_refs, bytes*m->nref));
+    HIPCHK(hipHostMalloc((void **)&P.h_ref, bytes));
+    P.plane = bytes;
+    P.ref_stride = ref_stride;
+    P.ref_h = ref_h;
+  }
+  P.org_x = org_x;
+  P.org_y = org_y;
+  // the reconstruction is produced on the context's stream
+  if (!m->ctx_ready) HIPCHK(hipEventCreateWithFlags(&m->ctx_ready, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(m->ctx_ready, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(m->stream, m->ctx_ready, 0));
+  McRefArgs a;
+  a.rec = ctx->rec[pli] + (size_t)slot*ctx->psz[pli];
+  a.pw = ctx->pw[pli];
+  a.ph = ctx->ph[pli];
+  a.ref = P.d_refs + bytes*k;
+  a.ref_stride = ref_stride;
+  a.ref_h = ref_h;
+  a.org_x = org_x;
+  a.org_y = org_y;
+  hipLaunchKernelGGL(k_mc_ref_from_rec, dim3((ref_stride/4 + 256)/256, ref_h), dim3(256), 0, m->stream, a);
+  HIPCHK(hipGetLastError());
+  // the context may overwrite its reconstruction plane with the next frame: that waits for the copy
   if (!m->done) HIPCHK(hipEventCreateWithFlags(&m->done, hipEventDisableTiming));
   HIPCHK(hipEventRecord(m->done, m->stream));
   HIPCHK(hipStreamWaitEvent(ctx->stream, m->done, 0));

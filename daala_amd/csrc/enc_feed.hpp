@@ -389,6 +389,7 @@ int od_hip_enc_feed_view(od_hip_enc_feed *f, int slot, od_hip_feed_level lev[4])
 struct od_hip_dering {
   int device = 0, fw = 0, fh = 0, nplanes = 0, xdec[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
+  bool own_stream = false;        // false: leased from the per-device pool (daala_hip.hip: lease_stream)
   size_t psz[3] = {0, 0, 0};
   int16_t *d_in[3] = {nullptr, nullptr, nullptr};
   int16_t *d_out[3] = {nullptr, nullptr, nullptr};
@@ -418,7 +419,7 @@ void od_hip_dering_destroy(od_hip_dering *d) {
   if (d->d_mag2) (void)hipFree(d->d_mag2);
   if (d->d_dist) (void)hipFree(d->d_dist);
   if (d->h_dist) (void)hipHostFree(d->h_dist);
-  if (d->stream) (void)hipStreamDestroy(d->stream);
+  if (d->stream && d->own_stream) (void)hipStreamDestroy(d->stream);
   delete d;
 }
 
@@ -436,7 +437,8 @@ od_hip_dering *od_hip_dering_create(int device, int frame_width, int frame_heigh
   d->fw = frame_width;
   d->fh = frame_height;
   d->nplanes = nplanes;
-  bool ok = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess;
+  d->stream = lease_stream(device, d->own_stream);
+  bool ok = d->stream != nullptr;
   for (int p = 0; ok && p < nplanes; p++) {
     d->xdec[p] = xdec[p];
     d->psz[p] = (size_t)(frame_width >> xdec[p])*(frame_height >> xdec[p]);

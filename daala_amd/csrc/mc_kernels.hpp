@@ -279,3 +279,32 @@ __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_sad_items(McSadArgs a) {
   }
   if (lane == 0) a.sad[idx] = total;
 }
+
+// A reference plane built ON the device from a context's reconstruction plane: the frame area
+// copied, the padding filled by replicating the frame's edge samples - what
+// od_coeff_to_ref_plane + od_img_edge_ext (src/state.c:1100-1171: left/right from the row's
+// edge sample, top/bottom from the extended edge rows) leave in a reference image.  Four
+// output bytes per thread.
+struct McRefArgs {
+  const uint8_t *rec;     // pw x ph, dense
+  int pw, ph;
+  uint8_t *ref;           // ref_h rows of ref_stride bytes
+  int ref_stride, ref_h, org_x, org_y;
+};
+
+__global__ __launch_bounds__(256) void k_mc_ref_from_rec(McRefArgs a) {
+  const int x4 = (blockIdx.x*256 + threadIdx.x)*4, y = blockIdx.y;
+  if (x4 >= a.ref_stride) return;
+  int sy = y - a.org_y;
+  sy = sy < 0 ? 0 : sy >= a.ph ? a.ph - 1 : sy;
+  const uint8_t *row = a.rec + (size_t)sy*a.pw;
+  uint32_t word = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int sx = x4 + k - a.org_x;
+    sx = sx < 0 ? 0 : sx >= a.pw ? a.pw - 1 : sx;
+    word |= (uint32_t)row[sx] << (8*k);
+  }
+  if (x4 + 4 <= a.ref_stride) *reinterpret_cast<uint32_t *>(a.ref + (size_t)y*a.ref_stride + x4) = word;
+  else for (int k = 0; x4 + k < a.ref_stride; k++) a.ref[(size_t)y*a.ref_stride + x4 + k] = (uint8_t)(word >> (8*k));
+}

@@ -47,6 +47,24 @@ __constant__ int8_t TAIL_DIR[8][3][2] = {
 __constant__ int16_t TAIL_THRESH_Q8[18] = {128, 134, 150, 168, 188, 210, 234, 262, 292,
   327, 365, 408, 455, 509, 569, 635, 710, 768};
 
+// Sums over aligned groups of 8 / 16 / 32 neighbouring lanes without the LDS pipe: quad
+// permutes (xor 1, xor 2), row_half_mirror (lane i <-> 7 - i: the other quad of the eight),
+// row_mirror (i <-> 15 - i: the other eight of the row); only the last step of a 32-lane sum
+// crosses rows (one ds_bpermute).  Every lane of the group ends up with the group's sum.
+__device__ __forceinline__ int tail_sum8(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+  return v;
+}
+template <int N>
+__device__ __forceinline__ int tail_sum_group(int v) {
+  v = tail_sum8(v);
+  if (N >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);   // row_mirror
+  if (N >= 32) v += __shfl_xor(v, 16);
+  return v;
+}
+
 #define TAIL_PSTRIDE 72                    /* line sums of one block: 4 directions x 16 lines, padded
                                               so that the 8 blocks of a wave instruction spread over the banks */
 
@@ -85,16 +103,10 @@ __device__ __forceinline__ void tail_dir_accumulate(const int (&x)[8], int32_t *
     }
     else if (d == 6) {
       // line j = column j: the 8 rows of a block sit in 8 neighbouring lanes - summed
-      // there (three butterfly steps per column), one lane writes
+      // there (three DPP steps per column), one lane writes
       int c[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        int v = x[j];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        c[j] = v;
-      }
+      for (int j = 0; j < 8; j++) c[j] = tail_sum8(x[j]);
       if (i == 0) {
 #pragma unroll
         for (int j = 0; j < 8; j++) q[j] = c[j];
@@ -160,15 +172,46 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE
     const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
     const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
-    for (int e = lane; e < tw*tw; e += 64) {
-      const int r = e/tw;
-      const int ii = r - 3, jj = e - r*tw - 3;
+    // interior columns 0 .. n - 1 of rows -3 .. n + 2: always inside the frame horizontally
+    // and aligned - four samples per lane and load
+    {
+      constexpr int LPR = n/4, RPP = 64/LPR;               // lanes per row, rows per pass
+      const int c4 = (lane % LPR)*4, r0 = lane/LPR;
+#pragma unroll
+      for (int pass = 0; pass < (tw + RPP - 1)/RPP; pass++) {
+        const int r = pass*RPP + r0;
+        if (r < tw) {
+          const int ii = r - 3;
+          int v0 = TAIL_VERY_LARGE, v1 = TAIL_VERY_LARGE, v2 = TAIL_VERY_LARGE, v3 = TAIL_VERY_LARGE;
+          if (ii >= lo_i && ii < hi_i) {
+            if (enc_mode) {
+              const short4 q = *reinterpret_cast<const short4 *>(P16 + (ptrdiff_t)ii*w + c4);
+              v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
+            }
+            else {
+              const int4 q = *reinterpret_cast<const int4 *>(P + (ptrdiff_t)ii*w + c4);
+              v0 = (int16_t)q.x; v1 = (int16_t)q.y; v2 = (int16_t)q.z; v3 = (int16_t)q.w;
+            }
+          }
+          int16_t *d0 = S.in0 + r*TAIL_BSTRIDE + c4 + 3;
+          d0[0] = (int16_t)v0; d0[1] = (int16_t)v1; d0[2] = (int16_t)v2; d0[3] = (int16_t)v3;
+          if ((unsigned)ii >= (unsigned)n) {               // a border row: the filtered tile keeps it
+            int16_t *d1 = S.in1 + r*TAIL_BSTRIDE + c4 + 3;
+            d1[0] = (int16_t)v0; d1[1] = (int16_t)v1; d1[2] = (int16_t)v2; d1[3] = (int16_t)v3;
+          }
+        }
+      }
+    }
+    // the three border columns on either side
+    for (int e = lane; e < 6*tw; e += 64) {
+      const int r = e/6, c6 = e - 6*r;
+      const int ii = r - 3, jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
       int16_t v = TAIL_VERY_LARGE;
       if (ii >= lo_i && ii < hi_i && jj >= lo_j && jj < hi_j) {
         v = enc_mode ? P16[(ptrdiff_t)ii*w + jj] : (int16_t)P[(ptrdiff_t)ii*w + jj];
       }
       S.in0[r*TAIL_BSTRIDE + jj + 3] = v;
-      if ((unsigned)ii >= (unsigned)n || (unsigned)jj >= (unsigned)n) S.in1[r*TAIL_BSTRIDE + jj + 3] = v;
+      S.in1[r*TAIL_BSTRIDE + jj + 3] = v;
     }
     __syncthreads();
     const int16_t *in = S.in0 + 3*TAIL_BSTRIDE + 3;
@@ -254,6 +297,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     // block for n/8 consecutive passes: its parameters are read once per block row
     constexpr int PER_BROW = NPX/4;          // passes per block row
     const int bcol = j >> bsz;
+    int yc[NPX];                             // a lane's own direction-filtered samples
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
       const int blk = rb*4 + bcol;
@@ -261,7 +305,8 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
       const int off0 = S.doff[blk*3], off1 = S.doff[blk*3 + 1], off2 = S.doff[blk*3 + 2];
 #pragma unroll
       for (int k = 0; k < PER_BROW; k++) {
-        const int i = (rb*PER_BROW + k)*RSTEP + i0;
+        const int r = rb*PER_BROW + k;
+        const int i = r*RSTEP + i0;
         const int16_t *c = in + i*TAIL_BSTRIDE + j;
         const int xx = c[0];
         int sum = 0, p0, p1;
@@ -274,7 +319,8 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         p0 = c[off2] - xx;  p1 = c[-off2] - xx;
         if (abs(p0) < th) sum += 2*p0;
         if (abs(p1) < th) sum += 2*p1;
-        S.in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)(xx + ((sum + 8) >> 4));
+        yc[r] = (int16_t)(xx + ((sum + 8) >> 4));
+        S.in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)yc[r];
       }
     }
     __syncthreads();
@@ -290,7 +336,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         const int r = rb*PER_BROW + k;
         const int i = r*RSTEP + i0;
         const int16_t *c = inf + i*TAIL_BSTRIDE + j;
-        const int yy = c[0];
+        const int yy = yc[r];
         int athresh = th/3 + abs(yy - in[i*TAIL_BSTRIDE + j]);
         athresh = th < athresh ? th : athresh;
         int sum = 0, p;
@@ -323,19 +369,22 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     int shift = 2*4 + 2*LN - 16;
     shift = shift < 0 ? 0 : shift;
     // per row: sum of squared differences >> shift (the row sits in n neighbouring lanes)
+    int32_t yv[NPX];
     int32_t dist = 0;
 #pragma unroll
     for (int r = 0; r < NPX; r++) {
       const int i = r*RSTEP + i0;
-      const int32_t yv = a00 + ((j*a01 + i*a10 + (j*i*a11 >> LN) + n/2) >> LN);
-      const int32_t dd = yv - o[r];
-      int32_t part = dd*dd;
-#pragma unroll
-      for (int m = 1; m < n; m <<= 1) part += __shfl_xor(part, m);
-      if (j == 0) dist += part >> shift;
+      yv[r] = a00 + ((j*a01 + i*a10 + (j*i*a11 >> LN) + n/2) >> LN);
+      const int32_t dd = yv[r] - o[r];
+      dist += tail_sum_group<n>(dd*dd) >> shift;          // every lane of the row holds the row's term
     }
+    // one lane per row group holds what the rows it saw add up to: lanes 0, n, 2n, ...
+    {
+      int32_t tot = 0;
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) dist += __shfl_xor(dist, m);
+      for (int q = 0; q < 64; q += n) tot += __builtin_amdgcn_readlane(dist, q);
+      dist = tot;
+    }
     dist += n/2;
     dist >>= 2*LN - shift;
     const int strength = (pli == 1 || pli == 2) ? 20 : 5;
@@ -343,11 +392,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     wq = wq > 1024 ? 1024 : wq;
     wq = wq*wq >> 12;
 #pragma unroll
-    for (int r = 0; r < NPX; r++) {
-      const int i = r*RSTEP + i0;
-      const int32_t yv = a00 + ((j*a01 + i*a10 + (j*i*a11 >> LN) + n/2) >> LN);
-      o[r] = o[r] - ((wq*(o[r] - yv) + 128) >> 8);
-    }
+    for (int r = 0; r < NPX; r++) o[r] = o[r] - ((wq*(o[r] - yv[r]) + 128) >> 8);
   }
   if (enc_mode) {
     int16_t *O = a.o16[pli] + porg;
@@ -375,7 +420,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
 }
 
 #define TAIL_THREADS 64
-__global__ __launch_bounds__(TAIL_THREADS) void k_decode_tail(TailArgs a) {
+__global__ __launch_bounds__(TAIL_THREADS, 3) void k_decode_tail(TailArgs a) {
   __shared__ TailShared S;
   const int lane = threadIdx.x;
   int sbx, sby, f;

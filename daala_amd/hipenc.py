@@ -269,6 +269,13 @@ def synth_wide_bands():
     return int(out[2])
 
 
+def ref_resident_frames():
+    """Frames of the last decode whose reconstruction became a reference image on the device."""
+    f = hipenc().od_hipdec_ref_resident_frames
+    f.restype = ctypes.c_long
+    return int(f())
+
+
 def tail_frames():
     """Frames of the last decode whose pixel-domain stage (od_hip_decode_tail) ran on the device."""
     f = hipenc().od_hipdec_tail_frames

@@ -91,6 +91,8 @@ typedef struct dec_tls {
   od_hip_mc *mc;            /* this thread's resident motion-compensation object */
   const od_state *mc_state; /* the codec state its reference copies belong to */
   unsigned char mc_dirty[OD_FRAME_MAX + 1];   /* reference image k changed since its upload */
+  int mc_resident;                  /* image index the frame being reconstructed was written to on the device
+                                       (od_hip_mc_set_ref_ctx), or -1 */
   int failed;               /* a device stage of the current packet / frame failed: surfaced as an error code */
   int haar_frame;           /* the frame being decoded uses the Haar wavelet with a quantizer > 0: host path */
   int check;
@@ -124,6 +126,7 @@ static __thread long ds_frames;          /* P frames whose PVQ synthesis ran on 
 static __thread long ds_check_fail;
 static __thread long ds_wide_bands;      /* bands whose pulses needed more than 16 bits */
 static long g_ds_frames;
+static long g_ref_resident_frames;   /* frames of the last decode that became a reference on the device */
 static long g_ds_check_fail;
 static long g_ds_wide_bands;
 static long g_mc_dev_frames;      /* totals of the last od_hipdec_decode_frames call */
@@ -145,6 +148,12 @@ void od_hipdec_synth_stats(long out[3]) {
   out[0] = g_ds_frames;
   out[1] = g_ds_check_fail;
   out[2] = g_ds_wide_bands;
+}
+
+/* Frames of the last decode whose reconstruction became a reference image on the device
+   (od_hip_mc_set_ref_ctx): no reference upload for the frame that follows. */
+long od_hipdec_ref_resident_frames(void) {
+  return g_ref_resident_frames;
 }
 
 void od_hipdec_mc_stats(long out[2]) {
@@ -674,6 +683,10 @@ static void stage_failed(const char *stage, int rc) {
   }
 }
 
+/* HIPDEC_REF_RESIDENT=0: references always uploaded from the host image (rounds 2-3) */
+static int ref_resident_on = 1;
+static __thread long ref_resident_frames;   /* frames that became a reference on the device */
+
 static int device_frame(od_state *state) {
   const unsigned char *bskip[3];
   int32_t thr[3];
@@ -725,6 +738,29 @@ static int device_frame(od_state *state) {
   if (od_hip_set_decode_info(D.ctx, 0, state->dering_flags, bskip,
    state->skip_stride) != 0) return -3;
   if (od_hip_decode_tail(D.ctx, 0, 1, thr, quant, state->frame_type == OD_I_FRAME) != 0) return -4;
+  /* The frame just reconstructed is the next frame's reference (src/decode.c:1267-1270:
+     od_img_edge_ext of ref_imgs[SELF]): when this thread's prediction object exists - the
+     stream has P frames - the reference is taken from the context's reconstruction planes on
+     the device, padding included; the host copy below is only the picture the caller gets. */
+  D.mc_resident = -1;
+  if (D.mc != NULL && D.mc_state == state && ref_resident_on && nplanes <= 3 && !state->full_precision_references) {
+    int k;
+    int ok;
+    k = state->ref_imgi[OD_FRAME_SELF];
+    ok = k >= 0 && k <= OD_FRAME_MAX;
+    for (pli = 0; ok && pli < nplanes; pli++) {
+      const od_img_plane *rp;
+      rp = state->ref_imgs[k].planes + pli;
+      ok = rp->xstride == 1 && od_hip_mc_set_ref_ctx(D.mc, pli, k, D.ctx, 0, rp->ystride,
+       (state->frame_height + 2*OD_BUFFER_PADDING) >> rp->ydec, OD_BUFFER_PADDING >> rp->xdec,
+       OD_BUFFER_PADDING >> rp->ydec) == 0;
+    }
+    if (ok) {
+      D.mc_resident = k;
+      ref_resident_frames++;
+    }
+    else if (k >= 0 && k <= OD_FRAME_MAX) D.mc_dirty[k] = 1;      /* falls back to the upload of the host image */
+  }
   for (pli = 0; pli < nplanes; pli++) {
     if (od_hip_download_recon(D.ctx, 0, pli, D.rec[pli]) != 0) return -5;
   }
@@ -825,6 +861,9 @@ void od_coeff_to_ref_plane(od_state *state, od_img *dst, int pli, od_coeff *src,
   for (y = 0; y < h; y++) {
     memcpy(ip->data + (size_t)y*ip->ystride, D.rec[pli] + (size_t)y*w, w);
   }
+  /* the device copy of this reference image was written by device_frame() from the same
+     reconstruction: it is current */
+  if (D.mc_resident >= 0 && dst == state->ref_imgs + D.mc_resident) D.mc_dirty[D.mc_resident] = 0;
 }
 
 /* daala_decode_packet_in (src/decode.c:1159), the decoder's entry point, keeps its signature
@@ -1063,6 +1102,8 @@ static void *dworker(void *arg) {
   tail_dev_frames = 0;
   g_md_hits += D.md_hits;
   g_ds_frames += ds_frames;
+  g_ref_resident_frames += ref_resident_frames;
+  ref_resident_frames = 0;
   g_ds_check_fail += ds_check_fail;
   g_ds_wide_bands += ds_wide_bands;
   g_md_check_fail += D.md_check_fail;
@@ -1395,6 +1436,12 @@ long od_hipdec_decode_frames(const od_hipenc_params *p, const unsigned char *hdr
   g_tail_dev_frames = 0;
   g_md_hits = g_md_check_fail = 0;
   g_ds_frames = g_ds_check_fail = g_ds_wide_bands = 0;
+  g_ref_resident_frames = 0;
+  {
+    const char *e;
+    e = getenv("HIPDEC_REF_RESIDENT");
+    ref_resident_on = e == NULL || atoi(e) != 0;
+  }
   memset(&J, 0, sizeof(J));
   J.p = p;
   J.nframes = nframes;

@@ -30,7 +30,7 @@
  *     _coeffs / set_bsize / set_decode_info, od_hip_forward_pyramid, od_hip_forward_haar is the
  *     feed's, od_hip_inverse_haar, od_hip_decode_tail, od_hip_download_*, od_hip_enc_feed_*
  *     (4b), od_hip_dering_* (4c), od_hip_pfeed_* (4d), od_hip_dsynth_* (4e), od_hip_mc_create /
- *     destroy / set_ref / set_src / predict / predict_ctx / sad_items, od_hip_pvq_compand,
+ *     destroy / set_ref / set_ref_ctx / set_src / predict / predict_ctx / sad_items, od_hip_pvq_compand,
  *     od_hip_host_register / _unregister, od_hip_last_error, od_hip_device_count.
  *   DRIVER - the device-only path of bench.py and the multi-GPU drivers: od_hip_forward_known,
  *     od_hip_inverse, od_hip_pvq_gains / _compand_level / _search / _noref_search / _nblocks /
@@ -595,6 +595,13 @@ int od_hip_mc_predict(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int
  * context's stream waits for the prediction on the device; the call does not block. */
 int od_hip_mc_predict_ctx(od_hip_mc *mc, int pli, const od_hip_mc_block *blocks, int nblocks,
  od_hip_ctx *ctx, int slot);
+/* Reference image k of plane pli taken from the RECONSTRUCTION plane of slot `slot` of a
+ * context on the same device (what od_hip_decode_tail left there), padded on the device as
+ * od_img_edge_ext pads a reference image (src/state.c:1100-1171: the frame's edge samples
+ * replicated): a decoded frame becomes the next frame's reference without crossing PCIe
+ * (src/decode.c:1267-1270 on the device).  Geometry arguments as od_hip_mc_set_ref. */
+int od_hip_mc_set_ref_ctx(od_hip_mc *mc, int pli, int k, od_hip_ctx *ctx, int slot, int ref_stride,
+ int ref_h, int org_x, int org_y);
 
 /* F3, second half: batched OBMC prediction + SAD for the motion search.  What
  * od_mv_est_sad (src/mcenc.c:2271-2300) computes for one block - od_state_pred_block_from_setup

@@ -471,10 +471,14 @@ def test_inter_gop_golden_frames_and_second_keyframe():
     diff = [f for f in range(nf) if not np.array_equal(pics0[f], pics1[f])]
     assert not diff, diff
     frames, mism = H.mc_stats()
-    assert frames == nf - 2 and mism == 0
+    assert frames == nf - 2 and mism == 0        # check mode: every device prediction == the host's
     done, smis = H.synth_stats()
     assert smis == 0
     assert H.tail_frames() == nf
+    # every frame after the first became a reference ON the device (od_hip_mc_set_ref_ctx: tail ->
+    # edge extension -> resident reference set), the second keyframe and the golden frames too;
+    # the predictions checked above were made from those
+    assert H.ref_resident_frames() == nf - 1
 
 
 def test_haar_frames_with_a_quantizer_decode_on_the_host_path(monkeypatch):
