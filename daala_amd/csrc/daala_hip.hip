@@ -751,6 +751,17 @@ int od_hip_mc_set_ref_ctx(od_hip_mc *m, int pli, int k, od_hip_ctx *ctx, int slo
   return 0;
 }
 
+#ifdef TAIL_STAMPS
+// diagnostic build only: reads and clears the phase cycle counters of k_decode_tail
+int od_hip_tail_stamps(unsigned long long out[16]) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_stamps), 16*sizeof(unsigned long long)));
+  unsigned long long z[16] = {};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamps), z, sizeof(z)));
+  return 0;
+}
+#endif
+
 // F3, second half (mc_kernels.hpp: k_mc_sad_items).  od_hip_mc_set_src: plane pli of the frame
 // being coded, w x h samples (the encoder's padded input plane), resident until the next call.
 int od_hip_mc_set_src(od_hip_mc *m, int pli, const unsigned char *plane, int stride, int w, int h, int xdec,
@@ -2146,7 +2157,7 @@ int od_hip_decode_tail(od_hip_ctx *ctx, int slot0, int nslots, const int32_t *th
   t.is_keyframe = is_keyframe;
   {
     Timed tm(ctx, "k_decode_tail");
-    hipLaunchKernelGGL(k_decode_tail, dim3(ctx->nhsb, ctx->nvsb, nslots), dim3(TAIL_THREADS), 0, ctx->stream, t);
+    tail_launch(t, dim3(ctx->nhsb, ctx->nvsb, nslots), ctx->stream);
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -502,7 +502,7 @@ static int dering_run_impl(od_hip_dering *d, const int16_t *const in[], const un
   t.bskip_fstride = (size_t)fw4*fh4;
   t.fw = d->fw; t.fh = d->fh; t.nhsb = d->fw/32; t.nvsb = d->fh/32; t.nplanes = d->nplanes;
   t.is_keyframe = 1;
-  hipLaunchKernelGGL(k_decode_tail, dim3(t.nhsb, t.nvsb, 1), dim3(TAIL_THREADS), 0, d->stream, t);
+  tail_launch(t, dim3(t.nhsb, t.nvsb, 1), d->stream);
   HIPCHK(hipGetLastError());
   if (dist) {
     const long total = (long)t.nhsb*t.nvsb*32;

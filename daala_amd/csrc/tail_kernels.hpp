@@ -146,74 +146,196 @@ __device__ __forceinline__ int tail_dir_cost(const int32_t *p, int d) {
   return cost;
 }
 
+#ifdef TAIL_STAMPS
+/* diagnostic build only (make FLAGS+=-DTAIL_STAMPS, tools/tail_stamps.py): cycles of a wave's
+   life per phase of the luma plane, summed over one wave in 16; no output depends on them */
+__device__ unsigned long long g_tail_stamps[16];
+#define TAIL_STAMP(ph) do { if (pli == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  t_acc[ph] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define TAIL_STAMP(ph) do { } while (0)
+#endif
+
 struct TailShared {
   int16_t in0[TAIL_BSTRIDE*TAIL_BSTRIDE];   // unfiltered tile + border
-  int16_t in1[TAIL_BSTRIDE*TAIL_BSTRIDE];   // border + direction-filtered interior
-  int32_t scratch[16*TAIL_PSTRIDE];         // line sums (four directions at a time); later the packed bytes
+  // Three tenants, one after the other: the line sums of the direction search (luma only, four
+  // directions at a time), then the filtered tile (border + direction-filtered interior), then
+  // the packed output bytes.  Sharing the space takes the workgroup from 11.6 to 8.7 KB of LDS:
+  // 18 instead of 13 single-wave workgroups per CU.
+  union alignas(16) {
+    int16_t in1[TAIL_BSTRIDE*TAIL_BSTRIDE];
+    int32_t scratch[16*TAIL_PSTRIDE];
+  };
   int32_t cost[128];                        // [block][direction]
   int dirs[16], vars[16], thresh[16];
   int doff[16*3];                           // tap offsets of each block's direction
+  int16_t tab_off[24];                      // TAIL_DIR as tile offsets (dy*TAIL_BSTRIDE + dx), [direction][tap]
+  int16_t tab_thr[18];                      // TAIL_THRESH_Q8
 };
+
+// A plane's (n + 6)^2 tile on its way from HBM to LDS, held in registers between the ISSUE of
+// its loads and their COMMIT to LDS: the kernel issues the loads of all three planes of a
+// 4:2:0 superblock up front, so the chroma tiles (and the skip maps) travel while the luma
+// plane is being filtered - one memory round trip per superblock instead of one per plane
+// plus one per skip test (stamps of the first single-wave version, profiles/r04_tail_stamps_*:
+// a third of a wave's life went into waiting for tile loads).
+template <int LN>
+struct TailTile {
+  static constexpr int n = 1 << LN, tw = n + 6;
+  static constexpr int LPR = n/4, RPP = 64/LPR;            // interior: lanes per row, rows per pass
+  static constexpr int NPASS = (tw + RPP - 1)/RPP, NB = (6*tw + 63)/64;
+  int4 q[NPASS];            // four interior samples per pass (int16 input: two dwords used)
+  int b[NB];                // border columns, one sample per pass
+  int skip;                 // lanes 0 .. 15: the block's neighbourhood was skipped entirely
+};
+
+template <int LN>
+__device__ __forceinline__ void tail_tile_issue(TailTile<LN> &T, const TailArgs &a, int pli, int sbx, int sby,
+                                                int f, bool enc_mode, int lane) {
+  using TT = TailTile<LN>;
+  constexpr int n = TT::n, tw = TT::tw, xdec = 5 - LN;
+  const int w = a.fw >> xdec;
+  const size_t porg = (size_t)f*a.fstride[pli] + (size_t)(sby << LN)*w + (sbx << LN);
+  const int32_t *P = enc_mode ? nullptr : a.p[pli] + porg;
+  const int16_t *P16 = enc_mode ? a.p16[pli] + porg : nullptr;
+  // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE (filled at commit)
+  const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
+  const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
+  // interior columns 0 .. n - 1 of rows -3 .. n + 2: always inside the frame horizontally and
+  // aligned - four samples per lane and load
+  const int c4 = (lane % TT::LPR)*4, r0 = lane/TT::LPR;
+#pragma unroll
+  for (int pass = 0; pass < TT::NPASS; pass++) {
+    const int ii = pass*TT::RPP + r0 - 3;
+    T.q[pass] = make_int4(0, 0, 0, 0);
+    if (ii >= lo_i && ii < hi_i) {
+      if (enc_mode) {
+        const int2 u = *reinterpret_cast<const int2 *>(P16 + (ptrdiff_t)ii*w + c4);
+        T.q[pass].x = u.x;
+        T.q[pass].y = u.y;
+      }
+      else T.q[pass] = *reinterpret_cast<const int4 *>(P + (ptrdiff_t)ii*w + c4);
+    }
+  }
+  // the three border columns on either side
+#pragma unroll
+  for (int it = 0; it < TT::NB; it++) {
+    const int e = lane + 64*it;
+    const int r = e/6, c6 = e - 6*r;
+    const int ii = r - 3, jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
+    T.b[it] = TAIL_VERY_LARGE;
+    if (e < 6*tw && ii >= lo_i && ii < hi_i && jj >= lo_j && jj < hi_j) {
+      T.b[it] = enc_mode ? (int)P16[(ptrdiff_t)ii*w + jj] : (int)(int16_t)P[(ptrdiff_t)ii*w + jj];
+    }
+  }
+  // skipped neighbourhood => no filtering (src/filter.c:1898-1917): every flag of the block's
+  // neighbourhood is read (no early exit: the loads leave together)
+  T.skip = 0;
+  if (lane < 16) {
+    const int by = lane >> 2, bx = lane & 3;
+    const int sstride = a.fw/4;
+    const uint8_t *bs = a.bskip[pli] + (size_t)f*a.bskip_fstride +
+                        (size_t)(sby << (3 - xdec))*sstride + (sbx << (3 - xdec));
+    const int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
+    const int xend = (2 >> xdec) + (sbx != a.nhsb - 1), yend = (2 >> xdec) + (sby != a.nvsb - 1);
+    int all = 1;
+#pragma unroll
+    for (int ii = -1; ii < 3; ii++) {
+#pragma unroll
+      for (int jj = -1; jj < 3; jj++) {
+        if (ii >= ystart && ii < yend && jj >= xstart && jj < xend) {
+          all &= bs[(ptrdiff_t)((by << 1 >> xdec) + ii)*sstride + (bx << 1 >> xdec) + jj] != 0;
+        }
+      }
+    }
+    T.skip = all;
+  }
+}
+
+// IN1: the filtered tile's border is written too (not for luma, whose direction search uses
+// that space first: tail_border_copy fills it afterwards)
+template <int LN, bool IN1>
+__device__ __forceinline__ void tail_tile_commit(const TailTile<LN> &T, const TailArgs &a, TailShared &S, int sbx,
+                                                 int sby, bool enc_mode, int lane) {
+  using TT = TailTile<LN>;
+  constexpr int n = TT::n, tw = TT::tw;
+  const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
+  const int c4 = (lane % TT::LPR)*4, r0 = lane/TT::LPR;
+#pragma unroll
+  for (int pass = 0; pass < TT::NPASS; pass++) {
+    const int r = pass*TT::RPP + r0;
+    if (r < tw) {
+      const int ii = r - 3;
+      int v0 = TAIL_VERY_LARGE, v1 = TAIL_VERY_LARGE, v2 = TAIL_VERY_LARGE, v3 = TAIL_VERY_LARGE;
+      if (ii >= lo_i && ii < hi_i) {
+        if (enc_mode) {
+          v0 = (int16_t)(T.q[pass].x & 0xffff); v1 = T.q[pass].x >> 16;
+          v2 = (int16_t)(T.q[pass].y & 0xffff); v3 = T.q[pass].y >> 16;
+        }
+        else {
+          v0 = (int16_t)T.q[pass].x; v1 = (int16_t)T.q[pass].y; v2 = (int16_t)T.q[pass].z; v3 = (int16_t)T.q[pass].w;
+        }
+      }
+      int16_t *d0 = S.in0 + r*TAIL_BSTRIDE + c4 + 3;
+      d0[0] = (int16_t)v0; d0[1] = (int16_t)v1; d0[2] = (int16_t)v2; d0[3] = (int16_t)v3;
+      if (IN1 && (unsigned)ii >= (unsigned)n) {        // a border row: the filtered tile keeps it
+        int16_t *d1 = S.in1 + r*TAIL_BSTRIDE + c4 + 3;
+        d1[0] = (int16_t)v0; d1[1] = (int16_t)v1; d1[2] = (int16_t)v2; d1[3] = (int16_t)v3;
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < TT::NB; it++) {
+    const int e = lane + 64*it;
+    const int r = e/6, c6 = e - 6*r;
+    const int jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
+    if (e < 6*tw) {
+      S.in0[r*TAIL_BSTRIDE + jj + 3] = (int16_t)T.b[it];
+      if (IN1) S.in1[r*TAIL_BSTRIDE + jj + 3] = (int16_t)T.b[it];
+    }
+  }
+}
+
+// What the orthogonal filter reads beyond the interior of the filtered tile - two samples
+// straight above, below, left and right of it, never a corner (src/filter.c:1753-1793: taps at
+// +-1 and +-2 along a row or a column) - copied from the unfiltered tile, LDS to LDS.
+template <int LN>
+__device__ __forceinline__ void tail_border_copy(TailShared &S, int lane) {
+  constexpr int n = 1 << LN;
+#pragma unroll
+  for (int it = 0; it < 4*n/64; it++) {
+    const int e = lane + 64*it;
+    const int k = e >> LN, c = e & (n - 1);            // k: which of the four lines
+    const int off = k < 2 ? k + 1 : n + k + 1;         // tile rows / columns 1, 2, n + 3, n + 4
+    S.in1[off*TAIL_BSTRIDE + c + 3] = S.in0[off*TAIL_BSTRIDE + c + 3];
+    S.in1[(c + 3)*TAIL_BSTRIDE + off] = S.in0[(c + 3)*TAIL_BSTRIDE + off];
+  }
+}
 
 // One plane of one superblock.  LN = 5: 32x32 samples (luma, 4:4:4 chroma), LN = 4: 16x16.
 // A lane owns the samples e = lane + 64 r: column j = lane & (n - 1), rows (64 >> LN) apart.
-template <int LN>
+template <int LN, bool PRE>
 __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int pli, int sbx, int sby, int f,
-                                           bool enc_mode, bool dering_on, bool smooth_on, int lane) {
+                                           bool enc_mode, bool dering_on, bool smooth_on, int lane,
+                                           TailTile<LN> &T) {
   constexpr int n = 1 << LN, NPX = n*n/64, RSTEP = 64 >> LN;   // rows covered by one wave pass
-  constexpr int xdec = 5 - LN, bsz = 3 - xdec, tw = n + 6;
+  constexpr int xdec = 5 - LN, bsz = 3 - xdec;
   const int w = a.fw >> xdec;
   const size_t porg = (size_t)f*a.fstride[pli] + (size_t)(sby << LN)*w + (sbx << LN);
   const int32_t *P = enc_mode ? nullptr : a.p[pli] + porg;
   const int16_t *P16 = enc_mode ? a.p16[pli] + porg : nullptr;
   const int j = lane & (n - 1), i0 = lane >> LN;
   int o[NPX];
+#ifdef TAIL_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   if (dering_on) {
-    // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE
-    const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
-    const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
-    // interior columns 0 .. n - 1 of rows -3 .. n + 2: always inside the frame horizontally
-    // and aligned - four samples per lane and load
-    {
-      constexpr int LPR = n/4, RPP = 64/LPR;               // lanes per row, rows per pass
-      const int c4 = (lane % LPR)*4, r0 = lane/LPR;
-#pragma unroll
-      for (int pass = 0; pass < (tw + RPP - 1)/RPP; pass++) {
-        const int r = pass*RPP + r0;
-        if (r < tw) {
-          const int ii = r - 3;
-          int v0 = TAIL_VERY_LARGE, v1 = TAIL_VERY_LARGE, v2 = TAIL_VERY_LARGE, v3 = TAIL_VERY_LARGE;
-          if (ii >= lo_i && ii < hi_i) {
-            if (enc_mode) {
-              const short4 q = *reinterpret_cast<const short4 *>(P16 + (ptrdiff_t)ii*w + c4);
-              v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
-            }
-            else {
-              const int4 q = *reinterpret_cast<const int4 *>(P + (ptrdiff_t)ii*w + c4);
-              v0 = (int16_t)q.x; v1 = (int16_t)q.y; v2 = (int16_t)q.z; v3 = (int16_t)q.w;
-            }
-          }
-          int16_t *d0 = S.in0 + r*TAIL_BSTRIDE + c4 + 3;
-          d0[0] = (int16_t)v0; d0[1] = (int16_t)v1; d0[2] = (int16_t)v2; d0[3] = (int16_t)v3;
-          if ((unsigned)ii >= (unsigned)n) {               // a border row: the filtered tile keeps it
-            int16_t *d1 = S.in1 + r*TAIL_BSTRIDE + c4 + 3;
-            d1[0] = (int16_t)v0; d1[1] = (int16_t)v1; d1[2] = (int16_t)v2; d1[3] = (int16_t)v3;
-          }
-        }
-      }
-    }
-    // the three border columns on either side
-    for (int e = lane; e < 6*tw; e += 64) {
-      const int r = e/6, c6 = e - 6*r;
-      const int ii = r - 3, jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
-      int16_t v = TAIL_VERY_LARGE;
-      if (ii >= lo_i && ii < hi_i && jj >= lo_j && jj < hi_j) {
-        v = enc_mode ? P16[(ptrdiff_t)ii*w + jj] : (int16_t)P[(ptrdiff_t)ii*w + jj];
-      }
-      S.in0[r*TAIL_BSTRIDE + jj + 3] = v;
-      S.in1[r*TAIL_BSTRIDE + jj + 3] = v;
-    }
+    if (!PRE) tail_tile_issue<LN>(T, a, pli, sbx, sby, f, enc_mode, lane);
+    if (pli == 0) tail_tile_commit<LN, false>(T, a, S, sbx, sby, enc_mode, lane);
+    else tail_tile_commit<LN, true>(T, a, S, sbx, sby, enc_mode, lane);
     __syncthreads();
+    TAIL_STAMP(0);                                   // tile in LDS
     const int16_t *in = S.in0 + 3*TAIL_BSTRIDE + 3;
     if (pli == 0) {
       // two rows of the 16 blocks' 128 per lane: block (lane >> 3) + 8 q, row lane & 7
@@ -228,7 +350,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
       }
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        for (int e = lane; e < 16*TAIL_PSTRIDE; e += 64) S.scratch[e] = 0;
+        for (int e = lane; e < 16*TAIL_PSTRIDE/4; e += 64) reinterpret_cast<int4 *>(S.scratch)[e] = make_int4(0, 0, 0, 0);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -260,7 +382,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
       // reuses them): keeps the per-pixel loop free of constant-memory gathers
       if (lane < 48) {
         const int blk = lane/3, k = lane - 3*blk;
-        S.doff[lane] = TAIL_DIR[S.dirs[blk]][k][0]*TAIL_BSTRIDE + TAIL_DIR[S.dirs[blk]][k][1];
+        S.doff[lane] = S.tab_off[S.dirs[blk]*3 + k];
       }
       if (lane < 16) {
         int varsum = 0;
@@ -272,32 +394,19 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         int il = pr ? 32 - __clz(pr) : 0;
         il = il - 9;
         il = il < 0 ? 0 : il > 17 ? 17 : il;
-        S.thresh[lane] = a.thr[0]*TAIL_THRESH_Q8[il] >> 8;
+        S.thresh[lane] = a.thr[0]*S.tab_thr[il] >> 8;
       }
+      tail_border_copy<LN>(S, lane);       // the line sums are done with: the space is the filtered tile now
     }
     else if (lane < 16) S.thresh[lane] = a.thr[pli];
-    if (lane < 16) {
-      // skipped neighbourhood => no filtering (src/filter.c:1898-1917); a lane only rewrites its own entry
-      const int by = lane >> 2, bx = lane & 3;
-      const int sstride = a.fw/4;
-      const uint8_t *bs = a.bskip[pli] + (size_t)f*a.bskip_fstride +
-                          (size_t)(sby << (3 - xdec))*sstride + (sbx << (3 - xdec));
-      const int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
-      const int xend = (2 >> xdec) + (sbx != a.nhsb - 1), yend = (2 >> xdec) + (sby != a.nvsb - 1);
-      int skip = 1;
-      for (int ii = ystart; ii < yend; ii++) {
-        for (int jj = xstart; jj < xend; jj++) {
-          skip = skip && bs[(ptrdiff_t)((by << 1 >> xdec) + ii)*sstride + (bx << 1 >> xdec) + jj];
-        }
-      }
-      if (skip) S.thresh[lane] = 0;
-    }
+    TAIL_STAMP(1);                                   // directions
+    if (lane < 16 && T.skip) S.thresh[lane] = 0;     // a lane only rewrites its own entry
     __syncthreads();
+    TAIL_STAMP(2);                                   // thresholds, skip test
     // direction filter (src/filter.c:1714-1740); a lane stays in one block column, and in one
     // block for n/8 consecutive passes: its parameters are read once per block row
     constexpr int PER_BROW = NPX/4;          // passes per block row
     const int bcol = j >> bsz;
-    int yc[NPX];                             // a lane's own direction-filtered samples
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
       const int blk = rb*4 + bcol;
@@ -319,11 +428,11 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         p0 = c[off2] - xx;  p1 = c[-off2] - xx;
         if (abs(p0) < th) sum += 2*p0;
         if (abs(p1) < th) sum += 2*p1;
-        yc[r] = (int16_t)(xx + ((sum + 8) >> 4));
-        S.in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)yc[r];
+        S.in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)(xx + ((sum + 8) >> 4));
       }
     }
     __syncthreads();
+    TAIL_STAMP(3);                                   // direction filter
     // orthogonal filter (src/filter.c:1753-1793)
     const int16_t *inf = S.in1 + 3*TAIL_BSTRIDE + 3;
 #pragma unroll
@@ -336,7 +445,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         const int r = rb*PER_BROW + k;
         const int i = r*RSTEP + i0;
         const int16_t *c = inf + i*TAIL_BSTRIDE + j;
-        const int yy = yc[r];
+        const int yy = c[0];
         int athresh = th/3 + abs(yy - in[i*TAIL_BSTRIDE + j]);
         athresh = th < athresh ? th : athresh;
         int sum = 0, p;
@@ -348,6 +457,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
       }
     }
     __syncthreads();           // the tiles are rewritten by the next plane
+    TAIL_STAMP(4);                                   // orthogonal filter
   }
   else {
 #pragma unroll
@@ -394,6 +504,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
 #pragma unroll
     for (int r = 0; r < NPX; r++) o[r] = o[r] - ((wq*(o[r] - yv[r]) + 128) >> 8);
   }
+  TAIL_STAMP(5);                                     // smoothing (or the plain load)
   if (enc_mode) {
     int16_t *O = a.o16[pli] + porg;
 #pragma unroll
@@ -417,10 +528,21 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     *reinterpret_cast<uint32_t *>(R + (size_t)(e4 >> LN)*w + (e4 & (n - 1))) = S.scratch[lane + 64*q];
   }
   __syncthreads();
+  TAIL_STAMP(6);                                     // clamp, pack, store
+#ifdef TAIL_STAMPS
+  if (pli == 0 && lane == 0 && ((sbx + sby) & 15) == 0) {
+    for (int q = 0; q < 7; q++) atomicAdd(&g_tail_stamps[q], t_acc[q]);
+    atomicAdd(&g_tail_stamps[15], 1ull);
+  }
+#endif
 }
 
 #define TAIL_THREADS 64
-__global__ __launch_bounds__(TAIL_THREADS, 3) void k_decode_tail(TailArgs a) {
+// F420: three planes, chroma decimated in both directions (the host knows the geometry and picks
+// the instantiation): a plane's loads leave while the plane before it is filtered.  Otherwise
+// (one plane, 4:4:4, ...) the planes simply follow one another.
+template <bool F420>
+__global__ __launch_bounds__(TAIL_THREADS, F420 ? 4 : 2) void k_decode_tail(TailArgs a) {
   __shared__ TailShared S;
   const int lane = threadIdx.x;
   int sbx, sby, f;
@@ -430,8 +552,40 @@ __global__ __launch_bounds__(TAIL_THREADS, 3) void k_decode_tail(TailArgs a) {
   const bool dering_on = a.q[0] > 0 && flag;
   const int sb_bsize = enc_mode ? 0 : a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];
   const bool smooth_on = !enc_mode && a.q[0] > 0 && a.is_keyframe && sb_bsize == 3;
-  for (int pli = 0; pli < a.nplanes; pli++) {
-    if (a.xdec[pli]) tail_plane<4>(a, S, pli, sbx, sby, f, enc_mode, dering_on, smooth_on, lane);
-    else tail_plane<5>(a, S, pli, sbx, sby, f, enc_mode, dering_on, smooth_on, lane);
+  // the two small tables of the direction search go to LDS now: their constant-memory reads
+  // travel with the tile loads instead of standing in the dependent chain after the search
+  if (lane < 24) S.tab_off[lane] = (int16_t)(TAIL_DIR[lane/3][lane%3][0]*TAIL_BSTRIDE + TAIL_DIR[lane/3][lane%3][1]);
+  else if (lane >= 32 && lane < 50) S.tab_thr[lane - 32] = TAIL_THRESH_Q8[lane - 32];
+  if (F420) {
+    TailTile<5> t0;
+    TailTile<4> t1, t2;
+    if (dering_on) {
+      tail_tile_issue<5>(t0, a, 0, sbx, sby, f, enc_mode, lane);
+      tail_tile_issue<4>(t1, a, 1, sbx, sby, f, enc_mode, lane);
+    }
+    tail_plane<5, true>(a, S, 0, sbx, sby, f, enc_mode, dering_on, smooth_on, lane, t0);
+    if (dering_on) tail_tile_issue<4>(t2, a, 2, sbx, sby, f, enc_mode, lane);   // travels while the first chroma plane is filtered
+    tail_plane<4, true>(a, S, 1, sbx, sby, f, enc_mode, dering_on, smooth_on, lane, t1);
+    tail_plane<4, true>(a, S, 2, sbx, sby, f, enc_mode, dering_on, smooth_on, lane, t2);
   }
+  else {
+    for (int pli = 0; pli < a.nplanes; pli++) {
+      if (a.xdec[pli]) {
+        TailTile<4> t;
+        tail_plane<4, false>(a, S, pli, sbx, sby, f, enc_mode, dering_on, smooth_on, lane, t);
+      }
+      else {
+        TailTile<5> t;
+        tail_plane<5, false>(a, S, pli, sbx, sby, f, enc_mode, dering_on, smooth_on, lane, t);
+      }
+    }
+  }
+}
+
+// host side: the instantiation that fits the geometry
+static inline void tail_launch(const TailArgs &t, dim3 grid, hipStream_t stream) {
+  if (t.nplanes == 3 && !t.xdec[0] && t.xdec[1] && t.xdec[2]) {
+    hipLaunchKernelGGL(k_decode_tail<true>, grid, dim3(TAIL_THREADS), 0, stream, t);
+  }
+  else hipLaunchKernelGGL(k_decode_tail<false>, grid, dim3(TAIL_THREADS), 0, stream, t);
 }

@@ -91,6 +91,7 @@ typedef struct dec_tls {
   od_hip_mc *mc;            /* this thread's resident motion-compensation object */
   const od_state *mc_state; /* the codec state its reference copies belong to */
   unsigned char mc_dirty[OD_FRAME_MAX + 1];   /* reference image k changed since its upload */
+  const void *poisoned;             /* decoder whose last frame failed: packets fail until its next keyframe */
   int mc_resident;                  /* image index the frame being reconstructed was written to on the device
                                        (od_hip_mc_set_ref_ctx), or -1 */
   int failed;               /* a device stage of the current packet / frame failed: surfaced as an error code */
@@ -414,7 +415,12 @@ void pvq_synthesis(od_coeff *xcoeff, od_coeff *ypulse, od_coeff *ref, int n, dou
       D.ds_cur_mask |= 1u << band;
     }
     else D.ds_overflow = 1;
-    if (!D.check) return;
+    if (!D.check) {
+      /* the band is synthesised on the device; the host buffer is never read for it, but it is
+         left defined */
+      memset(xcoeff, 0, sizeof(*xcoeff)*n);
+      return;
+    }
   }
   pvq_synthesis_cpu(xcoeff, ypulse, ref, n, gr, noref, g, theta, qm, qm_inv);
 }
@@ -440,7 +446,9 @@ void od_hipdec_raster_to_coding_order(od_coeff *dst, int n, const od_coeff *src,
     int i;
     int len;
     len = n*n < 512 ? n*n : 512;        /* the coded positions (OD_BAND_OFFSETS, src/partition.c:77-83) */
-    for (i = 0; i < len; i++) dst[i] = DS_SENTINEL;
+    dst[0] = 0;                         /* index 0 is the DC: no band, and the block decoder adds the DC to it */
+    for (i = 1; i < len; i++) dst[i] = DS_SENTINEL;
+    for (; i < n*n; i++) dst[i] = 0;    /* never coded (32x32): defined, never read by the device path */
     return;
   }
   od_raster_to_coding_order(dst, n, src, stride);
@@ -454,7 +462,7 @@ void od_hipdec_coding_order_to_raster(od_coeff *dst, int stride, const od_coeff 
     st = &D.dec->state;
     b = D.ds_blocks + D.ds_cur;
     if (dst == st->dtmp[b->pli] + b->org && n == 4 << b->bs) {
-      b->dc = src[0] - (D.check ? st->mdtmp[b->pli][b->org] : DS_SENTINEL);
+      b->dc = src[0] - (D.check ? st->mdtmp[b->pli][b->org] : 0);
       for (i = 0; i < DS_NB[b->bs]; i++) {
         int j;
         int len;
@@ -875,6 +883,9 @@ int daala_decode_packet_in_cpu(daala_dec_ctx *dec, const daala_packet *op);
 int daala_decode_packet_in(daala_dec_ctx *dec, const daala_packet *op) {
   int rc;
   if (D.ctx == NULL || dec == NULL) return daala_decode_packet_in_cpu(dec, op);
+  /* after a failed frame the decoder's reference images are not what the stream expects: every
+     packet keeps failing until a keyframe resynchronises it */
+  if (D.poisoned == dec && op != NULL && !daala_packet_iskeyframe((daala_packet *)op)) return OD_EFAULT;
   D.dec = (od_dec_ctx *)dec;
   D.md_valid = 0;
   D.haar_frame = 0;
@@ -897,7 +908,11 @@ int daala_decode_packet_in(daala_dec_ctx *dec, const daala_packet *op) {
   D.dec = NULL;
   D.md_valid = 0;
   D.ds_on = 0;
-  if (rc >= 0 && D.failed) rc = OD_EFAULT;
+  if (rc >= 0 && D.failed) {
+    rc = OD_EFAULT;
+    D.poisoned = dec;
+  }
+  else if (rc >= 0 && D.poisoned == dec) D.poisoned = NULL;
   return rc;
 }
 

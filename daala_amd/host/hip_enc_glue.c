@@ -50,6 +50,7 @@ double od_hipenc_now(void) {
    microsecond per step) read the time stamp counter: a clock_gettime that is a system call on
    this kind of guest costs as much as what it brackets.  Seconds per tick are calibrated once
    per process against the monotonic clock. */
+#if defined(__x86_64__)
 static double tsc_period;
 static pthread_once_t tsc_once = PTHREAD_ONCE_INIT;
 static void tsc_calibrate(void) {
@@ -69,6 +70,14 @@ void od_hipenc_fine_timer_init(void) {
 double od_hipenc_fine_now(void) {
   return (double)__builtin_ia32_rdtsc()*tsc_period;
 }
+#else
+/* no time stamp counter: the sampled timers of HIPENC_TIME=1 use the monotonic clock */
+void od_hipenc_fine_timer_init(void) {
+}
+double od_hipenc_fine_now(void) {
+  return od_hipenc_now();
+}
+#endif
 
 /* pvq_search_rdo_double as the reference's own pvq_theta calls it (inter frames, and the
    reference's od_pvq_encode in check mode).  Check mode keeps the reference's C search (it is
@@ -346,6 +355,7 @@ int od_hipenc_pframe_feed(od_state *state, od_img *pred) {
   if (od_hip_pfeed_gains(T.pf, pin, sin_, ppr, spr) != 0) return -1;
   {
     pthread_t th[16];
+    int started[16];
     pf_stage_job jobs[16];
     int n;
     int i;
@@ -358,16 +368,14 @@ int od_hipenc_pframe_feed(od_state *state, od_img *pred) {
       jobs[i].rc = 0;
     }
     for (i = 1; i < n; i++) {
-      if (pthread_create(&th[i], NULL, pf_stage_thread, &jobs[i]) != 0) {
-        /* no thread: this one does that part too */
-        th[i] = 0;
-        pf_stage_thread(&jobs[i]);
-      }
+      started[i] = pthread_create(&th[i], NULL, pf_stage_thread, &jobs[i]) == 0;
+      /* no thread: this one does that part too */
+      if (!started[i]) pf_stage_thread(&jobs[i]);
     }
     pf_stage_thread(&jobs[0]);
     bad = jobs[0].rc;
     for (i = 1; i < n; i++) {
-      if (th[i] != 0) pthread_join(th[i], NULL);
+      if (started[i]) pthread_join(th[i], NULL);
       bad |= jobs[i].rc;
     }
     if (bad) return -1;
