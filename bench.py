@@ -599,7 +599,6 @@ def main():
         helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--_ref-helper', helper_path],
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE)
 
-    import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # Rehearsal of the N > 1 code path on a 1-GPU box (tools/rehearse_multirank.sh):
@@ -612,8 +611,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # torch 2.10+rocm7.0 bundles its own HIP runtime under the SAME soname as the image's ROCm 7.2
+    # (libamdhip64.so.7): once torch is imported, every HIP client of the process - this library
+    # too - runs on the bundled one, whose launch path costs 45 us per launch here instead of 3
+    # (tools/runtime_probe.py, profiles/r04_runtime_probe.jsonl: host issue 11.3 ms per device step
+    # instead of 0.8).  torch is plumbing for the N > 1 process group only, so the single-GPU run
+    # does not import it: its "barrier" has nobody to wait for and its device synchronisation is
+    # hipDeviceSynchronize through the C-ABI (od_hip_device_sync) - what torch.cuda.synchronize()
+    # calls.  N > 1 imports torch first, as before.
+    torch = None
     dist = None
+    if world > 1 or os.environ.get('BENCH_TORCH') == '1':     # BENCH_TORCH=1: A/B of the two runtimes at N = 1
+        import torch
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -628,6 +638,12 @@ def main():
     lib = b.load()                     # no fallback: raises if the HIP library is missing
     if lib.od_hip_device_count() <= local_rank:
         raise SystemExit('HIP device %d not available' % local_rank)
+
+    def device_sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+        elif lib.od_hip_device_sync(local_rank) != 0:
+            raise SystemExit('device synchronisation failed: %s' % lib.od_hip_last_error().decode())
     if args.device_only:
         frames = make_frames(FRAMES, seed0=1 + rank)
         ds, roofline = device_step(local_rank, frames, rank, args.device_steps, 2, args.skip_pvq, 1)
@@ -644,11 +660,11 @@ def main():
             step()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             nb, pk = step()
-        torch.cuda.synchronize()
+        device_sync()
         elapsed = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
@@ -722,11 +738,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nbytes, packets, st = step()
-    torch.cuda.synchronize()
+    device_sync()
     elapsed = time.perf_counter() - t0
     barrier()
     if dist is not None:
@@ -751,6 +767,9 @@ def main():
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed/args.steps*1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int32+f64', 'data': 'synthetic',
+            'sync': 'torch.cuda.synchronize' if torch is not None else
+                    'hipDeviceSynchronize (od_hip_device_sync): torch is not imported at N = 1, its bundled HIP runtime '
+                    'would replace the system one (DESIGN section 4)',
             'config': {'workload': '1920x1080 4:2:0 synthetic Y4M-shaped frames, 30 intra frames per '
                                    'step and GPU (BASELINE configs[1]), -v 20, complexity 7, activity '
                                    'masking on, deringing on; host frames in -> packets out',

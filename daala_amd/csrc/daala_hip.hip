@@ -1576,6 +1576,30 @@ int pvq_launch(od_hip_ctx *ctx, PvqCall &c, int nslots, bool gain_only) {
   }
   return 0;
 }
+// A level whose bands all have beta == 1 (everything with activity masking off; with it on: the
+// chroma planes and the 4x4 luma level) needs no libm: its gain launch already wrote cg = g/q0
+// and k_pvq_order builds the work lists - no transfer, no host stage.  OD_HIP_PVQ_DEV_COMPAND=0
+// sends those levels through the host stage as well (rounds 1-3; A/B).
+bool pvq_level_on_device(const od_hip_ctx *ctx, const double *beta, int nbands) {
+  static const int on = getenv("OD_HIP_PVQ_DEV_COMPAND") ? atoi(getenv("OD_HIP_PVQ_DEV_COMPAND")) : 1;
+  // strips (od_hip_set_strip) and unsorted lists keep the host stage, which writes identity lists
+  if (!on || ctx->strip0 != 0 || ctx->strip1 != ctx->nvsb || !pvq_sort_enabled()) return false;
+  for (int b = 0; b < nbands; b++) if (beta[b] != 1) return false;
+  return true;
+}
+
+// the work lists of every band of the level, on the context's stream (after its gain launch)
+int pvq_order_launch(od_hip_ctx *ctx, PvqCall &c, int nslots) {
+  if (c.a.blk_end <= c.a.blk_first) return 0;
+  PvqOrderArgs oa;
+  oa.a = c.a;
+  oa.nlist = c.a.nbands;
+  for (int b = 0; b < c.a.nbands; b++) oa.a.band_list[b] = b;
+  Timed tm(ctx, "k_pvq_order");
+  hipLaunchKernelGGL(k_pvq_order, dim3(c.a.nbands, nslots), dim3(PVQ_ORDER_THREADS), 0, ctx->stream, oa);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 }  // namespace
 
 // Measurement: enable = 1 allocates/zeroes three device counters that every following search
@@ -1635,6 +1659,9 @@ int od_hip_pvq_compand_level(od_hip_ctx *ctx, int slot0, int nslots, int pli, in
   // only the strip's records travel: [band][blk_first, blk_end) of every slot
   const long first = c.a.blk_first, count = c.a.blk_end - c.a.blk_first;
   if (count <= 0) return 0;
+  if (pvq_level_on_device(ctx, beta, c.a.nbands)) {
+    return pvq_order_launch(ctx, c, nslots);        // cg is there since the gain launch: nothing crosses PCIe
+  }
   const size_t per = (size_t)count, tot = (size_t)nslots*c.a.nbands*per;
   std::vector<double> g(tot), cg(tot);
   for (int s = 0; s < nslots; s++) {
@@ -2213,6 +2240,13 @@ int od_hip_host_register(void *ptr, size_t bytes) {
 int od_hip_host_unregister(void *ptr) {
   if (!ptr) return fail(OD_HIP_EFAULT, "null pointer");
   HIPCHK(hipHostUnregister(ptr));
+  return 0;
+}
+
+int od_hip_device_sync(int device) {
+  if (int rc = ensure_device()) return rc;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());
   return 0;
 }
 

@@ -172,6 +172,18 @@ int od_hip_enc_feed_gains(od_hip_enc_feed *f, int slot0, int nslots) {
     }
   }
   HIPCHK(hipEventRecord(f->gains_done, ctx->stream));
+  // Levels whose bands all have beta == 1 need nothing from the host: their gain launch wrote
+  // cg = g/q0, the work lists are built on the device and the searches start right here - they
+  // run while the host compands the other levels (masking off: every level, no host stage at all).
+  for (int p = 0; p < 3; p++) {
+    if (!f->P[p].on) continue;
+    for (int l = 0; l < ctx->nlev[p]; l++) {
+      auto &L = f->P[p].lev[l];
+      if (!pvq_level_on_device(ctx, L.beta, ctx->arena[p].lev[l].nb)) continue;
+      if (int rc = od_hip_pvq_compand_level(ctx, slot0, nslots, p, l, L.q, L.beta)) return rc;
+      if (int rc = od_hip_pvq_search(ctx, slot0, nslots, p, l, L.qm.data(), L.q, L.beta)) return rc;
+    }
+  }
   HIPCHK(hipStreamWaitEvent(f->up, f->gains_done, 0));
   for (int s = slot0; s < slot0 + nslots; s++) {
     for (int p = 0; p < 3; p++) {
@@ -208,16 +220,23 @@ int od_hip_enc_feed_compand(od_hip_enc_feed *f, int slot) {
       const int per_sb = (32 >> ctx->geo.xdec[p])/Y.n;
       const long nbx = ctx->pw[p]/Y.n;
       const long first = (long)ctx->strip0*per_sb*nbx, count = (long)(ctx->strip1 - ctx->strip0)*per_sb*nbx;
+      const bool on_device = pvq_level_on_device(ctx, L.beta, Y.nb);
       for (int b = 0; b < Y.nb; b++) {
         const int q0 = L.q[b];
         const double beta = L.beta[b];
         const size_t o = (size_t)b*Y.nblk + first;
         for (long i = 0; i < count; i++) cg[o + i] = host_gain_compand(g[o + i], q0, beta);
-        pvq_block_order(cg + o, first, count, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
+        // a level the device companded itself: the host keeps cg (the same quotient g/q0) for
+        // the consumer of the feed; the work list exists on the device already
+        if (!on_device) pvq_block_order(cg + o, first, count, Y.off[b + 1] - Y.off[b], beta, pvq_sort_enabled(), perm + 2*o);
+      }
+      // one transfer per level that went through the host: its companded gains and work lists
+      if (!on_device) {
+        const size_t bytes = Y.o_perm + 2*Y.nrec*4 - Y.o_cg;
+        HIPCHK(hipMemcpyAsync(A.in + (size_t)slot*A.in_slot + Y.o_cg, Q.h_in + (size_t)slot*A.in_slot + Y.o_cg, bytes,
+                              hipMemcpyHostToDevice, f->up));
       }
     }
-    HIPCHK(hipMemcpyAsync(A.in + (size_t)slot*A.in_slot, Q.h_in + (size_t)slot*A.in_slot, A.in_slot,
-                          hipMemcpyHostToDevice, f->up));
   }
   HIPCHK(hipEventRecord(f->cgup[slot], f->up));
   f->companded[slot] = 1;
@@ -237,6 +256,7 @@ int od_hip_enc_feed_search(od_hip_enc_feed *f, int slot0, int nslots) {
     if (!f->P[p].on) continue;
     for (int l = 0; l < ctx->nlev[p]; l++) {
       auto &L = f->P[p].lev[l];
+      if (pvq_level_on_device(ctx, L.beta, ctx->arena[p].lev[l].nb)) continue;     // searched since od_hip_enc_feed_gains
       if (int rc = od_hip_pvq_search(ctx, slot0, nslots, p, l, L.qm.data(), L.q, L.beta)) return rc;
     }
   }

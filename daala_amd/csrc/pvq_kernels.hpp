@@ -728,8 +728,110 @@ __global__ __launch_bounds__(64) void k_pvq_gain(PvqLevelArgs3 aa) {
   const double acc = pvq_chain_sum<N>(g, lane, [&](int j) {
     return cf[j]*(double)cf[j]*qi[j]*PVQ_QM_SCALE_1*qi[j]*PVQ_QM_SCALE_1;
   });
-  if (live && g == 0) a.out.g[(size_t)f*a.out.fs_g + (size_t)band*nblk + blk] = sqrt(acc);
+  if (live && g == 0) {
+    const double gain = sqrt(acc);
+    a.out.g[(size_t)f*a.out.fs_g + (size_t)band*nblk + blk] = gain;
+    // beta == 1: od_gain_compand is g/q0 (src/pvq.c:423), one exactly rounded division - the
+    // companded gain needs no libm and no host (the host computes the same quotient for its own
+    // use); k_pvq_order then builds the band's work list on the device
+    if (a.beta[band] == 1) a.out.cg[(size_t)f*a.out.fs_cg + (size_t)band*nblk + blk] = gain/a.q[band];
+  }
 }
+
+// Work list of a band whose companded gains were computed on the device (beta == 1): the
+// counting sort of pvq_block_order (daala_hip.hip) - entries 2*block + candidate by descending K
+// - as one workgroup per (band, frame).  Performance only: any permutation of the entries is a
+// correct list, so the order inside a K class (atomic cursors) need not be reproducible.
+struct PvqOrderArgs {
+  PvqLevelArgs a;
+  int nlist;
+};
+
+#define PVQ_ORDER_THREADS 1024
+// adds `n` to LDS counter `ctr[key]` for every lane of the wave, one atomic per distinct key of
+// the wave (most lanes of a wave share a key: a plain per-lane atomic would serialise on one
+// address); returns the lane's own slot (the counter's value before + its rank among the lanes
+// of its key)
+__device__ __forceinline__ int pvq_order_take(int *ctr, int key, bool active) {
+  int slot = 0;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int k = __shfl(key, leader, 64);
+    const unsigned long long same = __ballot(active && key == k);
+    int base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&ctr[k], __popcll(same));
+    base = __shfl(base, leader, 64);
+    if (active && key == k) slot = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+__global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order(PvqOrderArgs aa) {
+  const PvqLevelArgs &a = aa.a;
+  __shared__ int hist[257];
+  const int t = threadIdx.x;
+  const int band = a.band_list[blockIdx.x], f = blockIdx.y;
+  const long nblk = (long)a.nbx*a.nby;
+  const long first = a.blk_first, count = a.blk_end - a.blk_first;
+  const int n = a.off[band + 1] - a.off[band];
+  const double beta = a.beta[band];
+  const double sq = sqrt((double)((n + 3)/2));
+  const double *cg = a.out.cg + (size_t)f*a.out.fs_cg + (size_t)band*nblk;
+  int32_t *perm = const_cast<int32_t *>(a.out.perm) + (size_t)f*a.out.fs_perm + (size_t)band*2*nblk;
+  auto key_of = [&](double c, int cand) -> int {
+    const double lo = floor(c) < 1 ? 1 : floor(c), hi = ceil(c);
+    const double q = lo + cand;
+    int k = 0;
+    if (q <= hi) {
+      if (n == 15 && q == 1 && beta > 1.25) k = 1;
+      else {
+        const double v = floor(.5 + (q - .2)*sq/beta);
+        k = v < 1 ? 1 : v > 255 ? 255 : (int)v;
+      }
+    }
+    return 255 - k;
+  };
+  if (t < 257) hist[t] = 0;
+  __syncthreads();
+  const long rounds = (count + PVQ_ORDER_THREADS - 1)/PVQ_ORDER_THREADS;
+  for (long r = 0; r < rounds; r++) {
+    const long i = r*PVQ_ORDER_THREADS + t;
+    const bool on = i < count;
+    const double c = on ? cg[first + i] : 0;
+    (void)pvq_order_take(hist, key_of(c, 0), on);
+    (void)pvq_order_take(hist, key_of(c, 1), on);
+  }
+  __syncthreads();
+  // exclusive scan of the 256 bins: one wave, 4 bins per lane
+  if (t < 64) {
+    int v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { v[q] = hist[4*t + q]; sum += v[q]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (t >= o) inc += up;
+    }
+    int run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { hist[4*t + q] = run; run += v[q]; }
+  }
+  __syncthreads();
+  for (long r = 0; r < rounds; r++) {
+    const long i = r*PVQ_ORDER_THREADS + t;
+    const bool on = i < count;
+    const double c = on ? cg[first + i] : 0;
+#pragma unroll
+    for (int cand = 0; cand < 2; cand++) {
+      const int pos = pvq_order_take(hist, key_of(c, cand), on);
+      if (on) perm[2*first + pos] = (int32_t)(2*(first + i) + cand);
+    }
+  }
+}
+
 
 // The searches: one lane group per CANDIDATE (round 2: per band, its two gain candidates one
 // after the other).  The host's companding stage knows cg of every band, hence which

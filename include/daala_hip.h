@@ -35,7 +35,7 @@
  *   DRIVER - the device-only path of bench.py and the multi-GPU drivers: od_hip_forward_known,
  *     od_hip_inverse, od_hip_pvq_gains / _compand_level / _search / _noref_search / _nblocks /
  *     _download / _stats, od_hip_enc_feed_run / _refresh, od_hip_set_strip, od_hip_comm_*,
- *     od_hip_gather_strips, od_hip_strip_bytes / _export / _import, od_hip_sync,
+ *     od_hip_gather_strips, od_hip_strip_bytes / _export / _import, od_hip_sync, od_hip_device_sync,
  *     od_hip_timing_reset / _get, od_hip_calibrate_traffic, od_hip_version.
  *   VECTOR - dense batches on host memory, the form the reference's own tools and unit tests
  *     use (dcttest, filter.c -DTEST, test_coef_coder); they exist for PARITY TESTS and are bound
@@ -675,6 +675,8 @@ int od_hip_host_unregister(void *ptr);
 
 /* Synchronise the context's stream / time its last batch (ms, HIP events). */
 int od_hip_sync(od_hip_ctx *ctx);
+/* hipDeviceSynchronize on `device`: every stream of every object of this process on it. */
+int od_hip_device_sync(int device);
 
 /* Kernel timing hooks for bench.py: HIP events recorded on the context's own
  * stream around every launch of the named kernel since the last reset.
