@@ -121,11 +121,14 @@ def main():
         'decode_reference_s': round(s0, 3), 'decode_seam_s': round(s1, 3),
         'mc_frames_on_device_in_decode': int(frames_dev), 'mc_check_fail': int(bad),
         'tail_frames_on_device_in_decode': int(tail), 'prediction_transforms_from_device_pyramid': int(md_hits),
+        'references_resident_on_device_in_decode': int(H.ref_resident_frames()),
+        'mv_est_calc_sads_device_calls': int(st.mv_dev_calls), 'mv_est_block_sads_on_device': int(st.mv_dev_sads),
+        'mv_est_seconds_per_P_frame': round(st.mv_stage_s[7]/max(1, nf - 1), 4),
+        'decode_seam_ms_per_frame': round(1e3*s1/nf, 2), 'decode_reference_ms_per_frame': round(1e3*s0/nf, 2),
         'what': 'P frames: od_state_mc_predict (OBMC, all planes) on the device in both seams; decoder: '
                 'forward pyramid of the prediction and the whole pixel-domain stage on the device too; '
-                'encoder: deringing and its distortions on the device, own PVQ path + vector-unit '
-                'motion-search leaves on the host; od_mv_est (EPZS + DP refinement, src/mcenc.c) stays '
-                'the reference host code and dominates'}
+                'encoder: deringing and its distortions on the device, P-frame feed, od_mv_est_calc_sads as one '
+                'fused OBMC + SAD call per frame; EPZS and the DP refinement of od_mv_est stay reference host code'}
     print('configs[3]', res['configs3_inter_1080p'], file=sys.stderr, flush=True)
 
     # configs[4]: lossless
