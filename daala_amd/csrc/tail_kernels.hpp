@@ -312,6 +312,12 @@ __device__ __forceinline__ void tail_border_copy(TailShared &S, int lane) {
   }
 }
 
+// p when -t < p < t, else 0; tb = t - 1, tl = 2 t - 1 (0 when t = 0).  |p| <= 65535 and t is a
+// filter threshold (< 2^16): no wrap.
+__device__ __forceinline__ int tail_in_range(int p, int tb, unsigned tl) {
+  return (unsigned)(p + tb) < tl ? p : 0;
+}
+
 // One plane of one superblock.  LN = 5: 32x32 samples (luma, 4:4:4 chroma), LN = 4: 16x16.
 // A lane owns the samples e = lane + 64 r: column j = lane & (n - 1), rows (64 >> LN) apart.
 template <int LN, bool PRE>
@@ -411,6 +417,8 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     for (int rb = 0; rb < 4; rb++) {
       const int blk = rb*4 + bcol;
       const int th = S.thresh[blk];
+      const int tb = th - 1;
+      const unsigned tl = th > 0 ? 2u*(unsigned)th - 1u : 0u;
       const int off0 = S.doff[blk*3], off1 = S.doff[blk*3 + 1], off2 = S.doff[blk*3 + 2];
 #pragma unroll
       for (int k = 0; k < PER_BROW; k++) {
@@ -418,16 +426,12 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         const int i = r*RSTEP + i0;
         const int16_t *c = in + i*TAIL_BSTRIDE + j;
         const int xx = c[0];
-        int sum = 0, p0, p1;
-        p0 = c[off0] - xx;  p1 = c[-off0] - xx;
-        if (abs(p0) < th) sum += 3*p0;
-        if (abs(p1) < th) sum += 3*p1;
-        p0 = c[off1] - xx;  p1 = c[-off1] - xx;
-        if (abs(p0) < th) sum += 2*p0;
-        if (abs(p1) < th) sum += 2*p1;
-        p0 = c[off2] - xx;  p1 = c[-off2] - xx;
-        if (abs(p0) < th) sum += 2*p0;
-        if (abs(p1) < th) sum += 2*p1;
+        // "if (abs(p) < th) sum += tap*p" (src/filter.c:1731-1736) as one unsigned range test:
+        // -th < p < th  <=>  (unsigned)(p + th - 1) < 2 th - 1 (th = 0: the bound is 0, never true)
+        const int a0 = tail_in_range(c[off0] - xx, tb, tl) + tail_in_range(c[-off0] - xx, tb, tl);
+        const int a1 = tail_in_range(c[off1] - xx, tb, tl) + tail_in_range(c[-off1] - xx, tb, tl)
+                     + tail_in_range(c[off2] - xx, tb, tl) + tail_in_range(c[-off2] - xx, tb, tl);
+        const int sum = 3*a0 + 2*a1;
         S.in1[(i + 3)*TAIL_BSTRIDE + j + 3] = (int16_t)(xx + ((sum + 8) >> 4));
       }
     }
@@ -438,7 +442,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
       const int blk = rb*4 + bcol;
-      const int th = S.thresh[blk];
+      const int th = S.thresh[blk], th3 = th/3;
       const int offset = S.dirs[blk] <= 4 ? TAIL_BSTRIDE : 1;
 #pragma unroll
       for (int k = 0; k < PER_BROW; k++) {
@@ -446,13 +450,12 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         const int i = r*RSTEP + i0;
         const int16_t *c = inf + i*TAIL_BSTRIDE + j;
         const int yy = c[0];
-        int athresh = th/3 + abs(yy - in[i*TAIL_BSTRIDE + j]);
+        int athresh = th3 + abs(yy - in[i*TAIL_BSTRIDE + j]);
         athresh = th < athresh ? th : athresh;
-        int sum = 0, p;
-        p = c[offset] - yy;    if (abs(p) < athresh) sum += p;
-        p = c[-offset] - yy;   if (abs(p) < athresh) sum += p;
-        p = c[2*offset] - yy;  if (abs(p) < athresh) sum += p;
-        p = c[-2*offset] - yy; if (abs(p) < athresh) sum += p;
+        const int ab = athresh - 1;
+        const unsigned al = athresh > 0 ? 2u*(unsigned)athresh - 1u : 0u;
+        const int sum = tail_in_range(c[offset] - yy, ab, al) + tail_in_range(c[-offset] - yy, ab, al)
+                      + tail_in_range(c[2*offset] - yy, ab, al) + tail_in_range(c[-2*offset] - yy, ab, al);
         o[r] = (int16_t)(yy + ((3*sum + 8) >> 4));
       }
     }

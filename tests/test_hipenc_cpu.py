@@ -456,3 +456,24 @@ def test_host_vector_transforms_equal_reference():
             fh(za.ctypes.data_as(I32P), n, za.ctypes.data_as(I32P), n)
             fr(zb.ctypes.data_as(I32P), n, zb.ctypes.data_as(I32P), n)
             assert np.array_equal(za, zb), ('in place', n, trial)
+
+
+def test_motion_search_stage_timers_and_host_path():
+    """The build recipe pipes src/mcenc.c through the same rebinding as encode.c (mcenc_head.h /
+    mcenc_tail.c).  Without a device od_mv_est_calc_sads runs the reference's own loop - packets equal
+    the pure reference encoder's - and the stage timers account for od_mv_est: every stage measured,
+    their sum below the whole, no device call counted."""
+    w, h, nf = 96, 64, 4
+    want, rec = inter_stream(w, h, nf, keyrate=4)
+    base = [synth_plane(w + 64, h + 64, 31), synth_plane(w//2 + 32, h//2 + 32, 32, 1),
+            synth_plane(w//2 + 32, h//2 + 32, 33, 1)]
+    frames = [[base[0][2*f:2*f + h, 3*f:3*f + w], base[1][f:f + h//2, (3*f)//2:(3*f)//2 + w//2],
+               base[2][f:f + h//2, (3*f)//2:(3*f)//2 + w//2]] for f in range(nf)]
+    buf = H.pack_frames(frames, w, h)
+    prm = H.Params(w, h, 20, 7, 1, 1, 0, 0, 4)
+    n, pk, st = H.encode(prm, buf, nf)
+    assert n > 0 and pk == want
+    s = list(st.mv_stage_s)
+    assert s[7] > 0 and s[0] > 0 and s[2] > 0 and s[6] > 0          # whole, EPZS, calc_sads, sub-pel
+    assert sum(s[:5]) + s[6] <= s[7]*1.001                            # the refinement loop is the rest
+    assert st.mv_dev_calls == 0 and st.mv_dev_sads == 0 and st.mv_check_fail == 0

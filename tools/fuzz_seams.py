@@ -59,6 +59,8 @@ def main():
     ap.add_argument('--no-device', action='store_true', help='dry run on a CPU-only box')
     ap.add_argument('--only', type=int, nargs='*', default=None, help='run only these case numbers (same draws)')
     ap.add_argument('--inter', action='store_true', help='inter streams only (keyframe rate 2...8, 3-6 frames)')
+    ap.add_argument('--inter-long', action='store_true',
+                    help='inter streams of 11-14 frames, keyframe rate 4 / 12 / 30: golden P frames and second keyframes occur')
     a = ap.parse_args()
     import daala_amd.hipenc as H
     import configs_round as C
@@ -73,6 +75,9 @@ def main():
         cx = int(rng.choice([0, 2, 7, 7, 10]))
         keyrate = int(rng.choice([2, 3, 4, 8])) if a.inter else int(rng.choice([1, 1, 1, 3]))
         nf = int(rng.integers(3, 7)) if a.inter else int(rng.integers(2, 5))
+        if a.inter_long:
+            keyrate = int(rng.choice([4, 12, 30]))
+            nf = int(rng.integers(11, 15))
         kind = str(rng.choice(['synth', 'noise', 'flat', 'bilevel', 'moving']))
         frames = content(rng, kind, w, h, nf)
         workers_draw = int(rng.integers(1, 4))
@@ -100,13 +105,15 @@ def main():
         ok = (n > 0 and got == want and st.check_fail == 0 and st.pvq_check_fail == 0 and (st.lost_sync == 0 or keyrate > 1)
               and st.g2_mismatch == 0 and st.fdct_check_fail == 0 and st.dering_check_fail == 0
               and st.dist_check_fail == 0 and nd0 == nf and nd1 == nf and np.array_equal(p0, p1)
-              and mcbad == 0 and mdbad == 0 and dsbad == 0 and nd2 == nf and np.array_equal(p0, p2))
+              and mcbad == 0 and mdbad == 0 and dsbad == 0 and nd2 == nf and np.array_equal(p0, p2)
+              and st.mv_check_fail == 0)
         print('case %2d: %3dx%-3d q=%-3d masking=%d complexity=%-2d keyrate=%d frames=%d workers=%d %-8s %s (bytes %d)'
               % (case, w, h, q, m, cx, keyrate, nf, workers, kind, 'ok' if ok else 'MISMATCH', n), flush=True)
         if not ok:
-            print('   encode: n %d packets_equal %s first_bad_packet %s check_fail %d pvq_check_fail %d lost_sync %d g2 %d fdct %d dering %d dist %d'
+            print('   encode: n %d packets_equal %s first_bad_packet %s check_fail %d pvq_check_fail %d lost_sync %d g2 %d fdct %d dering %d dist %d mv %d'
                   % (n, got == want, next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), None), st.check_fail,
-                     st.pvq_check_fail, st.lost_sync, st.g2_mismatch, st.fdct_check_fail, st.dering_check_fail, st.dist_check_fail))
+                     st.pvq_check_fail, st.lost_sync, st.g2_mismatch, st.fdct_check_fail, st.dering_check_fail, st.dist_check_fail,
+                     st.mv_check_fail))
             print('   decode: host %d check-mode %d (pictures equal %s) mc_bad %d md_bad %d synth_bad %d; no check %d (pictures equal %s)'
                   % (nd0, nd1, np.array_equal(p0, p1), mcbad, mdbad, dsbad, nd2, np.array_equal(p0, p2)))
         bad += not ok

@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""Diagnostic for tests/test_gpu_hipenc.py::test_inter_gop_golden_frames_and_second_keyframe: the
+33-frame GOP stream through the encoder seam with the device stages switched off one at a time
+(HIPENC_MV_SADS, HIPENC_PFEED), check mode on and off; prints which packets differ from the pure
+reference build and every check counter.  GPU box only."""
 import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import hipenc_lib as H
 from test_hipenc_cpu import inter_stream_frames
