@@ -238,6 +238,13 @@ class McSad(object):
             _chk(lib.od_hip_mc_set_src(self.h, pli, sp.ctypes.data_as(U8P), sp.shape[1], sp.shape[1], sp.shape[0],
                                        int(dec[pli][0]), int(dec[pli][1])))
 
+    def set_ref_ctx(self, pli, k, ctx, slot, ref_stride, ref_h, org_x, org_y):
+        """od_hip_mc_set_ref_ctx: reference image k of plane pli from the reconstruction plane of
+        a DaalaHip context's slot, padded on the device."""
+        self.lib.od_hip_mc_set_ref_ctx.argtypes = [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p, c_int, c_int,
+                                                   c_int, c_int, c_int]
+        _chk(self.lib.od_hip_mc_set_ref_ctx(self.h, pli, k, ctx.ctx, slot, ref_stride, ref_h, org_x, org_y))
+
     def sad_items(self, items, pic_w, pic_h, nplanes=None):
         it = np.ascontiguousarray(items, dtype=self.ITEM)
         out = np.zeros(len(it), np.int32)

@@ -202,6 +202,7 @@ struct od_hip_ctx {
   int strip0 = 0, strip1 = 0;
   unsigned long long *pvq_stats = nullptr;   // od_hip_pvq_stats: device work counters (measurement)
   struct StripCache *strips = nullptr;       // comm.hpp: segment lists and the staging buffer of strip transfers
+  int *order_scratch = nullptr;              // k_pvq_order_*: [2][slot][band][256] key histograms and cursors
 };
 static void strip_cache_free(od_hip_ctx *ctx);   // comm.hpp
 
@@ -1100,6 +1101,7 @@ void od_hip_ctx_destroy(od_hip_ctx *ctx) {
   }
   for (int b = 0; b < 4; b++) if (ctx->tab[b]) (void)hipFree(ctx->tab[b]);
   if (ctx->pvq_stats) (void)hipFree(ctx->pvq_stats);
+  if (ctx->order_scratch) (void)hipFree(ctx->order_scratch);
   strip_cache_free(ctx);
   if (ctx->bsize) (void)hipFree(ctx->bsize);
   if (ctx->dflags) (void)hipFree(ctx->dflags);
@@ -1588,15 +1590,25 @@ bool pvq_level_on_device(const od_hip_ctx *ctx, const double *beta, int nbands) 
   return true;
 }
 
-// the work lists of every band of the level, on the context's stream (after its gain launch)
+// the work lists of every band of the level, on the context's stream (after its gain launch):
+// count pass, scatter pass (pvq_kernels.hpp); the (frame, band) histograms and cursors live in a
+// small per-context scratch that every level reuses in stream order
 int pvq_order_launch(od_hip_ctx *ctx, PvqCall &c, int nslots) {
-  if (c.a.blk_end <= c.a.blk_first) return 0;
+  const long count = c.a.blk_end - c.a.blk_first;
+  if (count <= 0) return 0;
+  const size_t ints = (size_t)ctx->geo.nslots*10*256;
+  if (!ctx->order_scratch) HIPCHK(hipMalloc((void **)&ctx->order_scratch, 2*ints*sizeof(int)));
   PvqOrderArgs oa;
   oa.a = c.a;
   oa.nlist = c.a.nbands;
+  oa.gh = ctx->order_scratch;
+  oa.gc = ctx->order_scratch + ints;
   for (int b = 0; b < c.a.nbands; b++) oa.a.band_list[b] = b;
+  HIPCHK(hipMemsetAsync(ctx->order_scratch, 0, 2*ints*sizeof(int), ctx->stream));
+  const dim3 grid((unsigned)((count + PVQ_ORDER_CHUNK - 1)/PVQ_ORDER_CHUNK), c.a.nbands, nslots);
   Timed tm(ctx, "k_pvq_order");
-  hipLaunchKernelGGL(k_pvq_order, dim3(c.a.nbands, nslots), dim3(PVQ_ORDER_THREADS), 0, ctx->stream, oa);
+  hipLaunchKernelGGL(k_pvq_order_count, grid, dim3(PVQ_ORDER_THREADS), 0, ctx->stream, oa);
+  hipLaunchKernelGGL(k_pvq_order_scatter, grid, dim3(PVQ_ORDER_THREADS), 0, ctx->stream, oa);
   HIPCHK(hipGetLastError());
   return 0;
 }

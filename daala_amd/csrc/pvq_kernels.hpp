@@ -740,75 +740,112 @@ __global__ __launch_bounds__(64) void k_pvq_gain(PvqLevelArgs3 aa) {
 
 // Work list of a band whose companded gains were computed on the device (beta == 1): the
 // counting sort of pvq_block_order (daala_hip.hip) - entries 2*block + candidate by descending K
-// - as one workgroup per (band, frame).  Performance only: any permutation of the entries is a
+// - in two passes of one workgroup per (chunk of blocks, band, frame).  Performance only: any permutation of the entries is a
 // correct list, so the order inside a K class (atomic cursors) need not be reproducible.
 struct PvqOrderArgs {
   PvqLevelArgs a;
   int nlist;
+  int *gh, *gc;          // [frame][band][256]: key histogram, reservation cursors (zeroed before the launch)
 };
 
-#define PVQ_ORDER_THREADS 1024
-// adds `n` to LDS counter `ctr[key]` for every lane of the wave, one atomic per distinct key of
-// the wave (most lanes of a wave share a key: a plain per-lane atomic would serialise on one
-// address); returns the lane's own slot (the counter's value before + its rank among the lanes
-// of its key)
+#define PVQ_ORDER_THREADS 256
+#define PVQ_ORDER_CHUNK 4096        /* blocks per workgroup */
+// Takes one slot of LDS counter ctr[key] for every active lane and returns the lane's slot.  The
+// three most common keys of the wave are served by ONE atomic each (leader adds the population
+// count, lanes rank themselves by ballot): in the short-band levels most lanes of a wave share a
+// key and a per-lane atomic would serialise on one address.  Whatever is left - the long bands'
+// K are spread over the whole range - takes plain per-lane atomics, which only collide by chance.
 __device__ __forceinline__ int pvq_order_take(int *ctr, int key, bool active) {
+  const int lane = threadIdx.x & 63;
   int slot = 0;
   unsigned long long todo = __ballot(active);
-  while (todo) {
+#pragma unroll 1
+  for (int it = 0; it < 3 && todo; it++) {
     const int leader = __ffsll((long long)todo) - 1;
     const int k = __shfl(key, leader, 64);
-    const unsigned long long same = __ballot(active && key == k);
+    const unsigned long long same = __ballot(active && key == k) & todo;
     int base = 0;
-    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&ctr[k], __popcll(same));
+    if (lane == leader) base = atomicAdd(&ctr[k], __popcll(same));
     base = __shfl(base, leader, 64);
-    if (active && key == k) slot = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1));
+    if ((same >> lane) & 1) slot = base + __popcll(same & ((1ull << lane) - 1));
     todo &= ~same;
   }
+  if ((todo >> lane) & 1) slot = atomicAdd(&ctr[key], 1);
   return slot;
 }
 
-__global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order(PvqOrderArgs aa) {
-  const PvqLevelArgs &a = aa.a;
-  __shared__ int hist[257];
-  const int t = threadIdx.x;
-  const int band = a.band_list[blockIdx.x], f = blockIdx.y;
-  const long nblk = (long)a.nbx*a.nby;
-  const long first = a.blk_first, count = a.blk_end - a.blk_first;
-  const int n = a.off[band + 1] - a.off[band];
-  const double beta = a.beta[band];
-  const double sq = sqrt((double)((n + 3)/2));
-  const double *cg = a.out.cg + (size_t)f*a.out.fs_cg + (size_t)band*nblk;
-  int32_t *perm = const_cast<int32_t *>(a.out.perm) + (size_t)f*a.out.fs_perm + (size_t)band*2*nblk;
-  auto key_of = [&](double c, int cand) -> int {
-    const double lo = floor(c) < 1 ? 1 : floor(c), hi = ceil(c);
-    const double q = lo + cand;
-    int k = 0;
-    if (q <= hi) {
-      if (n == 15 && q == 1 && beta > 1.25) k = 1;
-      else {
-        const double v = floor(.5 + (q - .2)*sq/beta);
-        k = v < 1 ? 1 : v > 255 ? 255 : (int)v;
-      }
+// sort key of candidate `cand` of a band with companded gain c: 255 - K (descending K), K as
+// od_pvq_compute_k (src/pvq.c:508-514) clamped to a byte - the key function of pvq_block_order
+// (sqb = sqrt((n + 3)/2)/beta: the list is performance only, so the quotient may be formed once)
+__device__ __forceinline__ int pvq_order_key(double c, int cand, int n, double beta, double sqb) {
+  const double fl = floor(c);
+  const double lo = fl < 1 ? 1 : fl, hi = ceil(c);
+  const double q = lo + cand;
+  int k = 0;
+  if (q <= hi) {
+    if (n == 15 && q == 1 && beta > 1.25) k = 1;
+    else {
+      const double v = floor(.5 + (q - .2)*sqb);
+      k = v < 1 ? 1 : v > 255 ? 255 : (int)v;
     }
-    return 255 - k;
-  };
-  if (t < 257) hist[t] = 0;
+  }
+  return 255 - k;
+}
+
+// Pass 1: every workgroup counts the keys of its chunk of blocks (LDS, wave-aggregated) and adds
+// them to the (frame, band) histogram gh[(f*nbands + band)*256 + key].
+__global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order_count(PvqOrderArgs aa) {
+  const PvqLevelArgs &a = aa.a;
+  __shared__ int hist[256];
+  const int t = threadIdx.x;
+  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
+  const long nblk = (long)a.nbx*a.nby;
+  const long first = a.blk_first + (long)blockIdx.x*PVQ_ORDER_CHUNK;
+  const long end = first + PVQ_ORDER_CHUNK < a.blk_end ? first + PVQ_ORDER_CHUNK : a.blk_end;
+  if (first >= end) return;
+  const int n = a.off[band + 1] - a.off[band];
+  const double beta = a.beta[band], sq = sqrt((double)((n + 3)/2))/beta;
+  const double *cg = a.out.cg + (size_t)f*a.out.fs_cg + (size_t)band*nblk;
+  hist[t] = 0;
   __syncthreads();
-  const long rounds = (count + PVQ_ORDER_THREADS - 1)/PVQ_ORDER_THREADS;
-  for (long r = 0; r < rounds; r++) {
-    const long i = r*PVQ_ORDER_THREADS + t;
-    const bool on = i < count;
-    const double c = on ? cg[first + i] : 0;
-    (void)pvq_order_take(hist, key_of(c, 0), on);
-    (void)pvq_order_take(hist, key_of(c, 1), on);
+  for (long i0 = first; i0 < end; i0 += PVQ_ORDER_THREADS) {
+    const long i = i0 + t;
+    const bool on = i < end;
+    const double c = on ? cg[i] : 0;
+    (void)pvq_order_take(hist, pvq_order_key(c, 0, n, beta, sq), on);
+    (void)pvq_order_take(hist, pvq_order_key(c, 1, n, beta, sq), on);
   }
   __syncthreads();
-  // exclusive scan of the 256 bins: one wave, 4 bins per lane
+  if (hist[t]) atomicAdd(&aa.gh[((size_t)f*a.nbands + band)*256 + t], hist[t]);
+}
+
+// Pass 2: the workgroup turns the (frame, band) histogram into bin bases (exclusive scan),
+// reserves its chunk's share of every bin (one atomic per non-empty bin on the cursors gc) and
+// scatters its entries.  Which chunk comes first inside a bin is left to the atomics: any
+// permutation of a K class is a correct list.
+__global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order_scatter(PvqOrderArgs aa) {
+  const PvqLevelArgs &a = aa.a;
+  __shared__ int hist[256];
+  __shared__ int base[256];
+  const int t = threadIdx.x;
+  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
+  const long nblk = (long)a.nbx*a.nby;
+  const long first = a.blk_first + (long)blockIdx.x*PVQ_ORDER_CHUNK;
+  const long end = first + PVQ_ORDER_CHUNK < a.blk_end ? first + PVQ_ORDER_CHUNK : a.blk_end;
+  if (first >= end) return;
+  const int n = a.off[band + 1] - a.off[band];
+  const double beta = a.beta[band], sq = sqrt((double)((n + 3)/2))/beta;
+  const double *cg = a.out.cg + (size_t)f*a.out.fs_cg + (size_t)band*nblk;
+  int32_t *perm = const_cast<int32_t *>(a.out.perm) + (size_t)f*a.out.fs_perm + (size_t)band*2*nblk + 2*a.blk_first;
+  const size_t gb = ((size_t)f*a.nbands + band)*256;
+  hist[t] = 0;
+  base[t] = aa.gh[gb + t];
+  __syncthreads();
+  // exclusive scan of the 256 global bins: one wave, 4 bins per lane
   if (t < 64) {
     int v[4], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { v[q] = hist[4*t + q]; sum += v[q]; }
+    for (int q = 0; q < 4; q++) { v[q] = base[4*t + q]; sum += v[q]; }
     int inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -817,17 +854,42 @@ __global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order(PvqOrderArgs aa
     }
     int run = inc - sum;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { hist[4*t + q] = run; run += v[q]; }
+    for (int q = 0; q < 4; q++) { base[4*t + q] = run; run += v[q]; }
+  }
+  // the keys of this thread's entries, two bytes per round, kept for the scatter below
+  constexpr int ROUNDS = PVQ_ORDER_CHUNK/PVQ_ORDER_THREADS;
+  uint32_t keys[ROUNDS/2];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const long i = first + (long)r*PVQ_ORDER_THREADS + t;
+    const bool on = i < end;
+    const double c = on ? cg[i] : 0;
+    const int k0 = pvq_order_key(c, 0, n, beta, sq), k1 = pvq_order_key(c, 1, n, beta, sq);
+    (void)pvq_order_take(hist, k0, on);
+    (void)pvq_order_take(hist, k1, on);
+    const uint32_t pair = (uint32_t)k0 | (uint32_t)k1 << 8;
+    if (r & 1) keys[r >> 1] |= pair << 16;
+    else keys[r >> 1] = pair;
   }
   __syncthreads();
-  for (long r = 0; r < rounds; r++) {
-    const long i = r*PVQ_ORDER_THREADS + t;
-    const bool on = i < count;
-    const double c = on ? cg[first + i] : 0;
+  // this chunk's slice of bin t starts at base[t] + (what earlier reservations took)
+  {
+    const int mine = hist[t];
+    int start = base[t];
+    if (mine) start += atomicAdd(&aa.gc[gb + t], mine);
+    __syncthreads();
+    hist[t] = start;               // from here on: the chunk's write cursor of bin t
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const long i = first + (long)r*PVQ_ORDER_THREADS + t;
+    const bool on = i < end;
+    const uint32_t pair = keys[r >> 1] >> (16*(r & 1));
 #pragma unroll
     for (int cand = 0; cand < 2; cand++) {
-      const int pos = pvq_order_take(hist, key_of(c, cand), on);
-      if (on) perm[2*first + pos] = (int32_t)(2*(first + i) + cand);
+      const int pos = pvq_order_take(hist, (int)((pair >> (8*cand)) & 255), on);
+      if (on) perm[pos] = (int32_t)(2*i + cand);
     }
   }
 }

@@ -45,14 +45,24 @@ int od_hipenc_check_mode(void);
 static __thread od_hip_mc_sad_item *mv_items;
 static __thread int32_t *mv_sads;
 static __thread int mv_items_cap;
+/* The SADs of the top-level (64x64) blocks, which od_mv_est_init_du asks for once per vertex
+   whose error domain touches them (src/mcenc.c:3937-3942: the same block again and again while
+   the grid stands still): they ride the same device call and od_mv_est_sad answers from here
+   while od_mv_est_init_dus runs. */
+static __thread int32_t *mv_top;
+static __thread int mv_top_cap;
+static __thread int mv_top_nh;           /* top-level blocks per row; 0: table not valid */
 
 static int mv_calc_sads_device(od_mv_est_ctx *est) {
   od_state *state;
   int nplanes;
   int pass;
   int n;
+  int ntop;
   int rc;
   state = &est->enc->state;
+  ntop = 0;
+  mv_top_nh = 0;
   if (est->level_max <= 0 || state->frame_type != OD_P_FRAME || est->compute_distortion != od_enc_sad) return 0;
   nplanes = (est->flags & OD_MC_USE_CHROMA) ? est->enc->input_img[est->enc->curr_frame].nplanes : 1;
   if (nplanes != 1 && nplanes != 3) return 0;
@@ -123,18 +133,53 @@ static int mv_calc_sads_device(od_mv_est_ctx *est) {
     if (pass == 0) {
       n = i;
       if (n == 0) return 0;
-      if (n > mv_items_cap) {
+      ntop = (state->nhmvbs >> OD_LOG_MVB_DELTA0)*(state->nvmvbs >> OD_LOG_MVB_DELTA0);
+      if (n + ntop > mv_items_cap) {
         free(mv_items);
         free(mv_sads);
-        mv_items = (od_hip_mc_sad_item *)malloc(sizeof(*mv_items)*n);
-        mv_sads = (int32_t *)malloc(sizeof(*mv_sads)*n);
-        mv_items_cap = mv_items != NULL && mv_sads != NULL ? n : 0;
+        mv_items = (od_hip_mc_sad_item *)malloc(sizeof(*mv_items)*(n + ntop));
+        mv_sads = (int32_t *)malloc(sizeof(*mv_sads)*(n + ntop));
+        mv_items_cap = mv_items != NULL && mv_sads != NULL ? n + ntop : 0;
         if (mv_items_cap == 0) return 0;
+      }
+      if (ntop > mv_top_cap) {
+        free(mv_top);
+        mv_top = (int32_t *)malloc(sizeof(*mv_top)*ntop);
+        mv_top_cap = mv_top != NULL ? ntop : 0;
+        if (mv_top_cap == 0) ntop = 0;
       }
     }
     else if (pass == 1) {
-      rc = od_hipenc_mv_sad_items(est->enc, nplanes, mv_items, n, mv_sads);
+      /* the top-level blocks behind the regular items: oc 0, s 3 (src/mcenc.c:3940) */
+      int t;
+      for (t = 0; t < ntop; t++) {
+        od_hip_mc_sad_item *it;
+        int tvx;
+        int tvy;
+        int k;
+        it = mv_items + n + t;
+        tvx = (t%(state->nhmvbs >> OD_LOG_MVB_DELTA0)) << OD_LOG_MVB_DELTA0;
+        tvy = (t/(state->nhmvbs >> OD_LOG_MVB_DELTA0)) << OD_LOG_MVB_DELTA0;
+        it->x = tvx << OD_LOG_MVBSIZE_MIN;
+        it->y = tvy << OD_LOG_MVBSIZE_MIN;
+        it->log_blk_sz = OD_LOG_MVB_DELTA0 + OD_LOG_MVBSIZE_MIN;
+        it->oc = 0;
+        it->s = 3;
+        it->reserved = 0;
+        for (k = 0; k < 4; k++) {
+          const od_mv_grid_pt *g;
+          g = state->mv_grid[tvy + (OD_VERT_SETUP_DY[0][3][k] << OD_LOG_MVB_DELTA0)]
+           + tvx + (OD_VERT_SETUP_DX[0][3][k] << OD_LOG_MVB_DELTA0);
+          if (g->ref == OD_FRAME_NEXT || state->ref_imgi[g->ref] < 0) return 0;
+          it->mvx[k] = g->mv[0];
+          it->mvy[k] = g->mv[1];
+          it->ref[k] = state->ref_imgi[g->ref];
+        }
+      }
+      rc = od_hipenc_mv_sad_items(est->enc, nplanes, mv_items, n + ntop, mv_sads);
       if (rc <= 0) return 0;          /* rc < 0: the frame is marked failed; memory stays defined */
+      for (t = 0; t < ntop; t++) mv_top[t] = mv_sads[n + t];
+      mv_top_nh = ntop > 0 ? state->nhmvbs >> OD_LOG_MVB_DELTA0 : 0;
     }
   }
   return 1;
@@ -144,9 +189,13 @@ static int mv_calc_sads_device(od_mv_est_ctx *est) {
 void od_hipenc_mv_thread_cleanup(void) {
   free(mv_items);
   free(mv_sads);
+  free(mv_top);
   mv_items = NULL;
   mv_sads = NULL;
+  mv_top = NULL;
   mv_items_cap = 0;
+  mv_top_cap = 0;
+  mv_top_nh = 0;
 }
 
 static void od_mv_est_calc_sads(od_mv_est_ctx *est) {
@@ -194,6 +243,20 @@ static void od_mv_est_calc_sads(od_mv_est_ctx *est) {
   mv_inner += dt;
 }
 
+/* od_mv_est_sad (src/mcenc.c:2271) as its callers see it: a top-level block asked for while
+   od_mv_est_init_dus runs (the grid's vectors stand still from od_mv_est_calc_sads to its end) is
+   answered from the device call of od_mv_est_calc_sads; everything else is the reference's. */
+static int32_t od_mv_est_sad(od_mv_est_ctx *est, int vx, int vy, int oc, int s, int log_mvb_sz) {
+  if (mv_top_nh > 0 && log_mvb_sz == OD_LOG_MVB_DELTA0 && oc == 0 && s == 3
+   && !(vx & OD_MVB_MASK) && !(vy & OD_MVB_MASK)) {
+    int32_t v;
+    v = mv_top[(vy >> OD_LOG_MVB_DELTA0)*mv_top_nh + (vx >> OD_LOG_MVB_DELTA0)];
+    if (od_hipenc_check_mode() && v != od_mv_est_sad_cpu(est, vx, vy, oc, s, log_mvb_sz)) od_hipenc_mv_check_fail(1);
+    return v;
+  }
+  return od_mv_est_sad_cpu(est, vx, vy, oc, s, log_mvb_sz);
+}
+
 static void od_mv_est_init_dus(od_mv_est_ctx *est) {
   double t0;
   double dt;
@@ -202,6 +265,7 @@ static void od_mv_est_init_dus(od_mv_est_ctx *est) {
   mv_inner = 0;
   t0 = od_hipenc_now();
   od_mv_est_init_dus_cpu(est);
+  mv_top_nh = 0;                 /* the grid moves again from here on */
   dt = od_hipenc_now() - t0;
   od_hipenc_mv_stage(OD_HIPENC_MV_INIT_DUS, dt - mv_inner);
   mv_inner = keep + dt;

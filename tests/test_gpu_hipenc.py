@@ -433,7 +433,7 @@ def test_inter_stream_1080p_pframe_feed_packets_identical():
     n, pk, st = H.encode(prm, buf, nf, use_device=1)
     assert n > 0 and pk == want
     assert st.pfeed_frames == 2 and st.lost_sync == st1.lost_sync
-    assert st.mv_dev_calls == 2 and st.mv_dev_sads == 2*4*(120*68 + 60*34)
+    assert st.mv_dev_calls == 2 and st.mv_dev_sads == 2*(4*(120*68 + 60*34) + 30*17)   # two block sizes x four split states + the top-level blocks
     host_p = (st.cpu_other + st.cpu_noref_luma) - (st1.cpu_other + st1.cpu_noref_luma)
     dev_p = st.dev_hits - st1.dev_hits
     print('1080p I P P: P-frame searches from the feed %d, on the host %d; feed wait %.3f s; total %.2f s'

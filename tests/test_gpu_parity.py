@@ -695,6 +695,56 @@ def test_mvest_calc_sads_fused_obmc_sad(hip):
     mc.close()
 
 
+def test_reference_image_built_on_the_device_from_a_reconstruction(hip):
+    """od_hip_mc_set_ref_ctx (k_mc_ref_from_rec): a context's reconstruction plane becomes a
+    reference image of a prediction object ON the device, the padding filled as od_img_edge_ext
+    fills it (src/state.c:1100-1171: the frame's edge samples replicated).  Reference: the same
+    image padded on the host (numpy edge mode) and uploaded with od_hip_mc_set_ref; both objects
+    must give identical SADs for vectors that reach deep into every side of the padding - and
+    those must equal the oracle's."""
+    from testlib import mvest_oracle_sads, SAD_ITEM
+    o = oracle()
+    fw, fh, pad = 192, 128, 96
+    planes = [synth_plane(fw, fh, 5), synth_plane(fw//2, fh//2, 6, 1), synth_plane(fw//2, fh//2, 7, 1)]
+    ctx = hip.DaalaHip(fw, fh, fw, fh, nplanes=3, xdec=(0, 1, 1), nslots=1)
+    ctx.upload_planes(0, planes)
+    ctx.forward_haar()                       # lossless round trip: the reconstruction IS the input
+    ctx.inverse_haar()
+    for pli in range(3):
+        assert np.array_equal(ctx.download_recon(0, pli), planes[pli])
+    refs = [np.pad(planes[p], pad >> (p > 0), mode='edge')[None] for p in range(3)]
+    src = [synth_plane(fw, fh, 9), synth_plane(fw//2, fh//2, 10, 1), synth_plane(fw//2, fh//2, 11, 1)]
+    org = [pad, pad//2, pad//2]
+    dec = [(0, 0), (1, 1), (1, 1)]
+    host = hip.McSad(refs, org, org, src, dec)
+    dev = hip.McSad([np.zeros_like(r) for r in refs], org, org, src, dec)
+    for pli in range(3):
+        dev.set_ref_ctx(pli, 0, ctx, 0, refs[pli].shape[2], refs[pli].shape[1], org[pli], org[pli])
+    rng = np.random.default_rng(77)
+    it = np.zeros(400, SAD_ITEM)
+    for i in range(len(it)):
+        lg = int(rng.integers(3, 7))
+        n = 1 << lg
+        it[i]['log_blk_sz'] = lg
+        it[i]['x'] = int(rng.choice([0, fw - n, int(rng.integers(0, (fw - n)//8 + 1))*8]))
+        it[i]['y'] = int(rng.choice([0, fh - n, int(rng.integers(0, (fh - n)//8 + 1))*8]))
+        it[i]['oc'], it[i]['s'] = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        it[i]['mvx'] = rng.integers(-8*(pad - 8), 8*(pad - 8), size=4)
+        it[i]['mvy'] = rng.integers(-8*(pad - 8), 8*(pad - 8), size=4)
+    a = host.sad_items(it, fw, fh)
+    b = dev.sad_items(it, fw, fh)
+    assert np.array_equal(a, b), np.flatnonzero(a != b)[:5]
+    g = {'dims': np.array([fw//8, fh//8, 0, 4, 1, fw, fh] + sum([[refs[p].shape[2], refs[p].shape[1], org[p], org[p]]
+                                                                  for p in range(3)], []), np.int32),
+         'pic': np.array([fw, fh], np.int32)}
+    for p in range(3):
+        g['refs%d' % p], g['src%d' % p] = refs[p], src[p]
+    assert np.array_equal(a, mvest_oracle_sads(o, g, it))
+    host.close()
+    dev.close()
+    ctx.close()
+
+
 def test_superblock_row_strips_in_c_equal_the_full_frame(hip):
     """SURVEY 8e in C: od_hip_set_strip restricts the forward pyramid and the PVQ passes to a
     strip of superblock rows (the kernels read their lapping halo from the pixels: no halo
