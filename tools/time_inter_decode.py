@@ -21,7 +21,9 @@ t = time.time(); n, pk, st = H.encode(prm, buf, nf, use_device=1); print('encode
 hdr = H.headers(prm)
 n0, want, s0, _ = H.decode(prm, hdr, pk)
 print('reference decode %.3f s' % s0)
-for env in ('1', '0', '1', '0'):
+for env, res in (('1', '1'), ('1', '0'), ('0', '1'), ('1', '1'), ('1', '0'), ('0', '1')):
     os.environ['HIPDEC_SYNTH'] = env
+    os.environ['HIPDEC_REF_RESIDENT'] = res     # 0: references uploaded from the host image (rounds 2-3)
     nd, got, s1, d1 = H.decode(prm, hdr, pk, use_device=1)
-    print('HIPDEC_SYNTH=%s: %.3f s (device calls %.3f s) identical %s synth %s' % (env, s1, d1, np.array_equal(got, want), H.synth_stats()))
+    print('HIPDEC_SYNTH=%s HIPDEC_REF_RESIDENT=%s: %.3f s (device calls %.3f s) identical %s synth %s resident refs %d'
+          % (env, res, s1, d1, np.array_equal(got, want), H.synth_stats(), H.ref_resident_frames()))
