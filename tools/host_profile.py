@@ -98,7 +98,7 @@ def main():
         addr = pc - first
         j = bisect.bisect_right([t[0] for t in tab], addr) - 1
         by_sym[(tab[j][1] if j >= 0 else '?') + ' (' + name.split('.')[0] + ')'] += 1
-    print('# Host profile of the live seam, round 3 (%s)\n' % what)
+    print('# Host profile of the live seam (%s)\n' % what)
     print('Sampling profiler of the integration library (`daala_amd/host/hip_prof.c`, 500 us of process CPU time per '
           'sample; the kernel delivers one per scheduler tick, 250 per second of wall time), %d steps, %d samples; '
           'wall %.3f s per step.\n' % (a.steps, got, st.t_total_s))
