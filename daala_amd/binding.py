@@ -245,6 +245,21 @@ class McSad(object):
                                                    c_int, c_int, c_int]
         _chk(self.lib.od_hip_mc_set_ref_ctx(self.h, pli, k, ctx.ctx, slot, ref_stride, ref_h, org_x, org_y))
 
+    BMA_REC = np.dtype([('bx', np.int32), ('by', np.int32), ('log_blk_sz', np.int32), ('ref', np.int32),
+                        ('cx', np.int32), ('cy', np.int32), ('xmin', np.int32), ('xmax', np.int32),
+                        ('ymin', np.int32), ('ymax', np.int32)])
+
+    def bma_windows(self, recs, radius, pic_w, pic_h, nplanes=None):
+        """od_hip_mc_bma_windows: [nrec][(2 radius + 1)^2] block-matching SADs (-1: outside the limits)."""
+        r = np.ascontiguousarray(recs, dtype=self.BMA_REC)
+        W = 2*radius + 1
+        out = np.zeros((len(r), W*W), np.int32)
+        self.lib.od_hip_mc_bma_windows.argtypes = [ctypes.c_void_p, c_int, c_int, c_int, ctypes.c_void_p, c_int, c_int,
+                                                   ctypes.POINTER(ctypes.c_int32)]
+        _chk(self.lib.od_hip_mc_bma_windows(self.h, self.nplanes if nplanes is None else nplanes, pic_w, pic_h,
+                                            r.ctypes.data, len(r), radius, _p32(out)))
+        return out
+
     def sad_items(self, items, pic_w, pic_h, nplanes=None):
         it = np.ascontiguousarray(items, dtype=self.ITEM)
         out = np.zeros(len(it), np.int32)

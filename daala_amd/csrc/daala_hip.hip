@@ -523,6 +523,10 @@ struct od_hip_mc {
   McSadItem *d_items = nullptr, *h_items = nullptr;
   int32_t *d_sad = nullptr, *h_sad = nullptr;
   size_t items_cap = 0;
+  // od_hip_mc_bma_windows: vertex records and their SAD windows
+  McBmaRec *d_recs = nullptr, *h_recs = nullptr;
+  int32_t *d_win = nullptr, *h_win = nullptr;
+  size_t recs_cap = 0, win_cap = 0;
 };
 
 extern "C" {
@@ -547,6 +551,10 @@ void od_hip_mc_destroy(od_hip_mc *m) {
   if (m->h_items) (void)hipHostFree(m->h_items);
   if (m->d_sad) (void)hipFree(m->d_sad);
   if (m->h_sad) (void)hipHostFree(m->h_sad);
+  if (m->d_recs) (void)hipFree(m->d_recs);
+  if (m->h_recs) (void)hipHostFree(m->h_recs);
+  if (m->d_win) (void)hipFree(m->d_win);
+  if (m->h_win) (void)hipHostFree(m->h_win);
   if (m->done) (void)hipEventDestroy(m->done);
   if (m->ctx_ready) (void)hipEventDestroy(m->ctx_ready);
   if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
@@ -866,6 +874,88 @@ int od_hip_mc_sad_items(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const o
   HIPCHK(hipMemcpyAsync(m->h_sad, m->d_sad, (size_t)nitems*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   memcpy(sad, m->h_sad, (size_t)nitems*sizeof(int32_t));
+  return 0;
+}
+
+// F3: dense block-matching windows (mc_kernels.hpp: k_mc_bma_windows) - od_mv_est_bma_sad
+// (src/mcenc.c:2228-2268) of every half-sample vector within `radius` of each record's centre,
+// against the resident references and source planes.  out: [nrec][(2 radius + 1)^2], -1 where the
+// vector lies outside the record's limits.
+int od_hip_mc_bma_windows(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const od_hip_mc_bma_rec *recs,
+                          int nrec, int radius, int32_t *out) {
+  if (!m || !recs || !out) return fail(OD_HIP_EFAULT, "null pointer");
+  if (nplanes < 1 || nplanes > 3 || pic_w < 1 || pic_h < 1 || nrec < 0 || nrec > 65535 || radius < 0 || radius > 16)
+    return fail(OD_HIP_EINVAL, "bad geometry");      // nrec is the grid's y extent
+  for (int pli = 0; pli < nplanes; pli++) {
+    if (!m->pl[pli].d_refs) return fail(OD_HIP_EINVAL, "no reference planes set for this plane");
+    if (!m->src[pli].d) return fail(OD_HIP_EINVAL, "no source plane set for this plane");
+  }
+  // operand shapes are checked on the host before anything is launched: a block may hang over
+  // the frame (it is centred on a grid vertex) by at most its own size; what it reads of the
+  // references is clamped to the plane by the kernel
+  for (int b = 0; b < nrec; b++) {
+    const od_hip_mc_bma_rec &q = recs[b];
+    const int n = 1 << q.log_blk_sz;
+    if (q.log_blk_sz < 3 || q.log_blk_sz > 6 || q.ref < 0 || q.ref >= m->nref || (q.bx & 3) || (q.by & 3)
+        || q.bx < -n || q.by < -n || q.bx > m->src[0].w || q.by > m->src[0].h_rows
+        || q.xmin > q.xmax || q.ymin > q.ymax || q.xmin < -(1 << 14) || q.xmax > (1 << 14)
+        || q.ymin < -(1 << 14) || q.ymax > (1 << 14))
+      return fail(OD_HIP_EINVAL, "bad block-matching record");
+  }
+  if (nrec == 0) return 0;
+  HIPCHK(hipSetDevice(m->device));
+  static_assert(sizeof(McBmaRec) == sizeof(od_hip_mc_bma_rec), "McBmaRec mirrors od_hip_mc_bma_rec");
+  const int W = 2*radius + 1;
+  const size_t nwin = (size_t)nrec*W*W;
+  if (m->recs_cap < (size_t)nrec || m->win_cap < nwin) {
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->d_recs) (void)hipFree(m->d_recs);
+    if (m->h_recs) (void)hipHostFree(m->h_recs);
+    if (m->d_win) (void)hipFree(m->d_win);
+    if (m->h_win) (void)hipHostFree(m->h_win);
+    m->d_recs = m->h_recs = nullptr;
+    m->d_win = m->h_win = nullptr;
+    m->recs_cap = m->win_cap = 0;
+    const size_t rc = (size_t)nrec + nrec/2, wc = nwin + nwin/2;
+    HIPCHK(hipMalloc((void **)&m->d_recs, rc*sizeof(McBmaRec)));
+    HIPCHK(hipHostMalloc((void **)&m->h_recs, rc*sizeof(McBmaRec)));
+    HIPCHK(hipMalloc((void **)&m->d_win, wc*sizeof(int32_t)));
+    HIPCHK(hipHostMalloc((void **)&m->h_win, wc*sizeof(int32_t)));
+    m->recs_cap = rc;
+    m->win_cap = wc;
+  }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  memcpy(m->h_recs, recs, (size_t)nrec*sizeof(McBmaRec));
+  HIPCHK(hipMemcpyAsync(m->d_recs, m->h_recs, (size_t)nrec*sizeof(McBmaRec), hipMemcpyHostToDevice, m->stream));
+  McBmaArgs a;
+  for (int pli = 0; pli < 3; pli++) {
+    const int q = pli < nplanes ? pli : 0;
+    const auto &P = m->pl[q];
+    const auto &S = m->src[q];
+    a.pl[pli].R.refs = P.d_refs;
+    a.pl[pli].R.ref_plane = P.plane;
+    a.pl[pli].R.ref_stride = P.ref_stride;
+    a.pl[pli].R.ref_h = P.ref_h;
+    a.pl[pli].R.org_x = P.org_x;
+    a.pl[pli].R.org_y = P.org_y;
+    a.pl[pli].src = S.d;
+    a.pl[pli].src_stride = S.w;
+    a.pl[pli].xdec = S.xdec;
+    a.pl[pli].ydec = S.ydec;
+    a.pl[pli].clip_w = min((pic_w + (1 << S.xdec) - 1) >> S.xdec, S.w);
+    a.pl[pli].clip_h = min((pic_h + (1 << S.ydec) - 1) >> S.ydec, S.h_rows);
+    a.pl[pli].shift = q > 0 ? 2 : 0;                 // OD_MC_CHROMA_SCALE (src/mcenc.c:53)
+  }
+  a.nplanes = nplanes;
+  a.recs = m->d_recs;
+  a.nrec = nrec;
+  a.radius = radius;
+  a.sad = m->d_win;
+  hipLaunchKernelGGL(k_mc_bma_windows, dim3(W*W, nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(m->h_win, m->d_win, nwin*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  memcpy(out, m->h_win, nwin*sizeof(int32_t));
   return 0;
 }
 

@@ -308,3 +308,76 @@ __global__ __launch_bounds__(256) void k_mc_ref_from_rec(McRefArgs a) {
   if (x4 + 4 <= a.ref_stride) *reinterpret_cast<uint32_t *>(a.ref + (size_t)y*a.ref_stride + x4) = word;
   else for (int k = 0; x4 + k < a.ref_stride; k++) a.ref[(size_t)y*a.ref_stride + x4 + k] = (uint8_t)(word >> (8*k));
 }
+
+// F3: dense block-matching windows for the EPZS initialisation of the motion search.
+// od_mv_est_init_mv (src/mcenc.c:2511) judges candidate vectors of one grid vertex by
+// od_mv_est_bma_sad (:2228-2268): ONE single-vector prediction of the block centred on the vertex
+// (od_mc_predict1fmv8_c, every plane, vectors in half samples: mvx*(1 << (2 - xdec))) and
+// od_enc_sad against the frame being coded (the block clipped against the picture on every side,
+// it may hang over the frame's edge), chroma >> OD_MC_CHROMA_SCALE.  Which candidates it asks for
+// depends on the SADs it has seen, but they cluster around the median predictor - known for every
+// vertex of a level before the level starts - so the device evaluates the WHOLE (2R + 1)^2 window
+// of half-sample vectors around it for every vertex of the level in one launch and the host's
+// decision logic (the reference's own function) looks its SADs up.  One wave per (vertex, offset).
+struct McBmaRec {         // == od_hip_mc_bma_rec (include/daala_hip.h)
+  int32_t bx, by;         // luma position of the block's upper-left corner (may be negative)
+  int32_t log_blk_sz;     // luma log2 size, 3 .. 6
+  int32_t ref;            // reference image index
+  int32_t cx, cy;         // window centre, half samples
+  int32_t xmin, xmax, ymin, ymax;    // the vertex's vector limits, half samples (inclusive)
+};
+
+struct McBmaArgs {
+  McSadPlane pl[3];
+  int nplanes;
+  const McBmaRec *recs;
+  int nrec;
+  int radius;             // R: offsets -R .. R in both directions
+  int32_t *sad;           // [nrec][(2R + 1)^2]; -1: outside the limits, not evaluated
+};
+
+__global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_bma_windows(McBmaArgs a) {
+  __shared__ int16_t buff[(64 + 5)*64];
+  __shared__ uint8_t pred[4096];
+  const int lane = threadIdx.x;
+  const int W = 2*a.radius + 1;
+  const int rec = blockIdx.y, o = blockIdx.x;
+  if (rec >= a.nrec || o >= W*W) return;
+  const McBmaRec r = a.recs[rec];
+  const int mvx = r.cx + o%W - a.radius, mvy = r.cy + o/W - a.radius;
+  int32_t *out = a.sad + (size_t)rec*W*W + o;
+  if (mvx < r.xmin || mvx > r.xmax || mvy < r.ymin || mvy > r.ymax) {
+    if (lane == 0) *out = -1;
+    return;
+  }
+  int total = 0;
+  for (int pli = 0; pli < a.nplanes; pli++) {
+    const McSadPlane &P = a.pl[pli];
+    const int lx = r.log_blk_sz - P.xdec, ly = r.log_blk_sz - P.ydec;
+    const int bx = r.bx >> P.xdec, by = r.by >> P.ydec;          // arithmetic: positions are multiples of 4
+    const int xblk = 1 << lx, yblk = 1 << ly, npix = xblk*yblk;
+    int32_t ref4[4], cmvx[4], cmvy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      ref4[k] = r.ref;
+      cmvx[k] = mvx*(1 << (2 - P.xdec));
+      cmvy[k] = mvy*(1 << (2 - P.ydec));
+    }
+    int alias[4];
+    mc_predict_corners<MC_SAD_THREADS>(P.R, bx, by, lx, ly, ref4, cmvx, cmvy, buff, pred, alias, lane);   // one tile
+    // od_enc_sad: the block clipped against [0, clip_w) x [0, clip_h)
+    int acc = 0;
+    for (int e = lane; e < npix; e += MC_SAD_THREADS) {
+      const int j = e >> lx, i = e & (xblk - 1);
+      const int sx = bx + i, sy = by + j;
+      if (sx >= 0 && sx < P.clip_w && sy >= 0 && sy < P.clip_h) {
+        acc += abs((int)pred[e] - (int)P.src[(size_t)sy*P.src_stride + sx]);
+      }
+    }
+#pragma unroll
+    for (int q = 32; q > 0; q >>= 1) acc += __shfl_xor(acc, q);
+    total += acc >> P.shift;
+    __syncthreads();
+  }
+  if (lane == 0) *out = total;
+}

@@ -63,6 +63,7 @@ class Stats(ctypes.Structure):
                 ('rate_calls', ctypes.c_int64), ('frame_cpu_s', ctypes.c_double), ('pre_mc_s', ctypes.c_double),
                 ('mv_stage_s', ctypes.c_double*8),
                 ('mv_dev_calls', ctypes.c_int64), ('mv_dev_sads', ctypes.c_int64), ('mv_dev_wait_s', ctypes.c_double), ('mv_check_fail', ctypes.c_int64),
+                ('mv_bma_calls', ctypes.c_int64), ('mv_bma_windows', ctypes.c_int64), ('mv_bma_hits', ctypes.c_int64), ('mv_bma_misses', ctypes.c_int64), ('mv_level_walks', ctypes.c_int64),
                 ('t_setup_s', ctypes.c_double),
                 ('t_upload_s', ctypes.c_double), ('t_launch_s', ctypes.c_double),
                 ('t_compand_s', ctypes.c_double),

@@ -91,6 +91,8 @@ typedef struct dec_tls {
   od_hip_mc *mc;            /* this thread's resident motion-compensation object */
   const od_state *mc_state; /* the codec state its reference copies belong to */
   unsigned char mc_dirty[OD_FRAME_MAX + 1];   /* reference image k changed since its upload */
+  const od_state *mc_src_state;     /* the frame whose source planes the prediction object holds: */
+  int64_t mc_src_time;              /* ... its state and state->cur_time */
   const void *poisoned;             /* decoder whose last frame failed: packets fail until its next keyframe */
   int mc_resident;                  /* image index the frame being reconstructed was written to on the device
                                        (od_hip_mc_set_ref_ctx), or -1 */
@@ -1297,11 +1299,18 @@ int od_hipdec_mc_sad_items(od_state *state, const od_img *input, int nplanes,
   }
   if (injected_failure()) rc = -1;
   else rc = mc_refresh_refs(state, NULL, nplanes);
-  for (pli = 0; pli < nplanes && rc == 0; pli++) {
-    const od_img_plane *ip;
-    ip = input->planes + pli;
-    rc = od_hip_mc_set_src(D.mc, pli, ip->data, ip->ystride, state->frame_width >> ip->xdec,
-     state->frame_height >> ip->ydec, ip->xdec, ip->ydec);
+  /* the frame being coded: uploaded once per frame (the EPZS windows may have done it already) */
+  if (rc == 0 && (D.mc_src_state != state || D.mc_src_time != state->cur_time)) {
+    for (pli = 0; pli < nplanes && rc == 0; pli++) {
+      const od_img_plane *ip;
+      ip = input->planes + pli;
+      rc = od_hip_mc_set_src(D.mc, pli, ip->data, ip->ystride, state->frame_width >> ip->xdec,
+       state->frame_height >> ip->ydec, ip->xdec, ip->ydec);
+    }
+    if (rc == 0) {
+      D.mc_src_state = state;
+      D.mc_src_time = state->cur_time;
+    }
   }
   if (rc == 0) {
     rc = od_hip_mc_sad_items(D.mc, nplanes, state->info.pic_width, state->info.pic_height, items, nitems, sad);
@@ -1309,6 +1318,46 @@ int od_hipdec_mc_sad_items(od_state *state, const od_img *input, int nplanes,
   if (rc != 0) {
     D.failed = 1;
     stage_failed("motion search SADs", rc);
+    return -1;
+  }
+  return 1;
+}
+
+/* The block-matching windows of the EPZS initialisation (mcenc_tail.c) on this thread's
+   prediction object: references current, the frame being coded resident (od_mv_est_init_mvs runs
+   before od_mv_est_calc_sads: this is the frame's first use of the source planes).  Return codes
+   as od_hipdec_mc_sad_items. */
+int od_hipdec_mc_bma_windows(od_state *state, const od_img *input, int nplanes,
+ const od_hip_mc_bma_rec *recs, int nrec, int radius, int32_t *out) {
+  int pli;
+  int rc;
+  if (!od_hipenc_device_thread() || D.failed) return 0;
+  if (state->full_precision_references || nplanes < 1 || nplanes > 3 || input->nplanes < nplanes) return 0;
+  for (pli = 0; pli < nplanes; pli++) {
+    if (input->planes[pli].xstride != 1 || input->planes[pli].xdec > 1 || input->planes[pli].ydec > 1) return 0;
+  }
+  if (injected_failure()) rc = -1;
+  else rc = mc_refresh_refs(state, NULL, nplanes);
+  /* the source planes: once per frame (D.mc_src_frame: the encoder's frame counter) */
+  if (rc == 0 && (D.mc_src_state != state || D.mc_src_time != state->cur_time)) {
+    for (pli = 0; pli < nplanes && rc == 0; pli++) {
+      const od_img_plane *ip;
+      ip = input->planes + pli;
+      rc = od_hip_mc_set_src(D.mc, pli, ip->data, ip->ystride, state->frame_width >> ip->xdec,
+       state->frame_height >> ip->ydec, ip->xdec, ip->ydec);
+    }
+    if (rc == 0) {
+      D.mc_src_state = state;
+      D.mc_src_time = state->cur_time;
+    }
+  }
+  if (rc == 0) {
+    rc = od_hip_mc_bma_windows(D.mc, nplanes, state->info.pic_width, state->info.pic_height, recs, nrec,
+     radius, out);
+  }
+  if (rc != 0) {
+    D.failed = 1;
+    stage_failed("motion search block-matching windows", rc);
     return -1;
   }
   return 1;

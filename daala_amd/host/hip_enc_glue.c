@@ -414,6 +414,36 @@ int od_hipenc_mv_sad_items(daala_enc_ctx *enc, int nplanes, const od_hip_mc_sad_
   return rc;
 }
 
+/* The EPZS initialisation's block-matching windows (mcenc_tail.c: od_mv_est_init_mvs) on this
+   worker's prediction object.  nrec == 0 asks whether a device serves this thread at all. */
+int od_hipdec_mc_bma_windows(od_state *state, const od_img *input, int nplanes,
+ const od_hip_mc_bma_rec *recs, int nrec, int radius, int32_t *out);
+static int mv_dev_epzs = 1;       /* HIPENC_MV_EPZS=0: the reference's od_mv_est_init_mvs, host SADs;
+                                     2: the level-by-level walk even without a device (host SADs): the CPU
+                                     tests pin the walk's equivalence to the reference's block-by-block one */
+
+int od_hipenc_mv_bma_windows(daala_enc_ctx *enc, int nplanes, const od_hip_mc_bma_rec *recs, int nrec,
+ int radius, int32_t *out) {
+  double t0;
+  int rc;
+  if (!mv_dev_epzs || enc == NULL || enc != T.enc) return 0;
+  if (nrec == 0) return od_hipenc_device_thread() || mv_dev_epzs == 2;
+  t0 = now_s();
+  rc = od_hipdec_mc_bma_windows(&enc->state, enc->input_img + enc->curr_frame, nplanes, recs, nrec, radius, out);
+  if (rc > 0) {
+    T.st.mv_bma_calls++;
+    T.st.mv_bma_windows += nrec;
+    T.st.mv_dev_wait_s += now_s() - t0;
+  }
+  return rc;
+}
+
+void od_hipenc_mv_bma_stats(long hits, long misses) {
+  T.st.mv_level_walks++;
+  T.st.mv_bma_hits += hits;
+  T.st.mv_bma_misses += misses;
+}
+
 /* check mode: the reference's loop ran beside the device call and its sad_cache differs */
 void od_hipenc_mv_check_fail(long n) {
   T.st.mv_check_fail += n;
@@ -821,6 +851,11 @@ static void add_stats(od_hipenc_stats *a, const od_hipenc_stats *b) {
     a->mv_dev_sads += b->mv_dev_sads;
     a->mv_dev_wait_s += b->mv_dev_wait_s;
     a->mv_check_fail += b->mv_check_fail;
+    a->mv_bma_calls += b->mv_bma_calls;
+    a->mv_bma_windows += b->mv_bma_windows;
+    a->mv_bma_hits += b->mv_bma_hits;
+    a->mv_bma_misses += b->mv_bma_misses;
+    a->mv_level_walks += b->mv_level_walks;
   }
   for (int i = 0; i < 4; i++) a->search_class_s[i] += b->search_class_s[i];
 }
@@ -1165,6 +1200,8 @@ od_hipenc *od_hipenc_open(const od_hipenc_params *p, int use_device, int device,
     if (e != NULL) pf_helpers = atoi(e);
     e = getenv("HIPENC_MV_SADS");
     mv_dev_sads = e == NULL || atoi(e) != 0;
+    e = getenv("HIPENC_MV_EPZS");
+    mv_dev_epzs = e == NULL ? 1 : atoi(e);
   }
   S->use_device = use_device;
   S->device = device;

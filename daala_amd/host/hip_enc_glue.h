@@ -60,6 +60,11 @@ typedef struct od_hipenc_stats {
   int64_t mv_dev_sads;     /* block SADs in them */
   double mv_dev_wait_s;    /* seconds the coding thread spent in those calls */
   int64_t mv_check_fail;   /* check mode: device SAD != the reference's od_mv_est_calc_sads (must be 0) */
+  int64_t mv_bma_calls;    /* EPZS initialisation: device calls (one per level and vertex parity) */
+  int64_t mv_bma_windows;  /* EPZS initialisation: vertices whose block-matching window came from the device */
+  int64_t mv_bma_hits;     /* ... od_mv_est_bma_sad calls answered from a window */
+  int64_t mv_bma_misses;   /* ... calls for a vector outside the vertex's window (reference code on the host) */
+  int64_t mv_level_walks;  /* od_mv_est_init_mvs calls that walked the grid level by level (one per reference and P frame) */
   double t_setup_s;        /* encoder/device context creation (not in t_total_s) */
   double t_upload_s;       /* pad + upload phase, wall */
   double t_launch_s;       /* upload done -> device batch enqueued (includes t_compand_s), wall */

@@ -3,7 +3,10 @@
  * (*_cpu); the definitions here are what their call sites bind to:
  *   - every stage is timed (a handful of clock reads per frame) into the worker's statistics
  *     (od_hipenc_stats.mv_stage_s), which is where profiles/r04_mvest_stages.md comes from. */
+#include "../../include/daala_hip.h"
 void od_hipenc_mv_stage(int stage, double seconds);   /* hip_enc_glue.c */
+void od_hipenc_mv_check_fail(long n);
+int od_hipenc_check_mode(void);
 double od_hipenc_now(void);
 
 enum {
@@ -19,10 +22,230 @@ enum {
 
 static __thread double mv_inner;     /* time of stages nested in the one being timed */
 
+/* ---------------------------------------------------------------------------------------------
+ * od_mv_est_init_mvs (src/mcenc.c:3036) with the block-matching SADs of levels >= 1 from the
+ * device.  od_mv_est_init_mv (:2511), the reference's own function, keeps making every decision;
+ * what changes is (a) the ORDER in which the vertices of the grid are visited and (b) where
+ * od_mv_est_bma_sad's numbers come from.
+ * (a) The reference walks motion vector blocks and, inside each, levels ("for cache coherency");
+ *     its comment (:3052-3062) states the contract: a level needs the levels below it; level 0
+ *     needs raster order; "order within a level does not matter".  Every predictor a level >= 1
+ *     vertex reads (od_state_get_predictor, od_mc_get_ref_predictor, the cneighbors /
+ *     pneighbors of od_mv_est_init_mv) is a vertex of a lower level inside its own block - the
+ *     even-level vertices on a block's right / bottom edge explicitly drop the neighbours that
+ *     belong to the next block (:2660-2663) - or the previous frame's vectors.  So the grid is
+ *     walked level by level here: level 0 exactly as the reference does, then every vertex of
+ *     level 1, of level 2, ...
+ * (b) Before a level starts, the median predictor of each of its vertices - the centre of the
+ *     candidates od_mv_est_init_mv will ask for - is known.  ONE device call evaluates the whole
+ *     (2R + 1)^2 window of half-sample vectors around every vertex's centre
+ *     (od_hip_mc_bma_windows); od_mv_est_bma_sad is rebound and answers from the vertex's window
+ *     when the vector lies inside it, and runs the reference's code when it does not.  The table
+ *     is indexed by the absolute vector: a wrong guess of the centre costs hits, never bits.
+ * Check mode compares every table answer with the reference's function (mv_check_fail). */
+int od_hipenc_mv_bma_windows(daala_enc_ctx *enc, int nplanes, const od_hip_mc_bma_rec *recs, int nrec,
+ int radius, int32_t *out);
+void od_hipenc_mv_bma_stats(long hits, long misses);
+
+#define MV_WIN_RADIUS (4)
+#define MV_WIN_W (2*MV_WIN_RADIUS + 1)
+
+static __thread struct {
+  int active;
+  int ref;
+  int bx;
+  int by;
+  int log_mvb_sz;
+  int cx;
+  int cy;
+  const int32_t *win;
+  long hits;
+  long misses;
+} mv_win;
+
+static __thread od_hip_mc_bma_rec *mv_recs;
+static __thread int32_t *mv_wins;
+static __thread int (*mv_verts)[2];
+static __thread int mv_recs_cap;
+
+static int32_t od_mv_est_bma_sad(od_mv_est_ctx *est, int ref, int bx, int by, int mvx, int mvy,
+ int log_mvb_sz) {
+  if (mv_win.active && ref == mv_win.ref && bx == mv_win.bx && by == mv_win.by
+   && log_mvb_sz == mv_win.log_mvb_sz) {
+    int dx;
+    int dy;
+    dx = mvx - mv_win.cx;
+    dy = mvy - mv_win.cy;
+    if (dx >= -MV_WIN_RADIUS && dx <= MV_WIN_RADIUS && dy >= -MV_WIN_RADIUS && dy <= MV_WIN_RADIUS) {
+      int32_t v;
+      v = mv_win.win[(dy + MV_WIN_RADIUS)*MV_WIN_W + dx + MV_WIN_RADIUS];
+      if (v >= 0) {
+        mv_win.hits++;
+        if (od_hipenc_check_mode() && v != od_mv_est_bma_sad_cpu(est, ref, bx, by, mvx, mvy, log_mvb_sz)) {
+          od_hipenc_mv_check_fail(1);
+        }
+        return v;
+      }
+    }
+    mv_win.misses++;
+  }
+  return od_mv_est_bma_sad_cpu(est, ref, bx, by, mvx, mvy, log_mvb_sz);
+}
+
+/* the vertices of one level (n of them, in mv_verts): windows from the device, then the
+   reference's od_mv_est_init_mv for each */
+static int mv_level_with_windows(od_mv_est_ctx *est, int ref, int must_update, int n) {
+  od_state *state;
+  int nplanes;
+  int i;
+  int rc;
+  state = &est->enc->state;
+  nplanes = (est->flags & OD_MC_USE_CHROMA) ? est->enc->input_img[est->enc->curr_frame].nplanes : 1;
+  for (i = 0; i < n; i++) {
+    od_hip_mc_bma_rec *r;
+    od_mv_limits limits;
+    int pred[2];
+    int vx;
+    int vy;
+    int level;
+    int log_mvb_sz;
+    int mvb_sz;
+    vx = mv_verts[i][0];
+    vy = mv_verts[i][1];
+    level = OD_MC_LEVEL[vy & OD_MVB_MASK][vx & OD_MVB_MASK];
+    log_mvb_sz = (OD_MC_LEVEL_MAX - level) >> 1;
+    mvb_sz = 1 << log_mvb_sz;
+    r = mv_recs + i;
+    /* src/mcenc.c:2585-2616: the limits in half samples, the block centred on the vertex, the
+       clamped median predictor */
+    od_mv_est_limits(state, &limits, vx, vy, log_mvb_sz + OD_LOG_MVBSIZE_MIN);
+    r->xmin = limits.xmin*2;
+    r->xmax = limits.xmax*2;
+    r->ymin = limits.ymin*2;
+    r->ymax = limits.ymax*2;
+    r->bx = (vx << OD_LOG_MVBSIZE_MIN) - (mvb_sz << (OD_LOG_MVBSIZE_MIN - 1));
+    r->by = (vy << OD_LOG_MVBSIZE_MIN) - (mvb_sz << (OD_LOG_MVBSIZE_MIN - 1));
+    r->log_blk_sz = log_mvb_sz + OD_LOG_MVBSIZE_MIN;
+    r->ref = state->ref_imgi[ref];
+    od_state_get_predictor(state, pred, vx, vy, level, 2, ref);
+    r->cx = OD_CLAMPI(r->xmin, pred[0], r->xmax);
+    r->cy = OD_CLAMPI(r->ymin, pred[1], r->ymax);
+  }
+  rc = od_hipenc_mv_bma_windows(est->enc, nplanes, mv_recs, n, MV_WIN_RADIUS, mv_wins);
+  for (i = 0; i < n; i++) {
+    if (rc > 0) {
+      mv_win.active = 1;
+      mv_win.ref = ref;
+      mv_win.bx = mv_recs[i].bx;
+      mv_win.by = mv_recs[i].by;
+      mv_win.log_mvb_sz = mv_recs[i].log_blk_sz - OD_LOG_MVBSIZE_MIN;
+      mv_win.cx = mv_recs[i].cx;
+      mv_win.cy = mv_recs[i].cy;
+      mv_win.win = mv_wins + (size_t)i*MV_WIN_W*MV_WIN_W;
+    }
+    od_mv_est_init_mv(est, ref, mv_verts[i][0], mv_verts[i][1], must_update);
+    mv_win.active = 0;
+  }
+  return rc;
+}
+
+static int mv_init_mvs_levels(od_mv_est_ctx *est, int ref, int must_update) {
+  od_state *state;
+  int nhmvbs;
+  int nvmvbs;
+  int vx;
+  int vy;
+  int log_mvb_sz;
+  int level;
+  int cap;
+  state = &est->enc->state;
+  nhmvbs = state->nhmvbs;
+  nvmvbs = state->nvmvbs;
+  if (state->frame_type != OD_P_FRAME || ref == OD_FRAME_NEXT || state->ref_imgi[ref] < 0
+   || est->level_max < 1 || !od_hipenc_mv_bma_windows(est->enc, 0, NULL, 0, MV_WIN_RADIUS, NULL)) {
+    return 0;
+  }
+  cap = (nhmvbs + 1)*(nvmvbs + 1);
+  if (cap > mv_recs_cap) {
+    free(mv_recs);
+    free(mv_wins);
+    free(mv_verts);
+    mv_recs = (od_hip_mc_bma_rec *)malloc(sizeof(*mv_recs)*cap);
+    mv_wins = (int32_t *)malloc(sizeof(*mv_wins)*cap*MV_WIN_W*MV_WIN_W);
+    mv_verts = (int (*)[2])malloc(sizeof(*mv_verts)*cap);
+    mv_recs_cap = mv_recs != NULL && mv_wins != NULL && mv_verts != NULL ? cap : 0;
+    if (mv_recs_cap == 0) return 0;
+  }
+  /* "Move the motion vector predictors back a frame." (:3045-3056) */
+  if (ref == OD_FRAME_PREV) {
+    OD_MOVE(est->bma_history_time + 1, est->bma_history_time + 0, 2);
+    est->bma_history_time[0] = est->enc->curr_display_order;
+    for (vy = 0; vy <= nvmvbs; vy++) {
+      for (vx = 0; vx <= nhmvbs; vx++) {
+        od_mv_node *mv;
+        mv = est->mvs[vy] + vx;
+        OD_MOVE(mv->bma_mvs + 1, mv->bma_mvs + 0, 2);
+      }
+    }
+  }
+  /* level 0: raster order, as the reference visits it (:3069-3076), SADs from the host */
+  for (vx = 0; vx <= nhmvbs; vx += OD_MVB_DELTA0) od_mv_est_init_mv(est, ref, vx, 0, must_update);
+  for (vy = 0; vy < nvmvbs; vy += OD_MVB_DELTA0) {
+    od_mv_est_init_mv(est, ref, 0, vy + OD_MVB_DELTA0, must_update);
+    for (vx = 0; vx < nhmvbs; vx += OD_MVB_DELTA0) {
+      od_mv_est_init_mv(est, ref, vx + OD_MVB_DELTA0, vy + OD_MVB_DELTA0, must_update);
+    }
+  }
+  /* the other levels, each over the whole grid: the vertex sets of :3078-3111 per block */
+  for (log_mvb_sz = OD_LOG_MVB_DELTA0, level = 1; log_mvb_sz-- > 0 && est->level_max >= level; level++) {
+    int mvb_sz;
+    int n;
+    int cx;
+    int cy;
+    mvb_sz = 1 << log_mvb_sz;
+    /* odd level */
+    n = 0;
+    for (vy = 0; vy < nvmvbs; vy += OD_MVB_DELTA0) {
+      for (vx = 0; vx < nhmvbs; vx += OD_MVB_DELTA0) {
+        for (cy = vy + mvb_sz; cy < vy + OD_MVB_DELTA0; cy += 2*mvb_sz) {
+          for (cx = vx + mvb_sz; cx < vx + OD_MVB_DELTA0; cx += 2*mvb_sz) {
+            mv_verts[n][0] = cx;
+            mv_verts[n][1] = cy;
+            n++;
+          }
+        }
+      }
+    }
+    if (mv_level_with_windows(est, ref, must_update, n) < 0) return -1;
+    level++;
+    if (est->level_max < level) break;
+    /* even level (the quincunx of :3095-3109; a block owns its bottom and right edges, the frame's
+       first row and column of blocks their top and left edges too) */
+    n = 0;
+    for (vy = 0; vy < nvmvbs; vy += OD_MVB_DELTA0) {
+      for (vx = 0; vx < nhmvbs; vx += OD_MVB_DELTA0) {
+        for (cy = vy + mvb_sz*!!vy; cy <= vy + OD_MVB_DELTA0; cy += mvb_sz) {
+          for (cx = vx + (cy & mvb_sz ? 2*mvb_sz*!!vx : mvb_sz); cx <= vx + OD_MVB_DELTA0; cx += 2*mvb_sz) {
+            mv_verts[n][0] = cx;
+            mv_verts[n][1] = cy;
+            n++;
+          }
+        }
+      }
+    }
+    if (mv_level_with_windows(est, ref, must_update, n) < 0) return -1;
+  }
+  od_hipenc_mv_bma_stats(mv_win.hits, mv_win.misses);
+  mv_win.hits = mv_win.misses = 0;
+  return 1;
+}
+
 static void od_mv_est_init_mvs(od_mv_est_ctx *est, int ref, int must_update) {
   double t0;
   t0 = od_hipenc_now();
-  od_mv_est_init_mvs_cpu(est, ref, must_update);
+  /* < 0: a device stage failed mid-way (the frame is marked failed); the grid is left as the
+     completed levels made it - the frame's result is discarded by the caller */
+  if (mv_init_mvs_levels(est, ref, must_update) == 0) od_mv_est_init_mvs_cpu(est, ref, must_update);
   od_hipenc_mv_stage(ref == OD_FRAME_PREV ? OD_HIPENC_MV_INIT_PREV : OD_HIPENC_MV_INIT_OTHER,
    od_hipenc_now() - t0);
 }
@@ -36,11 +259,8 @@ static void od_mv_est_init_mvs(od_mv_est_ctx *est, int ref, int must_update) {
    and a second walk stores them and the blocks' set-up state exactly as the reference does.
    Returns 0 when the call is not the device's (no device thread, B frames, SATD, level_max <= 0:
    the tail loop of the reference): od_mv_est_calc_sads_cpu runs instead. */
-#include "../../include/daala_hip.h"
 int od_hipenc_mv_sad_items(daala_enc_ctx *enc, int nplanes, const od_hip_mc_sad_item *items,
  int nitems, int32_t *sad);
-void od_hipenc_mv_check_fail(long n);
-int od_hipenc_check_mode(void);
 
 static __thread od_hip_mc_sad_item *mv_items;
 static __thread int32_t *mv_sads;
@@ -190,6 +410,13 @@ void od_hipenc_mv_thread_cleanup(void) {
   free(mv_items);
   free(mv_sads);
   free(mv_top);
+  free(mv_recs);
+  free(mv_wins);
+  free(mv_verts);
+  mv_recs = NULL;
+  mv_wins = NULL;
+  mv_verts = NULL;
+  mv_recs_cap = 0;
   mv_items = NULL;
   mv_sads = NULL;
   mv_top = NULL;

@@ -30,7 +30,7 @@
  *     _coeffs / set_bsize / set_decode_info, od_hip_forward_pyramid, od_hip_forward_haar is the
  *     feed's, od_hip_inverse_haar, od_hip_decode_tail, od_hip_download_*, od_hip_enc_feed_*
  *     (4b), od_hip_dering_* (4c), od_hip_pfeed_* (4d), od_hip_dsynth_* (4e), od_hip_mc_create /
- *     destroy / set_ref / set_ref_ctx / set_src / predict / predict_ctx / sad_items, od_hip_pvq_compand,
+ *     destroy / set_ref / set_ref_ctx / set_src / predict / predict_ctx / sad_items / bma_windows, od_hip_pvq_compand,
  *     od_hip_host_register / _unregister, od_hip_last_error, od_hip_device_count.
  *   DRIVER - the device-only path of bench.py and the multi-GPU drivers: od_hip_forward_known,
  *     od_hip_inverse, od_hip_pvq_gains / _compand_level / _search / _noref_search / _nblocks /
@@ -628,6 +628,26 @@ int od_hip_mc_set_src(od_hip_mc *mc, int pli, const unsigned char *plane, int st
  int xdec, int ydec);
 int od_hip_mc_sad_items(od_hip_mc *mc, int nplanes, int pic_w, int pic_h,
  const od_hip_mc_sad_item *items, int nitems, int32_t *sad);
+
+/* F3: dense block-matching windows for the EPZS initialisation of the motion search
+ * (od_mv_est_init_mv, src/mcenc.c:2511).  od_mv_est_bma_sad (:2228-2268) - ONE single-vector
+ * prediction of the block centred on a grid vertex (od_mc_predict1fmv8_c on every plane, the
+ * vector in half samples) + od_enc_sad (:1615) clipped against the picture, chroma >>
+ * OD_MC_CHROMA_SCALE - for EVERY half-sample vector within `radius` of the record's centre (the
+ * vertex's median predictor, known for a whole level of the grid before the level starts), all
+ * records in one launch, against the object's resident references and source planes.
+ *   bx, by: luma position of the block (multiples of 4; may be negative or hang over the frame);
+ *   cx, cy: window centre; xmin..ymax: the vertex's vector limits (od_mv_est_limits), inclusive.
+ * out: [nrec][(2 radius + 1)^2] row-major in (dy, dx); -1 where the vector is outside the limits. */
+typedef struct od_hip_mc_bma_rec {
+  int32_t bx, by;
+  int32_t log_blk_sz;
+  int32_t ref;
+  int32_t cx, cy;
+  int32_t xmin, xmax, ymin, ymax;
+} od_hip_mc_bma_rec;
+int od_hip_mc_bma_windows(od_hip_mc *mc, int nplanes, int pic_w, int pic_h,
+ const od_hip_mc_bma_rec *recs, int nrec, int radius, int32_t *out);
 
 /* A11: od_raster_to_coding_order (to_raster = 0, src/partition.c:144) and
  * od_coding_order_to_raster (to_raster = 1, :176) for nblocks dense n x n blocks

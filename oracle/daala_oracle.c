@@ -20,6 +20,7 @@
  * od_coeff == int32_t (reference src/filter.h:31).
  */
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1515,6 +1516,60 @@ void orc_mv_est_sad_items(const orc_sad_item *items, int nitems, int nplanes,
       total += pli > 0 ? acc >> 2 : acc;
     }
     sad[n] = total;
+  }
+}
+
+/* od_mv_est_bma_sad (src/mcenc.c:2228-2268) for every half-sample vector of a window: the
+   block-matching SAD the EPZS initialisation (od_mv_est_init_mv, :2511) judges its candidates by.
+   ONE single-vector prediction per plane (od_mc_predict1fmv8_c with mvx*(1 << (2 - xdec)), the
+   block's corner at (bx >> xdec, by >> ydec) of the reference - it may lie in the padding), then
+   od_enc_sad (:1615-1681): the block clipped against the picture on all four sides, chroma >>
+   OD_MC_CHROMA_SCALE.  Layout == od_hip_mc_bma_rec; out: [nrec][(2R + 1)^2], -1 outside the limits. */
+typedef struct orc_bma_rec {
+  int32_t bx, by, log_blk_sz, ref, cx, cy, xmin, xmax, ymin, ymax;
+} orc_bma_rec;
+
+void orc_mv_est_bma_windows(const orc_bma_rec *recs, int nrec, int radius, int nplanes,
+ const uint8_t *const refs[3], const int32_t *ref_stride, const int32_t *ref_h,
+ const int32_t *org_x, const int32_t *org_y, const uint8_t *const src[3],
+ const int32_t *src_stride, const int32_t *xdec, const int32_t *ydec, int pic_w, int pic_h,
+ int32_t *out) {
+  static __thread uint8_t pred[64*64];
+  int W = 2*radius + 1;
+  int n, o;
+  for (n = 0; n < nrec; n++) {
+    const orc_bma_rec *r = recs + n;
+    for (o = 0; o < W*W; o++) {
+      int mvx = r->cx + o%W - radius, mvy = r->cy + o/W - radius;
+      int32_t total = 0;
+      int pli;
+      if (mvx < r->xmin || mvx > r->xmax || mvy < r->ymin || mvy > r->ymax) {
+        out[(size_t)n*W*W + o] = -1;
+        continue;
+      }
+      for (pli = 0; pli < nplanes; pli++) {
+        int lx = r->log_blk_sz - xdec[pli], ly = r->log_blk_sz - ydec[pli];
+        int x = r->bx >> xdec[pli], y = r->by >> ydec[pli];
+        int w = 1 << lx, h = 1 << ly;
+        int clipw = (pic_w + (1 << xdec[pli]) - 1) >> xdec[pli];
+        int cliph = (pic_h + (1 << ydec[pli]) - 1) >> ydec[pli];
+        const uint8_t *at = refs[pli] + (size_t)r->ref*ref_stride[pli]*ref_h[pli]
+         + (ptrdiff_t)(org_y[pli] + y)*ref_stride[pli] + org_x[pli] + x;
+        int32_t acc = 0;
+        int i, j;
+        orc_mc_predict1fmv8(pred, at, ref_stride[pli], mvx*(1 << (2 - xdec[pli])),
+         mvy*(1 << (2 - ydec[pli])), lx, ly);
+        for (j = 0; j < h; j++) {
+          for (i = 0; i < w; i++) {
+            if (x + i >= 0 && x + i < clipw && y + j >= 0 && y + j < cliph) {
+              acc += abs((int)pred[(j << lx) + i] - (int)src[pli][(size_t)(y + j)*src_stride[pli] + x + i]);
+            }
+          }
+        }
+        total += pli > 0 ? acc >> 2 : acc;
+      }
+      out[(size_t)n*W*W + o] = total;
+    }
   }
 }
 

@@ -164,3 +164,15 @@ int probe_mvest_get(int32_t *gmvx, int32_t *gmvy, int32_t *gref, unsigned char *
   }
   return 0;
 }
+
+/* od_mv_est_bma_sad (static, src/mcenc.c:2228) on the same state: the SAD of the single-vector
+   prediction of the block at luma (bx, by) - the caller passes the corner, as od_mv_est_init_mv
+   does after centring the block on its vertex - with the half-sample vector (mvx, mvy) from
+   reference frame type `ref` (OD_FRAME_GOLD = 0, OD_FRAME_PREV = 1).  *img receives the image index
+   that frame type maps to (state->ref_imgi[ref]). */
+int32_t probe_mvest_bma_sad(int ref, int bx, int by, int mvx, int mvy, int log_mvb_sz, int *img) {
+  if (g_enc == NULL) return -1;
+  if (img != NULL) *img = g_enc->state.ref_imgi[ref];
+  if (g_enc->state.ref_imgi[ref] < 0) return -1;
+  return od_mv_est_bma_sad(g_enc->mvest, ref, bx, by, mvx, mvy, log_mvb_sz);
+}

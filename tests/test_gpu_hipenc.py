@@ -413,6 +413,9 @@ def test_inter_stream_encoded_through_the_seam():
     # od_mv_est_calc_sads of every P frame came from the device (one fused OBMC + SAD call per
     # frame); in check mode the reference's own loop ran beside it on the same grid
     assert st.mv_dev_calls == 3 and st.mv_dev_sads > 0 and st.mv_check_fail == 0
+    # the EPZS initialisation walked levels >= 1 against device block-matching windows; in check
+    # mode every SAD read from a window was computed again by the reference's od_mv_est_bma_sad
+    assert st.mv_level_walks >= 3 and st.mv_bma_windows > 0 and st.mv_bma_hits > st.mv_bma_misses
 
 
 def test_inter_stream_1080p_pframe_feed_packets_identical():
@@ -464,6 +467,7 @@ def test_inter_gop_golden_frames_and_second_keyframe():
     assert st.pvq_check_fail == 0 and st.check_fail == 0 and st.fdct_check_fail == 0
     assert st.dering_check_fail == 0 and st.dist_check_fail == 0 and st.mv_check_fail == 0
     assert st.pfeed_frames == nf - 2 and st.mv_dev_calls == nf - 2
+    assert st.mv_level_walks >= nf - 2 and st.mv_bma_windows > 0
     hdr = H.headers(prm)
     n0, pics0, _, _ = H.decode(prm, hdr, want, use_device=0)
     n1, pics1, _, _ = H.decode(prm, hdr, want, use_device=1)

@@ -695,6 +695,48 @@ def test_mvest_calc_sads_fused_obmc_sad(hip):
     mc.close()
 
 
+def test_mvest_bma_windows(hip):
+    """F3, EPZS initialisation: od_hip_mc_bma_windows (k_mc_bma_windows: one wave per vertex and
+    window offset) against the REAL od_mv_est_bma_sad's values (tests/golden/mvest_sads.npz: blocks
+    centred on grid vertices, some hanging over the frame on every side) at the window centres, and
+    against the oracle for every half-sample vector of 5x5 windows - with limits that cut some
+    windows, luma only and three planes."""
+    from testlib import BMA_REC, mvest_oracle_bma_windows
+    g = golden('mvest_sads.npz')
+    o = oracle()
+    dims = g['dims']
+    refs = [g['refs%d' % p] for p in range(3)]
+    src = [g['src%d' % p] for p in range(3)]
+    ox = [int(dims[9 + 4*p]) for p in range(3)]
+    oy = [int(dims[10 + 4*p]) for p in range(3)]
+    mc = hip.McSad(refs, ox, oy, src, [(0, 0), (1, 1), (1, 1)])
+    req = g['bma_req']
+    recs = np.zeros(len(req), BMA_REC)
+    recs['bx'], recs['by'], recs['log_blk_sz'], recs['ref'] = req[:, 0], req[:, 1], req[:, 2], req[:, 3]
+    recs['cx'], recs['cy'] = req[:, 4], req[:, 5]
+    recs['xmin'] = recs['ymin'] = -(1 << 13)
+    recs['xmax'] = recs['ymax'] = 1 << 13
+    pw, ph = int(g['pic'][0]), int(g['pic'][1])
+    got = mc.bma_windows(recs, 0, pw, ph)
+    assert np.array_equal(got[:, 0], g['bma_sad'])
+    rng = np.random.default_rng(4)
+    cut = recs[:160].copy()                      # limits that cut the windows
+    cut['xmin'] = cut['cx'] - rng.integers(0, 3, size=len(cut))
+    cut['xmax'] = cut['cx'] + rng.integers(0, 3, size=len(cut))
+    cut['ymin'] = cut['cy'] - rng.integers(0, 3, size=len(cut))
+    cut['ymax'] = cut['cy'] + rng.integers(0, 3, size=len(cut))
+    for nplanes in (3, 1):
+        want = mvest_oracle_bma_windows(o, g, cut, 2, nplanes)
+        got = mc.bma_windows(cut, 2, pw, ph, nplanes)
+        assert (want == -1).any() and (want[:, 12] >= 0).all()
+        assert np.array_equal(got, want), (nplanes, np.argwhere(got != want)[:5])
+    bad = recs[:1].copy()
+    bad['ref'] = refs[0].shape[0]
+    with pytest.raises(hip.HipError):
+        mc.bma_windows(bad, 1, pw, ph)
+    mc.close()
+
+
 def test_reference_image_built_on_the_device_from_a_reconstruction(hip):
     """od_hip_mc_set_ref_ctx (k_mc_ref_from_rec): a context's reconstruction plane becomes a
     reference image of a prediction object ON the device, the padding filled as od_img_edge_ext

@@ -477,3 +477,21 @@ def test_motion_search_stage_timers_and_host_path():
     assert s[7] > 0 and s[0] > 0 and s[2] > 0 and s[6] > 0          # whole, EPZS, calc_sads, sub-pel
     assert sum(s[:5]) + s[6] <= s[7]*1.001                            # the refinement loop is the rest
     assert st.mv_dev_calls == 0 and st.mv_dev_sads == 0 and st.mv_check_fail == 0
+
+
+def test_motion_search_level_by_level_walk_equals_the_reference_walk(monkeypatch):
+    """od_mv_est_init_mvs walks the vector grid block by block in the reference (src/mcenc.c:3036);
+    with a device the integration library walks it LEVEL BY LEVEL (mcenc_tail.c) so that a level's
+    block-matching windows are one device call.  HIPENC_MV_EPZS=2 forces that walk without a device
+    (host SADs): the packets of inter streams - the 33-frame GOP across golden frames and the second
+    keyframe among them - must equal the pure reference encoder's."""
+    from test_gpu_hipenc import ref_encode
+    monkeypatch.setenv('HIPENC_MV_EPZS', '2')
+    for w, h, nf, keyrate in ((176, 144, 33, 30), (150, 100, 9, 3)):
+        buf = inter_stream_frames(w, h, nf)
+        want = ref_encode(w, h, buf, nf, keyrate)
+        prm = H.Params(w, h, 20, 7, 1, 1, 0, 0, keyrate)
+        n, pk, st = H.encode(prm, buf, nf)
+        assert n > 0 and pk == want
+        nkey = (nf + keyrate - 1)//keyrate
+        assert st.mv_level_walks >= nf - nkey and st.mv_bma_windows == 0      # every P frame, at least the previous reference

@@ -257,3 +257,22 @@ def test_mvest_calc_sads_golden():
     got = mvest_split(mvest_oracle_sads(o, g, items), sizes, smax, g['dims'])
     assert np.array_equal(got[1], g['sad1']) and np.array_equal(got[2], g['sad2'])
     assert g['sad1'].max() > 0
+
+
+def test_mvest_bma_sad_golden():
+    """F3: the oracle's od_mv_est_bma_sad (single-vector prediction of every plane + the SAD clipped
+    against the picture on all four sides) against the REAL static function's values for 400 blocks
+    centred on grid vertices - 50 of them hanging over the frame's left or top edge, others over
+    the right / bottom edge - stored in tests/golden/mvest_sads.npz (bma_req, bma_sad)."""
+    from testlib import BMA_REC, mvest_oracle_bma_windows
+    g = load('mvest_sads.npz')
+    o = oracle()
+    req = g['bma_req']
+    recs = np.zeros(len(req), BMA_REC)
+    recs['bx'], recs['by'], recs['log_blk_sz'], recs['ref'] = req[:, 0], req[:, 1], req[:, 2], req[:, 3]
+    recs['cx'], recs['cy'] = req[:, 4], req[:, 5]
+    recs['xmin'] = recs['ymin'] = -(1 << 13)
+    recs['xmax'] = recs['ymax'] = 1 << 13
+    got = mvest_oracle_bma_windows(o, g, recs, 0)
+    assert np.array_equal(got[:, 0], g['bma_sad'])
+    assert (req[:, 0] < 0).sum() + (req[:, 1] < 0).sum() > 20 and g['bma_sad'].max() > 1000

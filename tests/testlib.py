@@ -287,3 +287,30 @@ def mvest_split(sad, sizes, smax, dims):
             out[l] = sad[o:o + sizes[l]].reshape(nv >> l, nh >> l, smax[l])
             o += int(sizes[l])
     return out
+
+
+BMA_REC = np.dtype([('bx', np.int32), ('by', np.int32), ('log_blk_sz', np.int32), ('ref', np.int32),
+                    ('cx', np.int32), ('cy', np.int32), ('xmin', np.int32), ('xmax', np.int32),
+                    ('ymin', np.int32), ('ymax', np.int32)])
+
+
+def mvest_oracle_bma_windows(o, g, recs, radius, nplanes=3):
+    """orc_mv_est_bma_windows on a fixture of the mcenc probe's layout: [nrec][(2R+1)^2]."""
+    dims = g['dims']
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    refs = [np.ascontiguousarray(g['refs%d' % p]) for p in range(3)]
+    src = [np.ascontiguousarray(g['src%d' % p]) for p in range(3)]
+    rs = np.array([dims[7 + 4*p] for p in range(3)], np.int32)
+    rh = np.array([dims[8 + 4*p] for p in range(3)], np.int32)
+    ox = np.array([dims[9 + 4*p] for p in range(3)], np.int32)
+    oy = np.array([dims[10 + 4*p] for p in range(3)], np.int32)
+    ss = np.array([s.shape[1] for s in src], np.int32)
+    dec = np.array([0, 1, 1], np.int32)
+    W = 2*radius + 1
+    out = np.zeros((len(recs), W*W), np.int32)
+    recs = np.ascontiguousarray(recs, dtype=BMA_REC)
+    o.orc_mv_est_bma_windows(ctypes.c_void_p(recs.ctypes.data), len(recs), radius, nplanes,
+                             (U8P*3)(*[pu8(r) for r in refs]), p32(rs), p32(rh), p32(ox), p32(oy),
+                             (U8P*3)(*[pu8(s) for s in src]), p32(ss), p32(dec), p32(dec),
+                             int(g['pic'][0]), int(g['pic'][1]), p32(out))
+    return out

@@ -367,11 +367,33 @@ def mvest_sads():
     sad = [np.zeros((nv >> l, nh >> l, 4), np.int32) for l in range(3)]
     assert mp.probe_mvest_get(p32(gmvx), p32(gmvy), p32(gref), (U8P*3)(*[pu8(a) for a in refs]),
                               (U8P*3)(*[pu8(a) for a in src]), (I32P*3)(*[p32(a) for a in sad])) == 0
+    # od_mv_est_bma_sad (the real static function, same state): block-matching SADs of blocks centred
+    # on grid vertices - also on the frame's edges, where the block hangs over it - for half-sample
+    # vectors around the vertex's own vector, both reference frame types
+    mp.probe_mvest_bma_sad.restype = ctypes.c_int32
+    req, want = [], []
+    for i in range(400):
+        lg = int(g.integers(0, 4))                       # log_mvb_sz: 8x8 .. 64x64
+        n = 8 << lg
+        vx = int(g.integers(0, nh + 1))//(1 << lg)*(1 << lg)
+        vy = int(g.integers(0, nv + 1))//(1 << lg)*(1 << lg)
+        rtype = int(g.integers(0, 2))
+        bx, by = vx*8 - n//2, vy*8 - n//2
+        mvx = int(gmvx[vy, vx])//4 + int(g.integers(-6, 7))
+        mvy = int(gmvy[vy, vx])//4 + int(g.integers(-6, 7))
+        img = ctypes.c_int()
+        v = mp.probe_mvest_bma_sad(rtype, bx, by, mvx, mvy, lg, ctypes.byref(img))
+        if img.value < 0:
+            continue
+        req.append([bx, by, lg + 3, img.value, mvx, mvy])
+        want.append(v)
     mp.probe_mvest_close()
     assert len(np.unique(gref)) >= 2 and np.any(gmvx & 7) and np.any(gmvy & 7), 'grid too tame'
+    assert len(req) > 300 and any(r[0] < 0 for r in req) and any(r[1] < 0 for r in req)
     np.savez_compressed(os.path.join(G, 'mvest_sads.npz'), dims=dims, pic=np.array([w, h], np.int32), gmvx=gmvx,
                         gmvy=gmvy, gref=gref, refs0=refs[0], refs1=refs[1], refs2=refs[2], src0=src[0],
-                        src1=src[1], src2=src[2], sad1=sad[1], sad2=sad[2])
+                        src1=src[1], src2=src[2], sad1=sad[1], sad2=sad[2], bma_req=np.array(req, np.int32),
+                        bma_sad=np.array(want, np.int32))
     print('mvest_sads: grid', gmvx.shape, 'images used', np.unique(gref), 'sad1', sad[1].shape, 'sad2', sad[2].shape)
 
 

@@ -50,6 +50,11 @@ def main():
     if st.mv_dev_calls:
         print('\nDevice batches: %d calls, %d block SADs, %.4f s waiting per P frame.'
               % (st.mv_dev_calls, st.mv_dev_sads, st.mv_dev_wait_s/max(1, npf)))
+    if st.mv_level_walks:
+        print('\nEPZS initialisation walked level by level %d times; %d device calls built the 9x9 block-matching '
+              'windows of %d vertices; `od_mv_est_bma_sad` answered from a window %d times, on the host %d times '
+              '(level 0 and vectors outside a window).'
+              % (st.mv_level_walks, st.mv_bma_calls, st.mv_bma_windows, st.mv_bma_hits, st.mv_bma_misses))
 
 
 if __name__ == '__main__':
