@@ -884,8 +884,8 @@ int od_hip_mc_sad_items(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const o
 int od_hip_mc_bma_windows(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const od_hip_mc_bma_rec *recs,
                           int nrec, int radius, int32_t *out) {
   if (!m || !recs || !out) return fail(OD_HIP_EFAULT, "null pointer");
-  if (nplanes < 1 || nplanes > 3 || pic_w < 1 || pic_h < 1 || nrec < 0 || nrec > 65535 || radius < 0 || radius > 16)
-    return fail(OD_HIP_EINVAL, "bad geometry");      // nrec is the grid's y extent
+  if (nplanes < 1 || nplanes > 3 || pic_w < 1 || pic_h < 1 || nrec < 0 || nrec > (1 << 22) || radius < 0 || radius > 16)
+    return fail(OD_HIP_EINVAL, "bad geometry");
   for (int pli = 0; pli < nplanes; pli++) {
     if (!m->pl[pli].d_refs) return fail(OD_HIP_EINVAL, "no reference planes set for this plane");
     if (!m->src[pli].d) return fail(OD_HIP_EINVAL, "no source plane set for this plane");
@@ -947,12 +947,16 @@ int od_hip_mc_bma_windows(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const
     a.pl[pli].shift = q > 0 ? 2 : 0;                 // OD_MC_CHROMA_SCALE (src/mcenc.c:53)
   }
   a.nplanes = nplanes;
-  a.recs = m->d_recs;
-  a.nrec = nrec;
   a.radius = radius;
-  a.sad = m->d_win;
-  hipLaunchKernelGGL(k_mc_bma_windows, dim3(W*W, nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
-  HIPCHK(hipGetLastError());
+  // the records are the grid's y extent (at most 65 535): a 4K frame's finest level has more
+  constexpr int CHUNK = 32768;
+  for (int r0 = 0; r0 < nrec; r0 += CHUNK) {
+    a.recs = m->d_recs + r0;
+    a.nrec = min(CHUNK, nrec - r0);
+    a.sad = m->d_win + (size_t)r0*W*W;
+    hipLaunchKernelGGL(k_mc_bma_windows, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipMemcpyAsync(m->h_win, m->d_win, nwin*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   memcpy(out, m->h_win, nwin*sizeof(int32_t));

@@ -730,6 +730,15 @@ def test_mvest_bma_windows(hip):
         got = mc.bma_windows(cut, 2, pw, ph, nplanes)
         assert (want == -1).any() and (want[:, 12] >= 0).all()
         assert np.array_equal(got, want), (nplanes, np.argwhere(got != want)[:5])
+    # more records than one launch's grid takes (a 4K frame's finest level): launched in chunks
+    small = cut[cut['log_blk_sz'] == cut['log_blk_sz'].min()]
+    many = np.tile(small, 1 + 40000//len(small))[:40000]
+    assert len(many) == 40000
+    many['cx'] += rng.integers(-6, 7, size=len(many))
+    many['cy'] += rng.integers(-6, 7, size=len(many))
+    want = mvest_oracle_bma_windows(o, g, many, 1, 1)
+    got = mc.bma_windows(many, 1, pw, ph, 1)
+    assert np.array_equal(got, want)
     bad = recs[:1].copy()
     bad['ref'] = refs[0].shape[0]
     with pytest.raises(hip.HipError):
