@@ -157,7 +157,8 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
   using T = RowTile<SB>;
   // lapped spatial tile as int16: |value| <= 6452 for pixel-driven data
   // (tools/range_analysis.py); halves its LDS footprint
-  __shared__ int16_t A[T::HAH*T::LDA];
+  __shared__ __attribute__((aligned(8))) int16_t A_[T::HAH*T::LDA + 2];
+  int16_t *const A = A_ + 2;             // the load stage writes the pair (-2, -1) of row 0
   __shared__ int32_t Z[SB*T::LDZ];
   __shared__ uint8_t bsz[16*T::NSB];
   const int tid = threadIdx.x;
@@ -178,21 +179,40 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
     }
   }
   {
-    // A1: 8-bit pixels -> (p - 128) << 4, dword loads starting 4 bytes left of the tile
+    // A1: 8-bit pixels -> (p - 128) << 4, dword loads starting 4 bytes left of the tile.  All of
+    // a thread's loads are issued before the first conversion (the rolled loop waited for every
+    // load by itself), and a dword's four samples are converted as two packed 16-bit pairs and
+    // stored as two dwords: sample 4*dx + b - 2 of the halo'd row; the pairs (-2, -1) and (68, 69)
+    // fall into the row padding (LDA = HAW + 2; the tile starts two entries into its array).
     const uint8_t *pix = a.pix + (size_t)f*a.pix_fstride;
     constexpr int DW = T::HAW/4 + 1;                   // 18 dwords cover x0-4 .. x0+67
     static_assert(DW == 18, "the division by DW below is spelled for 18");
-    for (int e = tid; e < T::HAH*DW; e += 128) {
+    static_assert(T::LDA == T::HAW + 2 && T::LDA % 2 == 0, "row padding takes the two outer pairs");
+    constexpr int NE = T::HAH*DW, IT = (NE + 127)/128;
+    typedef unsigned short rt_u16x2 __attribute__((ext_vector_type(2)));
+    uint32_t v[IT];
+    int at[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+      const int e = min(tid + it*128, NE - 1);
       const int ty = __umul24(e, 3641) >> 16, dx = e - ty*DW;       // e/18, exact for e < 5000
       const int gy = min(max(y0 - 2 + ty, 0), a.h - 1);
       const int gx = min(max(x0 - 4 + dx*4, 0), a.w - 4);
-      const uint32_t v = *reinterpret_cast<const uint32_t *>(pix + ((unsigned)__umul24(gy, a.pstride) + gx));
+      v[it] = *reinterpret_cast<const uint32_t *>(pix + ((unsigned)__umul24(gy, a.pstride) + gx));
+      at[it] = ty*T::LDA + dx*4 - 2;
+    }
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int txx = dx*4 + b - 2;
-        if (txx >= 0 && txx < T::HAW) {
-          A[ty*T::LDA + txx] = (int16_t)(((int32_t)((v >> (8*b)) & 255) - 128) << 4);
-        }
+    for (int it = 0; it < IT; it++) {
+      if (it + 1 < IT || tid + it*128 < NE) {
+        union { uint32_t u; rt_u16x2 h; } lo, hi;
+        lo.u = __builtin_amdgcn_perm(0u, v[it], 0x0c010c00u);      // bytes 0, 1 -> the two halves
+        hi.u = __builtin_amdgcn_perm(0u, v[it], 0x0c030c02u);      // bytes 2, 3
+        const rt_u16x2 k16 = {16, 16}, kb = {0xf800, 0xf800};       // (p << 4) - (128 << 4), mod 2^16
+        lo.h = lo.h*k16 + kb;
+        hi.h = hi.h*k16 + kb;
+        uint32_t *q = reinterpret_cast<uint32_t *>(A + at[it]);
+        q[0] = lo.u;
+        q[1] = hi.u;
       }
     }
   }
