@@ -74,20 +74,51 @@ __device__ __forceinline__ void rt_store_tile(int32_t *__restrict__ dst, int w, 
   }
 }
 
+// Load stage of the inverse tile kernels (one wave): the tile's block sizes (16 bytes per
+// superblock) and its SB x 64 coefficients, every global load issued before the first wait - the
+// rolled form waited for the block-size byte, then for the tile in two halves, three memory round
+// trips in a wave's life.  Returns the wave's max |coefficient| for the 24-bit-multiplier check
+// (from the registers: the tile is not read back from LDS for it); -v - 1 for negative v, as the
+// range analysis counts it.
 template <int SB>
-__device__ __forceinline__ void rt_load_tile(int32_t *Z, const int32_t *__restrict__ src, int w,
-                                             int x0) {
+__device__ __forceinline__ int rt_load_tile_bsz(int32_t *Z, uint8_t *bsz, const int32_t *__restrict__ src,
+                                                int w, int x0, const uint8_t *__restrict__ bsize,
+                                                int bstride, int sby, int sbx0, int nsb) {
   using T = RowTile<SB>;
+  static_assert(16*T::NSB <= 64, "one block-size byte per lane");
   const int lane = threadIdx.x;
   const int r0 = lane & 3, c4 = (lane >> 2)*4;
+  int b = 3;
+  {
+    const int s = lane >> 4, c = lane & 15;
+    if (lane < 16*T::NSB && s < nsb) b = bsize[(size_t)(sby*4 + (c >> 2))*bstride + (sbx0 + s)*4 + (c & 3)];
+  }
+  int4 v[SB/4];
+#pragma unroll
+  for (int it = 0; it < SB/4; it++) v[it] = make_int4(0, 0, 0, 0);
+  if (x0 + c4 < w) {
+    // one address per lane and a uniform row step (no 64-bit multiply-add per load)
+    const int32_t *q = src + (size_t)(unsigned)__umul24(r0, w) + c4;
+    const size_t step = (size_t)4*(unsigned)w;
+#pragma unroll
+    for (int it = 0; it < SB/4; it++) {
+      v[it] = *reinterpret_cast<const int4 *>(q);
+      q += step;
+    }
+  }
+  if (lane < 16*T::NSB) bsz[lane] = (uint8_t)b;
+  int hi = 0, lo = 0;
 #pragma unroll
   for (int it = 0; it < SB/4; it++) {
-    const int r = it*4 + r0;
-    int4 v = make_int4(0, 0, 0, 0);
-    if (x0 + c4 < w) v = *reinterpret_cast<const int4 *>(src + (size_t)r*w + c4);
-    int32_t *p = Z + r*T::LDZ + c4;
-    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    int32_t *p = Z + (it*4 + r0)*T::LDZ + c4;
+    p[0] = v[it].x; p[1] = v[it].y; p[2] = v[it].z; p[3] = v[it].w;
+    hi = max(max(hi, v[it].x), max(v[it].y, max(v[it].z, v[it].w)));
+    lo = min(min(lo, v[it].x), min(v[it].y, min(v[it].z, v[it].w)));
   }
+  int mx = max(hi, -(lo + 1));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+  return mx;
 }
 
 // Raw workgroup barrier for the two waves of a row-tile workgroup: waits for the
@@ -170,12 +201,12 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
   const int sbx0 = tx*T::NSB;                          // first superblock of the tile
   const int nsb = min(T::NSB, a.nhsb - sbx0);          // superblocks really present
   const int dec = a.dec;
+  static_assert(16*T::NSB <= 128, "one block-size byte per thread");
+  int bsz_mine = 3;                                    // stored behind the pixel loads: one wait for both
   if (KNOWN) {
-    for (int e = tid; e < 16*T::NSB; e += 128) {
-      const int s = e >> 4, c = e & 15;
-      bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
-                                 (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
-                       : 3;
+    const int s = tid >> 4, c = tid & 15;
+    if (tid < 16*T::NSB && s < nsb) {
+      bsz_mine = a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)];
     }
   }
   {
@@ -201,9 +232,12 @@ __global__ __launch_bounds__(128) void k_forward_rt(FwdArgs a) {
       v[it] = *reinterpret_cast<const uint32_t *>(pix + ((unsigned)__umul24(gy, a.pstride) + gx));
       at[it] = ty*T::LDA + dx*4 - 2;
     }
+    if (KNOWN && tid < 16*T::NSB) bsz[tid] = (uint8_t)bsz_mine;
+    // threads beyond the last entry repeat it (same address, same value): no branch around the
+    // last round, so its load is issued with the others
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-      if (it + 1 < IT || tid + it*128 < NE) {
+      {
         union { uint32_t u; rt_u16x2 h; } lo, hi;
         lo.u = __builtin_amdgcn_perm(0u, v[it], 0x0c010c00u);      // bytes 0, 1 -> the two halves
         hi.u = __builtin_amdgcn_perm(0u, v[it], 0x0c030c02u);      // bytes 2, 3
@@ -425,28 +459,15 @@ __global__ __launch_bounds__(64) void k_inverse_rt(InvArgs a) {
   using T = RowTile<SB>;
   __shared__ int32_t Z[SB*T::LDZ];
   __shared__ uint8_t bsz[16*T::NSB];
-  const int lane = threadIdx.x;
   int tx, sby, f;
   rt_tile_coords(tx, sby, f);
   const int x0 = tx*T::W, y0 = sby*SB;
   const int sbx0 = tx*T::NSB;
   const int nsb = min(T::NSB, a.nhsb - sbx0);
-  for (int e = lane; e < 16*T::NSB; e += 64) {
-    const int s = e >> 4, c = e & 15;
-    bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
-                               (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
-                     : 3;
-  }
-  rt_load_tile<SB>(Z, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0);
+  // range check for the 24-bit multiplier: the tile's largest magnitude
+  const int mx = rt_load_tile_bsz<SB>(Z, bsz, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0,
+                                      a.bsize + (size_t)f*a.bsize_fstride, a.bstride, sby, sbx0, nsb);
   rt_sync();
-  // range check for the 24-bit multiplier
-  int mx = 0;
-  for (int e = lane; e < SB*T::W; e += 64) {
-    const int v = Z[(e >> 6)*T::LDZ + (e & 63)];
-    mx = max(mx, v < 0 ? -(v + 1) : v);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
   if (mx <= (1 << 18)) {
     rt_inverse_body<SB, NLEV, true>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
   }
@@ -532,21 +553,9 @@ __global__ __launch_bounds__(64, RT_FUSED_WAVES) void k_inverse_rt_fused(InvArgs
     const int tw = min(T::W, a.w - x0);
     const bool first = t == 0;                                   // the segment's left edge
     const bool lastt = t == RT_SEG - 1 || tx == a.ntx - 1;       // the segment's right edge
-    for (int e = lane; e < 16*T::NSB; e += 64) {
-      const int s = e >> 4, c = e & 15;
-      bsz[e] = s < nsb ? a.bsize[(size_t)f*a.bsize_fstride +
-                                 (size_t)(sby*4 + (c >> 2))*a.bstride + (sbx0 + s)*4 + (c & 3)]
-                       : 3;
-    }
-    rt_load_tile<SB>(Z, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0);
+    const int mx = rt_load_tile_bsz<SB>(Z, bsz, a.d + (size_t)f*a.fstride + (size_t)y0*a.w + x0, a.w, x0,
+                                        a.bsize + (size_t)f*a.bsize_fstride, a.bstride, sby, sbx0, nsb);
     rt_sync();
-    int mx = 0;
-    for (int e = lane; e < SB*T::W; e += 64) {
-      const int v = Z[(e >> 6)*T::LDZ + (e & 63)];
-      mx = max(mx, v < 0 ? -(v + 1) : v);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
     if (mx <= (1 << 18)) rt_inverse_body<SB, NLEV, true>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
     else rt_inverse_body<SB, NLEV, false>(Z, bsz, nsb, a.dec, tx, sby, a.pic_w, a.pic_h);
     // first pass on the tile-internal vertical superblock boundaries
@@ -652,27 +661,59 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
   // strips and bytes already final there): only segment edges are handled here
   const bool lseg = tx%RT_SEG == 0, rseg = tx%RT_SEG == RT_SEG - 1 || tx == a.ntx - 1;
   const bool left = tx > 0 && lseg, right = tx < a.ntx - 1 && rseg, top = sby > 0, last = sby == a.nvsb - 1;
+  // Every strip value the wave needs is loaded FIRST (raw int16: up to four 8-byte column-strip rows
+  // and six row-strip entries per lane, all independent), then the rare escapes are resolved: the
+  // straight-line form loaded a row, waited, looked for the marker, loaded the next - some twenty
+  // memory round trips in a wave that computes for a microsecond.
+  auto csraw = [&](int t, int y) -> uint2 {
+    return *reinterpret_cast<const uint2 *>(cs + ((size_t)t*a.h + y)*4);
+  };
   // the four strip columns of row y of tile t: its columns 0, 1, tw_t-2, tw_t-1
-  auto csrow = [&](int t, int y) -> int4 {
-    const uint2 u = *reinterpret_cast<const uint2 *>(cs + ((size_t)t*a.h + y)*4);
+  auto csval = [&](uint2 u, int t, int y) -> int4 {
     const int xt = t*T::W, twt = min(T::W, a.w - xt);
     const int32_t *e = esc + (size_t)y*a.w + xt;
     return make_int4(strip_get((int16_t)(u.x & 0xffff), e), strip_get((int16_t)(u.x >> 16), e + 1),
                      strip_get((int16_t)(u.y & 0xffff), e + twt - 2), strip_get((int16_t)(u.y >> 16), e + twt - 1));
   };
-  auto rsat = [&](int row4, size_t col, int y) -> int32_t {
-    return strip_get(rs[(size_t)row4*a.w + col], esc + (size_t)y*a.w + col);
-  };
+  const bool p1 = lane < SB, p1cur = p1 && (lseg || tx == a.ntx - 1), p1prv = p1 && lseg && left;
+  uint2 u1c = make_uint2(0, 0), u1p = make_uint2(0, 0);
+  if (p1cur) u1c = csraw(tx, y0 + lane);
+  if (p1prv) u1p = csraw(tx - 1, y0 + lane);
+  // the rows of the horizontal boundary above this tile (y0-2 .. y0+1) and, on the last tile row,
+  // the frame's last two rows: lane = 2*slot + side
+  const int k2 = lane >> 1, side = lane & 1;           // row slot, 0 = left boundary / 1 = right boundary
+  const int y2 = k2 < 4 ? y0 - 2 + k2 : y0 + SB - 6 + k2;   // slots 4, 5 -> y0 + SB - 2, y0 + SB - 1
+  const bool p2 = lane < 12 && (k2 < 4 ? (y2 >= 0) : last) && (side == 0 ? lseg : rseg);
+  const bool p2oth = p2 && (side == 0 ? left : right);
+  uint2 u2c = make_uint2(0, 0), u2o = make_uint2(0, 0);
+  if (p2) u2c = csraw(tx, y2);
+  if (p2oth) u2o = csraw(side == 0 ? tx - 1 : tx + 1, y2);
+  const bool p3 = lane < tw;
+  const size_t col = (size_t)x0 + lane;
+  int16_t r3[6] = {0, 0, 0, 0, 0, 0};
+  if (p3) {
+    if (top) {
+      r3[0] = rs[(size_t)((sby - 1)*4 + 2)*a.w + col];
+      r3[1] = rs[(size_t)((sby - 1)*4 + 3)*a.w + col];
+    }
+    r3[2] = rs[(size_t)(sby*4 + 0)*a.w + col];
+    r3[3] = rs[(size_t)(sby*4 + 1)*a.w + col];
+    if (last) {
+      r3[4] = rs[(size_t)(sby*4 + 2)*a.w + col];
+      r3[5] = rs[(size_t)(sby*4 + 3)*a.w + col];
+    }
+  }
   // first pass across the left segment boundary, this tile's interior rows
-  if (lane < SB) {
+  if (p1) {
     const int r = lane;
     const bool inner = r >= 2 && r < SB - 2;
     uint8_t *q = rec + (size_t)(y0 + r)*a.w + x0;
+    int4 cur = make_int4(0, 0, 0, 0);
+    if (p1cur) cur = csval(u1c, tx, y0 + r);
     if (lseg) {
-      const int4 cur = csrow(tx, y0 + r);
       int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
       if (left) {
-        const int4 prv = csrow(tx - 1, y0 + r);
+        const int4 prv = csval(u1p, tx - 1, y0 + r);
         v0 = prv.z; v1 = prv.w;
         lap4_post(v0, v1, v2, v3);
       }
@@ -683,53 +724,43 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
     }
     if (tx == a.ntx - 1 && inner) {
       // the frame's right edge has no boundary: its last two columns are only clamped
-      const int4 cur = csrow(tx, y0 + r);
       *reinterpret_cast<uint16_t *>(q + tw - 2) = (uint16_t)(clamp8(cur.z) | clamp8(cur.w) << 8);
     }
   }
-  // the first pass redone for the rows of the horizontal boundary above this tile
-  // (y0-2 .. y0+1) and, on the last tile row, for the frame's last two rows
-  if (lane < 12) {
-    const int k = lane >> 1, side = lane & 1;          // row slot, 0 = left boundary / 1 = right boundary
-    const int y = k < 4 ? y0 - 2 + k : y0 + SB - 6 + k;  // k = 4, 5 -> y0 + SB - 2, y0 + SB - 1
-    const bool need = k < 4 ? (y >= 0) : last;
-    if (need) {
-      const int4 cur = csrow(tx, y);
-      if (side == 0 && !lseg) { /* finished in the tile kernel */ }
-      else if (side == 1 && !rseg) { /* likewise */ }
-      else if (side == 0) {
-        int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
-        if (left) {
-          const int4 prv = csrow(tx - 1, y);
-          v0 = prv.z; v1 = prv.w;
-          lap4_post(v0, v1, v2, v3);
-        }
-        E[k][0] = v2; E[k][1] = v3;
+  // the first pass redone for the boundary rows (inside a segment the tile kernel finished them)
+  if (p2) {
+    const int4 cur = csval(u2c, tx, y2);
+    if (side == 0) {
+      int32_t v0 = 0, v1 = 0, v2 = cur.x, v3 = cur.y;
+      if (left) {
+        const int4 prv = csval(u2o, tx - 1, y2);
+        v0 = prv.z; v1 = prv.w;
+        lap4_post(v0, v1, v2, v3);
       }
-      else {
-        int32_t v0 = cur.z, v1 = cur.w, v2 = 0, v3 = 0;
-        if (right) {
-          const int4 nxt = csrow(tx + 1, y);
-          v2 = nxt.x; v3 = nxt.y;
-          lap4_post(v0, v1, v2, v3);
-        }
-        E[k][2] = v0; E[k][3] = v1;
+      E[k2][0] = v2; E[k2][1] = v3;
+    }
+    else {
+      int32_t v0 = cur.z, v1 = cur.w, v2 = 0, v3 = 0;
+      if (right) {
+        const int4 nxt = csval(u2o, tx + 1, y2);
+        v2 = nxt.x; v3 = nxt.y;
+        lap4_post(v0, v1, v2, v3);
       }
+      E[k2][2] = v0; E[k2][3] = v1;
     }
   }
   __syncthreads();
   // second pass across the horizontal boundary above this tile, one column per lane
-  if (lane < tw) {
+  if (p3) {
     const int c = lane;
     const int ei = (c < 2 && lseg) ? c : (c >= tw - 2 && rseg) ? c - (tw - 4) : -1;
-    const size_t col = (size_t)x0 + c;
-    int32_t v[4];
+    int32_t v[4] = {0, 0, 0, 0};
     if (top) {
-      v[0] = rsat((sby - 1)*4 + 2, col, y0 - 2);
-      v[1] = rsat((sby - 1)*4 + 3, col, y0 - 1);
+      v[0] = strip_get(r3[0], esc + (size_t)(y0 - 2)*a.w + col);
+      v[1] = strip_get(r3[1], esc + (size_t)(y0 - 1)*a.w + col);
     }
-    v[2] = rsat(sby*4 + 0, col, y0);
-    v[3] = rsat(sby*4 + 1, col, y0 + 1);
+    v[2] = strip_get(r3[2], esc + (size_t)y0*a.w + col);
+    v[3] = strip_get(r3[3], esc + (size_t)(y0 + 1)*a.w + col);
     if (ei >= 0) {
       if (top) { v[0] = E[0][ei]; v[1] = E[1][ei]; }
       v[2] = E[2][ei]; v[3] = E[3][ei];
@@ -742,7 +773,8 @@ __global__ __launch_bounds__(64) void k_inverse_strips(InvArgs a) {
     rec[(size_t)y0*a.w + col] = (uint8_t)clamp8(v[2]);
     rec[(size_t)(y0 + 1)*a.w + col] = (uint8_t)clamp8(v[3]);
     if (last) {
-      int32_t b0 = rsat(sby*4 + 2, col, y0 + SB - 2), b1 = rsat(sby*4 + 3, col, y0 + SB - 1);
+      int32_t b0 = strip_get(r3[4], esc + (size_t)(y0 + SB - 2)*a.w + col);
+      int32_t b1 = strip_get(r3[5], esc + (size_t)(y0 + SB - 1)*a.w + col);
       if (ei >= 0) { b0 = E[4][ei]; b1 = E[5][ei]; }
       rec[(size_t)(y0 + SB - 2)*a.w + col] = (uint8_t)clamp8(b0);
       rec[(size_t)(y0 + SB - 1)*a.w + col] = (uint8_t)clamp8(b1);
