@@ -169,8 +169,8 @@ struct TailShared {
   int32_t cost[128];                        // [block][direction]
   int dirs[16], vars[16], thresh[16];
   int doff[16*3];                           // tap offsets of each block's direction
-  int16_t tab_off[24];                      // TAIL_DIR as tile offsets (dy*TAIL_BSTRIDE + dx), [direction][tap]
-  int16_t tab_thr[18];                      // TAIL_THRESH_Q8
+  int16_t tab[64];                          // [0, 24): TAIL_DIR as tile offsets (dy*TAIL_BSTRIDE + dx), [direction][tap];
+                                            // [32, 50): TAIL_THRESH_Q8 - one entry per lane, one store
 };
 
 // A plane's (n + 6)^2 tile on its way from HBM to LDS, held in registers between the ISSUE of
@@ -185,10 +185,18 @@ struct TailTile {
   static constexpr int LPR = n/4, RPP = 64/LPR;            // interior: lanes per row, rows per pass
   static constexpr int NPASS = (tw + RPP - 1)/RPP, NB = (6*tw + 63)/64;
   int4 q[NPASS];            // four interior samples per pass (int16 input: two dwords used)
-  int b[NB];                // border columns, one sample per pass
-  int skip;                 // lanes 0 .. 15: the block's neighbourhood was skipped entirely
+  int b[NB];                // border columns, one sample per pass (raw: the commit converts)
+  int sk[16];               // the skip flags of a block's 4x4 neighbourhood (lanes & 15 = block)
 };
 
+__device__ __forceinline__ int tail_clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+// ISSUE: nothing but address arithmetic and loads - no load sits behind a lane-dependent branch
+// and no loaded value is touched, so the whole tile (interior passes, border columns, skip flags)
+// leaves in one batch.  Rows, columns and flags outside the frame or the neighbourhood are read
+// from the nearest valid position instead and discarded at the commit, which repeats the test.
+// (The first form had each load in its own `if`, its value converted right there: the compiler
+// waited for every one of them in turn - 25 memory round trips for a luma tile.)
 template <int LN>
 __device__ __forceinline__ void tail_tile_issue(TailTile<LN> &T, const TailArgs &a, int pli, int sbx, int sby,
                                                 int f, bool enc_mode, int lane) {
@@ -196,60 +204,78 @@ __device__ __forceinline__ void tail_tile_issue(TailTile<LN> &T, const TailArgs 
   constexpr int n = TT::n, tw = TT::tw, xdec = 5 - LN;
   const int w = a.fw >> xdec;
   const size_t porg = (size_t)f*a.fstride[pli] + (size_t)(sby << LN)*w + (sbx << LN);
-  const int32_t *P = enc_mode ? nullptr : a.p[pli] + porg;
-  const int16_t *P16 = enc_mode ? a.p16[pli] + porg : nullptr;
   // tile with a 3-sample border; outside the frame: OD_DERING_VERY_LARGE (filled at commit)
   const int lo_i = -3*(sby != 0), hi_i = n + 3*(sby != a.nvsb - 1);
   const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
   // interior columns 0 .. n - 1 of rows -3 .. n + 2: always inside the frame horizontally and
   // aligned - four samples per lane and load
   const int c4 = (lane % TT::LPR)*4, r0 = lane/TT::LPR;
-#pragma unroll
-  for (int pass = 0; pass < TT::NPASS; pass++) {
-    const int ii = pass*TT::RPP + r0 - 3;
-    T.q[pass] = make_int4(0, 0, 0, 0);
-    if (ii >= lo_i && ii < hi_i) {
-      if (enc_mode) {
-        const int2 u = *reinterpret_cast<const int2 *>(P16 + (ptrdiff_t)ii*w + c4);
-        T.q[pass].x = u.x;
-        T.q[pass].y = u.y;
-      }
-      else T.q[pass] = *reinterpret_cast<const int4 *>(P + (ptrdiff_t)ii*w + c4);
-    }
-  }
-  // the three border columns on either side
+  int bofs[TT::NB];
 #pragma unroll
   for (int it = 0; it < TT::NB; it++) {
-    const int e = lane + 64*it;
+    const int e = min(lane + 64*it, 6*tw - 1);
     const int r = e/6, c6 = e - 6*r;
-    const int ii = r - 3, jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
-    T.b[it] = TAIL_VERY_LARGE;
-    if (e < 6*tw && ii >= lo_i && ii < hi_i && jj >= lo_j && jj < hi_j) {
-      T.b[it] = enc_mode ? (int)P16[(ptrdiff_t)ii*w + jj] : (int)(int16_t)P[(ptrdiff_t)ii*w + jj];
+    const int ii = tail_clampi(r - 3, lo_i, hi_i - 1);
+    const int jj = tail_clampi(c6 < 3 ? c6 - 3 : n + c6 - 3, lo_j, hi_j - 1);
+    bofs[it] = ii*w + jj;
+  }
+  if (enc_mode) {
+    const int16_t *P16 = a.p16[pli] + porg;
+#pragma unroll
+    for (int pass = 0; pass < TT::NPASS; pass++) {
+      const int ii = tail_clampi(pass*TT::RPP + r0 - 3, lo_i, hi_i - 1);
+      const int2 u = *reinterpret_cast<const int2 *>(P16 + (ptrdiff_t)ii*w + c4);
+      T.q[pass] = make_int4(u.x, u.y, 0, 0);
     }
+#pragma unroll
+    for (int it = 0; it < TT::NB; it++) T.b[it] = P16[bofs[it]];
+  }
+  else {
+    const int32_t *P = a.p[pli] + porg;
+#pragma unroll
+    for (int pass = 0; pass < TT::NPASS; pass++) {
+      const int ii = tail_clampi(pass*TT::RPP + r0 - 3, lo_i, hi_i - 1);
+      T.q[pass] = *reinterpret_cast<const int4 *>(P + (ptrdiff_t)ii*w + c4);
+    }
+#pragma unroll
+    for (int it = 0; it < TT::NB; it++) T.b[it] = P[bofs[it]];
   }
   // skipped neighbourhood => no filtering (src/filter.c:1898-1917): every flag of the block's
   // neighbourhood is read (no early exit: the loads leave together)
-  T.skip = 0;
-  if (lane < 16) {
-    const int by = lane >> 2, bx = lane & 3;
+  {
+    const int by = (lane >> 2) & 3, bx = lane & 3;
     const int sstride = a.fw/4;
     const uint8_t *bs = a.bskip[pli] + (size_t)f*a.bskip_fstride +
                         (size_t)(sby << (3 - xdec))*sstride + (sbx << (3 - xdec));
     const int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
     const int xend = (2 >> xdec) + (sbx != a.nhsb - 1), yend = (2 >> xdec) + (sby != a.nvsb - 1);
-    int all = 1;
 #pragma unroll
     for (int ii = -1; ii < 3; ii++) {
 #pragma unroll
       for (int jj = -1; jj < 3; jj++) {
-        if (ii >= ystart && ii < yend && jj >= xstart && jj < xend) {
-          all &= bs[(ptrdiff_t)((by << 1 >> xdec) + ii)*sstride + (bx << 1 >> xdec) + jj] != 0;
-        }
+        const int ci = tail_clampi(ii, ystart, yend - 1), cj = tail_clampi(jj, xstart, xend - 1);
+        T.sk[(ii + 1)*4 + jj + 1] = bs[(ptrdiff_t)((by << 1 >> xdec) + ci)*sstride + (bx << 1 >> xdec) + cj];
       }
     }
-    T.skip = all;
   }
+}
+
+// the block's whole neighbourhood was skipped (lanes 0 .. 15 ask): flags outside the
+// neighbourhood - the issue read a neighbour of theirs - do not count
+template <int LN>
+__device__ __forceinline__ int tail_tile_skip(const TailTile<LN> &T, const TailArgs &a, int sbx, int sby) {
+  constexpr int xdec = 5 - LN;
+  const int xstart = sbx == 0 ? 0 : -1, ystart = sby == 0 ? 0 : -1;
+  const int xend = (2 >> xdec) + (sbx != a.nhsb - 1), yend = (2 >> xdec) + (sby != a.nvsb - 1);
+  int all = 1;
+#pragma unroll
+  for (int ii = -1; ii < 3; ii++) {
+#pragma unroll
+    for (int jj = -1; jj < 3; jj++) {
+      if (ii >= ystart && ii < yend && jj >= xstart && jj < xend) all &= T.sk[(ii + 1)*4 + jj + 1] != 0;
+    }
+  }
+  return all;
 }
 
 // IN1: the filtered tile's border is written too (not for luma, whose direction search uses
@@ -284,14 +310,17 @@ __device__ __forceinline__ void tail_tile_commit(const TailTile<LN> &T, const Ta
       }
     }
   }
+  const int lo_j = -3*(sbx != 0), hi_j = n + 3*(sbx != a.nhsb - 1);
 #pragma unroll
   for (int it = 0; it < TT::NB; it++) {
     const int e = lane + 64*it;
     const int r = e/6, c6 = e - 6*r;
-    const int jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
+    const int ii = r - 3, jj = c6 < 3 ? c6 - 3 : n + c6 - 3;
     if (e < 6*tw) {
-      S.in0[r*TAIL_BSTRIDE + jj + 3] = (int16_t)T.b[it];
-      if (IN1) S.in1[r*TAIL_BSTRIDE + jj + 3] = (int16_t)T.b[it];
+      const bool in = ii >= lo_i && ii < hi_i && jj >= lo_j && jj < hi_j;
+      const int16_t v = in ? (int16_t)T.b[it] : (int16_t)TAIL_VERY_LARGE;
+      S.in0[r*TAIL_BSTRIDE + jj + 3] = v;
+      if (IN1) S.in1[r*TAIL_BSTRIDE + jj + 3] = v;
     }
   }
 }
@@ -388,7 +417,7 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
       // reuses them): keeps the per-pixel loop free of constant-memory gathers
       if (lane < 48) {
         const int blk = lane/3, k = lane - 3*blk;
-        S.doff[lane] = S.tab_off[S.dirs[blk]*3 + k];
+        S.doff[lane] = S.tab[S.dirs[blk]*3 + k];
       }
       if (lane < 16) {
         int varsum = 0;
@@ -400,13 +429,13 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
         int il = pr ? 32 - __clz(pr) : 0;
         il = il - 9;
         il = il < 0 ? 0 : il > 17 ? 17 : il;
-        S.thresh[lane] = a.thr[0]*S.tab_thr[il] >> 8;
+        S.thresh[lane] = a.thr[0]*S.tab[32 + il] >> 8;
       }
       tail_border_copy<LN>(S, lane);       // the line sums are done with: the space is the filtered tile now
     }
     else if (lane < 16) S.thresh[lane] = a.thr[pli];
     TAIL_STAMP(1);                                   // directions
-    if (lane < 16 && T.skip) S.thresh[lane] = 0;     // a lane only rewrites its own entry
+    if (lane < 16 && tail_tile_skip<LN>(T, a, sbx, sby)) S.thresh[lane] = 0;     // a lane only rewrites its own entry
     __syncthreads();
     TAIL_STAMP(2);                                   // thresholds, skip test
     // direction filter (src/filter.c:1714-1740); a lane stays in one block column, and in one
@@ -462,12 +491,13 @@ __device__ __forceinline__ void tail_plane(const TailArgs &a, TailShared &S, int
     __syncthreads();           // the tiles are rewritten by the next plane
     TAIL_STAMP(4);                                   // orthogonal filter
   }
+  else if (enc_mode) {
+#pragma unroll
+    for (int r = 0; r < NPX; r++) o[r] = P16[(size_t)(r*RSTEP + i0)*w + j];
+  }
   else {
 #pragma unroll
-    for (int r = 0; r < NPX; r++) {
-      const int i = r*RSTEP + i0;
-      o[r] = enc_mode ? (int32_t)P16[(size_t)i*w + j] : P[(size_t)i*w + j];
-    }
+    for (int r = 0; r < NPX; r++) o[r] = P[(size_t)(r*RSTEP + i0)*w + j];
   }
   if (smooth_on) {
     // od_bilinear_smooth (src/filter.c:1952-2008) on the whole n x n tile: corners from the
@@ -551,14 +581,19 @@ __global__ __launch_bounds__(TAIL_THREADS, F420 ? 4 : 2) void k_decode_tail(Tail
   int sbx, sby, f;
   xcd_tile_coords(sbx, sby, f);        // 3-sample borders: neighbours share lines
   const bool enc_mode = a.flags == nullptr;
-  const int flag = enc_mode ? 1 : a.flags[(size_t)f*a.nhsb*a.nvsb + sby*a.nhsb + sbx];
+  // the superblock's flag and block size and the two small tables of the direction search: four
+  // independent reads, one wait (every lane reads a valid table entry; the tables go to LDS so
+  // that their reads do not stand in the dependent chain after the search)
+  int flag = 1, sb_bsize = 0;
+  if (!enc_mode) {
+    flag = a.flags[(size_t)f*a.nhsb*a.nvsb + sby*a.nhsb + sbx];
+    sb_bsize = a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];
+  }
+  const int lo_ = lane < 24 ? lane : 23, lt_ = lane >= 32 && lane < 50 ? lane - 32 : 0;
+  const int t_dy = TAIL_DIR[lo_/3][lo_%3][0], t_dx = TAIL_DIR[lo_/3][lo_%3][1], t_thr = TAIL_THRESH_Q8[lt_];
   const bool dering_on = a.q[0] > 0 && flag;
-  const int sb_bsize = enc_mode ? 0 : a.bsize[(size_t)f*a.bsize_fstride + (size_t)(sby*4)*a.bstride + sbx*4];
   const bool smooth_on = !enc_mode && a.q[0] > 0 && a.is_keyframe && sb_bsize == 3;
-  // the two small tables of the direction search go to LDS now: their constant-memory reads
-  // travel with the tile loads instead of standing in the dependent chain after the search
-  if (lane < 24) S.tab_off[lane] = (int16_t)(TAIL_DIR[lane/3][lane%3][0]*TAIL_BSTRIDE + TAIL_DIR[lane/3][lane%3][1]);
-  else if (lane >= 32 && lane < 50) S.tab_thr[lane - 32] = TAIL_THRESH_Q8[lane - 32];
+  S.tab[lane] = (int16_t)(lane < 24 ? t_dy*TAIL_BSTRIDE + t_dx : t_thr);      // no branch: the reads stay up here
   if (F420) {
     TailTile<5> t0;
     TailTile<4> t1, t2;

@@ -9,7 +9,7 @@ for r in $(seq 1 $R); do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 ds=d['device_step']
-print('$lib', 'step %.3f ms' % ds['ms_per_step'], ' '.join('%s=%.4f' % (k.replace('k_',''), v['avg_ms']) for k,v in ds['kernels'].items() if 'pvq' not in k), 'roofline %.4f' % d['roofline']['frac'])
+print('$lib', 'step %.3f ms' % ds['ms_per_step'], ' '.join('%s=%.4f' % (k.replace('k_',''), v['avg_ms']) for k,v in ds['kernels'].items() if 'pvq' not in k), 'tail %.4f' % ds['decode_tail']['ms_per_30_frames'], 'roofline %.4f' % d['roofline']['frac'])
 "
   done
 done
