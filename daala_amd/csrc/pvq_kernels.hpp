@@ -225,9 +225,13 @@ __device__ __attribute__((noinline)) double pvq_rsqrt_slow(int i) {
 #ifndef PVQ_G16
 #define PVQ_G16 1             /* lanes per 7..15-coefficient band */
 #endif
+#ifndef PVQ_G8
+#define PVQ_G8 PVQ_G16        /* lanes per 8-coefficient band; 2 measured in round 4: launch alone 0.053 -> 0.060 ms,
+                                 overlapped 0.105 -> 0.128 (tree + verification cost more than the shorter scan saves) */
+#endif
 template <int N>
 struct PvqGeom {
-  static constexpr int G = N > 32 ? PVQ_G128 : N > 16 ? PVQ_G32 : PVQ_G16;
+  static constexpr int G = N > 32 ? PVQ_G128 : N > 16 ? PVQ_G32 : N == 8 ? PVQ_G8 : PVQ_G16;
   static constexpr int NL = (N + G - 1)/G;
   static constexpr int BPW = 64/G;               // bands per wave
 };
@@ -598,6 +602,9 @@ struct PvqLevelArgs3 {
 #ifndef PVQ_STAGE_MIN_N
 #define PVQ_STAGE_MIN_N 32    /* bands longer than this are gathered through LDS (measured: pays for 128 only) */
 #endif
+#ifndef PVQ_RANK_MAJOR
+#define PVQ_RANK_MAJOR 0      /* 1: list position runs slowest in dispatch order (experiment, measured: see k_pvq_cand) */
+#endif
 #ifndef PVQ_V4_WAVES
 /* min waves/SIMD asked of the register allocator (512/w registers per lane) */
 #define PVQ_V4_WAVES(N) 3     /* no spills at 168 registers for every N; 4 and more spill into the scans */
@@ -933,9 +940,30 @@ __global__ __launch_bounds__(64, PVQ_V4_WAVES(N)) void k_pvq_cand(PvqLevelArgs3 
   __shared__ double RsqL[PVQ_RSQ_L(N)];
   const int lane = threadIdx.x;
   const int g = lane%G, inst = lane/G;
-  const long idx0 = 2*a.blk_first + (long)blockIdx.x*BPW;      // position in the band's work list
+  // Which (list position, band, frame) this workgroup takes.  The hardware hands workgroups out
+  // with x running fastest: the K-sorted list of frame 0 is walked from its longest search to its
+  // shortest before frame 1's longest search starts, and the last frame's K = 700 waves begin when
+  // the launch is almost over.  PVQ_RANK_MAJOR = 1 splits the place in dispatch order so that the
+  // list position runs SLOWEST (all bands and frames start their longest candidates first; every
+  // (x, y, z) still taken exactly once).  Measured round 4, alternating builds on one box, launches
+  // alone on the chip: <128> 0.812 -> 0.787 ms, <32> 0.219 -> 0.215, <15> 0.142 -> 0.139, <8> 0.053 ->
+  // 0.058; the overlapped phase 5.87 -> 6.02 ms.  The launches are bound by the SUM of wave time,
+  // not by their last waves (which is also why candidates above a K threshold were not given 64
+  // lanes: that shortens a wave at more lane time).  Off.
+  unsigned wx = blockIdx.x, wy = blockIdx.y, wz = blockIdx.z;
+#if PVQ_RANK_MAJOR
+  {
+    const unsigned gyz = gridDim.y*gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);
+    const unsigned r = lin%gyz;
+    wx = lin/gyz;
+    wy = r%gridDim.y;
+    wz = r/gridDim.y;
+  }
+#endif
+  const long idx0 = 2*a.blk_first + (long)wx*BPW;              // position in the band's work list
   const long idx_end = 2*a.blk_end;
-  const int band = a.band_list[blockIdx.y], f = blockIdx.z;
+  const int band = a.band_list[wy], f = (int)wz;
   const long nblk = (long)a.nbx*a.nby;
   const int32_t *list = a.out.perm ? a.out.perm + (size_t)f*a.out.fs_perm + (size_t)band*2*nblk : nullptr;
   const int nslot_here = (int)(idx_end - idx0 < BPW ? idx_end - idx0 : BPW);
