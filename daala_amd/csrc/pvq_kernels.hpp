@@ -814,13 +814,20 @@ __global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order_count(PvqOrderA
   const double beta = a.beta[band], sq = sqrt((double)((n + 3)/2))/beta;
   const double *cg = a.out.cg + (size_t)f*a.out.fs_cg + (size_t)band*nblk;
   hist[t] = 0;
+  // the chunk's gains are loaded in one batch (clamped index: no load behind a branch), then counted
+  constexpr int ROUNDS = PVQ_ORDER_CHUNK/PVQ_ORDER_THREADS;
+  double cv[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const long i = first + (long)r*PVQ_ORDER_THREADS + t;
+    cv[r] = cg[i < end ? i : end - 1];
+  }
   __syncthreads();
-  for (long i0 = first; i0 < end; i0 += PVQ_ORDER_THREADS) {
-    const long i = i0 + t;
-    const bool on = i < end;
-    const double c = on ? cg[i] : 0;
-    (void)pvq_order_take(hist, pvq_order_key(c, 0, n, beta, sq), on);
-    (void)pvq_order_take(hist, pvq_order_key(c, 1, n, beta, sq), on);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const bool on = first + (long)r*PVQ_ORDER_THREADS + t < end;
+    (void)pvq_order_take(hist, pvq_order_key(cv[r], 0, n, beta, sq), on);
+    (void)pvq_order_take(hist, pvq_order_key(cv[r], 1, n, beta, sq), on);
   }
   __syncthreads();
   if (hist[t]) atomicAdd(&aa.gh[((size_t)f*a.nbands + band)*256 + t], hist[t]);
@@ -847,6 +854,14 @@ __global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order_scatter(PvqOrde
   const size_t gb = ((size_t)f*a.nbands + band)*256;
   hist[t] = 0;
   base[t] = aa.gh[gb + t];
+  // the chunk's gains in one batch, with the histogram read (clamped index: no load behind a branch)
+  constexpr int ROUNDS = PVQ_ORDER_CHUNK/PVQ_ORDER_THREADS;
+  double cv[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const long i = first + (long)r*PVQ_ORDER_THREADS + t;
+    cv[r] = cg[i < end ? i : end - 1];
+  }
   __syncthreads();
   // exclusive scan of the 256 global bins: one wave, 4 bins per lane
   if (t < 64) {
@@ -864,13 +879,12 @@ __global__ __launch_bounds__(PVQ_ORDER_THREADS) void k_pvq_order_scatter(PvqOrde
     for (int q = 0; q < 4; q++) { base[4*t + q] = run; run += v[q]; }
   }
   // the keys of this thread's entries, two bytes per round, kept for the scatter below
-  constexpr int ROUNDS = PVQ_ORDER_CHUNK/PVQ_ORDER_THREADS;
   uint32_t keys[ROUNDS/2];
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) {
     const long i = first + (long)r*PVQ_ORDER_THREADS + t;
     const bool on = i < end;
-    const double c = on ? cg[i] : 0;
+    const double c = cv[r];
     const int k0 = pvq_order_key(c, 0, n, beta, sq), k1 = pvq_order_key(c, 1, n, beta, sq);
     (void)pvq_order_take(hist, k0, on);
     (void)pvq_order_take(hist, k1, on);
