@@ -128,7 +128,7 @@ def main():
         'what': 'P frames: od_state_mc_predict (OBMC, all planes) on the device in both seams; decoder: '
                 'forward pyramid of the prediction and the whole pixel-domain stage on the device too; '
                 'encoder: deringing and its distortions on the device, P-frame feed, od_mv_est_calc_sads as one '
-                'fused OBMC + SAD call per frame; EPZS and the DP refinement of od_mv_est stay reference host code'}
+                'fused OBMC + SAD call per frame; the EPZS initialisation of od_mv_est reads the block-matching SADs of levels >= 1 from device windows; its DP refinement stays reference host code'}
     print('configs[3]', res['configs3_inter_1080p'], file=sys.stderr, flush=True)
 
     # configs[4]: lossless
