@@ -59,32 +59,42 @@ static __thread struct {
   int cx;
   int cy;
   const int32_t *win;
+  int cx2;                  /* second window (around the coarser neighbour's vector), win2 == NULL: none */
+  int cy2;
+  const int32_t *win2;
   long hits;
   long misses;
 } mv_win;
 
-static __thread od_hip_mc_bma_rec *mv_recs;
+static __thread od_hip_mc_bma_rec *mv_recs;   /* up to two records per vertex */
 static __thread int32_t *mv_wins;
 static __thread int (*mv_verts)[2];
+static __thread int *mv_rec2;                  /* vertex -> index of its second record, or -1 */
 static __thread int mv_recs_cap;
 
 static int32_t od_mv_est_bma_sad(od_mv_est_ctx *est, int ref, int bx, int by, int mvx, int mvy,
  int log_mvb_sz) {
   if (mv_win.active && ref == mv_win.ref && bx == mv_win.bx && by == mv_win.by
    && log_mvb_sz == mv_win.log_mvb_sz) {
-    int dx;
-    int dy;
-    dx = mvx - mv_win.cx;
-    dy = mvy - mv_win.cy;
-    if (dx >= -MV_WIN_RADIUS && dx <= MV_WIN_RADIUS && dy >= -MV_WIN_RADIUS && dy <= MV_WIN_RADIUS) {
-      int32_t v;
-      v = mv_win.win[(dy + MV_WIN_RADIUS)*MV_WIN_W + dx + MV_WIN_RADIUS];
-      if (v >= 0) {
-        mv_win.hits++;
-        if (od_hipenc_check_mode() && v != od_mv_est_bma_sad_cpu(est, ref, bx, by, mvx, mvy, log_mvb_sz)) {
-          od_hipenc_mv_check_fail(1);
+    int w;
+    for (w = 0; w < 2; w++) {
+      const int32_t *win;
+      int dx;
+      int dy;
+      win = w == 0 ? mv_win.win : mv_win.win2;
+      if (win == NULL) continue;
+      dx = mvx - (w == 0 ? mv_win.cx : mv_win.cx2);
+      dy = mvy - (w == 0 ? mv_win.cy : mv_win.cy2);
+      if (dx >= -MV_WIN_RADIUS && dx <= MV_WIN_RADIUS && dy >= -MV_WIN_RADIUS && dy <= MV_WIN_RADIUS) {
+        int32_t v;
+        v = win[(dy + MV_WIN_RADIUS)*MV_WIN_W + dx + MV_WIN_RADIUS];
+        if (v >= 0) {
+          mv_win.hits++;
+          if (od_hipenc_check_mode() && v != od_mv_est_bma_sad_cpu(est, ref, bx, by, mvx, mvy, log_mvb_sz)) {
+            od_hipenc_mv_check_fail(1);
+          }
+          return v;
         }
-        return v;
       }
     }
     mv_win.misses++;
@@ -97,10 +107,12 @@ static int32_t od_mv_est_bma_sad(od_mv_est_ctx *est, int ref, int bx, int by, in
 static int mv_level_with_windows(od_mv_est_ctx *est, int ref, int must_update, int n) {
   od_state *state;
   int nplanes;
+  int nrec;
   int i;
   int rc;
   state = &est->enc->state;
   nplanes = (est->flags & OD_MC_USE_CHROMA) ? est->enc->input_img[est->enc->curr_frame].nplanes : 1;
+  nrec = n;
   for (i = 0; i < n; i++) {
     od_hip_mc_bma_rec *r;
     od_mv_limits limits;
@@ -130,8 +142,30 @@ static int mv_level_with_windows(od_mv_est_ctx *est, int ref, int must_update, i
     od_state_get_predictor(state, pred, vx, vy, level, 2, ref);
     r->cx = OD_CLAMPI(r->xmin, pred[0], r->xmax);
     r->cy = OD_CLAMPI(r->ymin, pred[1], r->ymax);
+    /* A second window where the search usually ends when it does not end at the predictor: around
+       the vector block matching found for the first Set B neighbour (:2620-2660: a vertex of a
+       coarser level, done before this level started) against this reference.  The golden reference's
+       searches end there more often than at their predictor (which follows the vectors the grid
+       holds, mostly of the previous reference).  Only when the first window does not cover it. */
+    mv_rec2[i] = -1;
+    if (state->frame_type == OD_P_FRAME) {
+      const od_mv_node *nb;
+      int cx2;
+      int cy2;
+      nb = NULL;
+      if (level & 1) nb = est->mvs[vy - mvb_sz] + vx - mvb_sz;
+      else if (vy >= mvb_sz) nb = est->mvs[vy - mvb_sz] + vx;
+      cx2 = OD_CLAMPI(r->xmin, nb != NULL ? nb->bma_mvs[0][ref][0] : 0, r->xmax);
+      cy2 = OD_CLAMPI(r->ymin, nb != NULL ? nb->bma_mvs[0][ref][1] : 0, r->ymax);
+      if (abs(cx2 - r->cx) > MV_WIN_RADIUS/2 || abs(cy2 - r->cy) > MV_WIN_RADIUS/2) {
+        mv_recs[nrec] = *r;
+        mv_recs[nrec].cx = cx2;
+        mv_recs[nrec].cy = cy2;
+        mv_rec2[i] = nrec++;
+      }
+    }
   }
-  rc = od_hipenc_mv_bma_windows(est->enc, nplanes, mv_recs, n, MV_WIN_RADIUS, mv_wins);
+  rc = od_hipenc_mv_bma_windows(est->enc, nplanes, mv_recs, nrec, MV_WIN_RADIUS, mv_wins);
   for (i = 0; i < n; i++) {
     if (rc > 0) {
       mv_win.active = 1;
@@ -142,6 +176,12 @@ static int mv_level_with_windows(od_mv_est_ctx *est, int ref, int must_update, i
       mv_win.cx = mv_recs[i].cx;
       mv_win.cy = mv_recs[i].cy;
       mv_win.win = mv_wins + (size_t)i*MV_WIN_W*MV_WIN_W;
+      mv_win.win2 = NULL;
+      if (mv_rec2[i] >= 0) {
+        mv_win.cx2 = mv_recs[mv_rec2[i]].cx;
+        mv_win.cy2 = mv_recs[mv_rec2[i]].cy;
+        mv_win.win2 = mv_wins + (size_t)mv_rec2[i]*MV_WIN_W*MV_WIN_W;
+      }
     }
     od_mv_est_init_mv(est, ref, mv_verts[i][0], mv_verts[i][1], must_update);
     mv_win.active = 0;
@@ -170,10 +210,12 @@ static int mv_init_mvs_levels(od_mv_est_ctx *est, int ref, int must_update) {
     free(mv_recs);
     free(mv_wins);
     free(mv_verts);
-    mv_recs = (od_hip_mc_bma_rec *)malloc(sizeof(*mv_recs)*cap);
-    mv_wins = (int32_t *)malloc(sizeof(*mv_wins)*cap*MV_WIN_W*MV_WIN_W);
+    free(mv_rec2);
+    mv_recs = (od_hip_mc_bma_rec *)malloc(sizeof(*mv_recs)*2*cap);
+    mv_wins = (int32_t *)malloc(sizeof(*mv_wins)*2*cap*MV_WIN_W*MV_WIN_W);
     mv_verts = (int (*)[2])malloc(sizeof(*mv_verts)*cap);
-    mv_recs_cap = mv_recs != NULL && mv_wins != NULL && mv_verts != NULL ? cap : 0;
+    mv_rec2 = (int *)malloc(sizeof(*mv_rec2)*cap);
+    mv_recs_cap = mv_recs != NULL && mv_wins != NULL && mv_verts != NULL && mv_rec2 != NULL ? cap : 0;
     if (mv_recs_cap == 0) return 0;
   }
   /* "Move the motion vector predictors back a frame." (:3045-3056) */
@@ -413,9 +455,11 @@ void od_hipenc_mv_thread_cleanup(void) {
   free(mv_recs);
   free(mv_wins);
   free(mv_verts);
+  free(mv_rec2);
   mv_recs = NULL;
   mv_wins = NULL;
   mv_verts = NULL;
+  mv_rec2 = NULL;
   mv_recs_cap = 0;
   mv_items = NULL;
   mv_sads = NULL;
