@@ -6,7 +6,8 @@
 //
 // One wave per superblock, grid (nhsb, nvsb, frames).  The tile lives in LDS
 // (stride SB+1); every level maps one 2x2 group to one lane-iteration.  The low band
-// ping-pongs between two tiles because level l reads (2i,2j) while writing (i,j).
+// ping-pongs between two tiles because level l reads (2i,2j) while writing (i,j); the second
+// tile needs only half the rows (10.6 KB of LDS per wave instead of 12.7: 15 waves per CU).
 // HBM-bound: forward reads 1 B and writes 4 B per sample, inverse the opposite
 // (5 B/sample algorithmic either way); rows of a superblock are 32 B (u8) / 128 B
 // (int32) contiguous segments.
@@ -27,30 +28,42 @@ template <int SB>
 __global__ __launch_bounds__(64) void k_haar_forward_plane(HaarArgs a) {
   constexpr int LD = SB + 1;
   constexpr int LN = SB == 32 ? 5 : 4;
-  __shared__ int32_t T[2][SB*LD];
+  // the low band ping-pongs between the full tile and a half-height one (level 0 writes 16x16)
+  __shared__ int32_t T0[SB*LD];
+  __shared__ int32_t T1[(SB/2)*LD];
   __shared__ int32_t Y[SB*LD];
   const int lane = threadIdx.x;
   int sbx, sby, fr;
   xcd_tile_coords(sbx, sby, fr);   // 4 adjacent luma SBs share each 128-byte line of the 8-bit plane
   const size_t org = (size_t)fr*a.fstride + (size_t)(sby*SB)*a.w + sbx*SB;
-  // load: dword = 4 pixels; SB*SB/4 dwords over 64 lanes
-  for (int e = lane; e < SB*SB/4; e += 64) {
-    const int r = e/(SB/4), c4 = e%(SB/4);
-    const uint32_t v = *reinterpret_cast<const uint32_t *>(a.pix + org + (size_t)r*a.w + 4*c4);
+  // load: dword = 4 pixels; SB*SB/4 dwords over 64 lanes, all of a lane's loads issued before the
+  // first is unpacked (the rolled loop waited for each in turn: waves parked 76 % of their life)
+  constexpr int NLD = SB*SB/4/64;
+  uint32_t pv[NLD];
 #pragma unroll
-    for (int k = 0; k < 4; k++) T[0][r*LD + 4*c4 + k] = (int32_t)((v >> (8*k)) & 255) - 128;
+  for (int q = 0; q < NLD; q++) {
+    const int e = lane + 64*q;
+    pv[q] = *reinterpret_cast<const uint32_t *>(a.pix + org + (size_t)(e/(SB/4))*a.w + 4*(e%(SB/4)));
+  }
+#pragma unroll
+  for (int q = 0; q < NLD; q++) {
+    const int e = lane + 64*q;
+    const int r = e/(SB/4), c4 = e%(SB/4);
+#pragma unroll
+    for (int k = 0; k < 4; k++) T0[r*LD + 4*c4 + k] = (int32_t)((pv[q] >> (8*k)) & 255) - 128;
   }
   __syncthreads();
   int cur = 0;
 #pragma unroll
   for (int level = 0; level < LN; level++) {
     const int np = SB >> level >> 1;
+    int32_t *src = cur ? T1 : T0, *dst = cur ? T0 : T1;
     for (int e = lane; e < np*np; e += 64) {
       const int i = e/np, j = e%np;
-      int32_t ll = T[cur][(2*i)*LD + 2*j], lh = T[cur][(2*i + 1)*LD + 2*j];
-      int32_t hl = T[cur][(2*i)*LD + 2*j + 1], hh = T[cur][(2*i + 1)*LD + 2*j + 1];
+      int32_t ll = src[(2*i)*LD + 2*j], lh = src[(2*i + 1)*LD + 2*j];
+      int32_t hl = src[(2*i)*LD + 2*j + 1], hh = src[(2*i + 1)*LD + 2*j + 1];
       haar2x2(ll, lh, hl, hh);
-      T[cur ^ 1][i*LD + j] = ll;
+      dst[i*LD + j] = ll;
       Y[i*LD + j + np] = lh;
       Y[(i + np)*LD + j] = hl;
       Y[(i + np)*LD + j + np] = hh;
@@ -58,7 +71,7 @@ __global__ __launch_bounds__(64) void k_haar_forward_plane(HaarArgs a) {
     cur ^= 1;
     __syncthreads();
   }
-  if (lane == 0) Y[0] = T[cur][0];
+  if (lane == 0) Y[0] = (cur ? T1 : T0)[0];
   __syncthreads();
   for (int e = lane; e < SB*SB/4; e += 64) {
     const int r = e/(SB/4), c4 = e%(SB/4);
@@ -71,46 +84,62 @@ template <int SB>
 __global__ __launch_bounds__(64) void k_haar_inverse_plane(HaarArgs a) {
   constexpr int LD = SB + 1;
   constexpr int LN = SB == 32 ? 5 : 4;
-  __shared__ int32_t X[2][SB*LD];
+  // the low band grows 1x1 -> SBxSB through LN levels, ping-ponging between a half-height tile
+  // and the full one; the parity is chosen so that the last level (the only one that needs SB
+  // rows) writes the full tile
+  __shared__ int32_t XF[SB*LD];
+  __shared__ int32_t XH[(SB/2)*LD];
   __shared__ int32_t Y[SB*LD];
   const int lane = threadIdx.x;
   int sbx, sby, fr;
   xcd_tile_coords(sbx, sby, fr);   // 4 adjacent luma SBs share each 128-byte line of the 8-bit plane
   const size_t org = (size_t)fr*a.fstride + (size_t)(sby*SB)*a.w + sbx*SB;
-  for (int e = lane; e < SB*SB/4; e += 64) {
+  constexpr int NLD = SB*SB/4/64;
+  int4 cv[NLD];
+#pragma unroll
+  for (int q = 0; q < NLD; q++) {      // all loads first (see the forward kernel)
+    const int e = lane + 64*q;
+    cv[q] = *reinterpret_cast<const int4 *>(a.d + org + (size_t)(e/(SB/4))*a.w + 4*(e%(SB/4)));
+  }
+#pragma unroll
+  for (int q = 0; q < NLD; q++) {
+    const int e = lane + 64*q;
     const int r = e/(SB/4), c4 = e%(SB/4);
-    const int4 v = *reinterpret_cast<const int4 *>(a.d + org + (size_t)r*a.w + 4*c4);
-    Y[r*LD + 4*c4] = v.x;
-    Y[r*LD + 4*c4 + 1] = v.y;
-    Y[r*LD + 4*c4 + 2] = v.z;
-    Y[r*LD + 4*c4 + 3] = v.w;
+    Y[r*LD + 4*c4] = cv[q].x;
+    Y[r*LD + 4*c4 + 1] = cv[q].y;
+    Y[r*LD + 4*c4 + 2] = cv[q].z;
+    Y[r*LD + 4*c4 + 3] = cv[q].w;
   }
   __syncthreads();
-  if (lane == 0) X[0][0] = Y[0];
+  // LN levels: the write of step s (s = 0 .. LN - 1) goes to XF when (LN - 1 - s) is even
+  int cur = (LN & 1) ? 1 : 0;          // 0: the low band is in XF, 1: in XH; the first write goes to the other
+  if (lane == 0) (cur ? XH : XF)[0] = Y[0];
   __syncthreads();
-  int cur = 0;
 #pragma unroll
   for (int level = LN - 1; level >= 0; level--) {
     const int np = 1 << (LN - 1 - level);
+    const int32_t *src = cur ? XH : XF;
+    int32_t *dst = cur ? XF : XH;
     for (int e = lane; e < np*np; e += 64) {
       const int i = e/np, j = e%np;
-      int32_t ll = X[cur][i*LD + j], lh = Y[i*LD + j + np];
+      int32_t ll = src[i*LD + j], lh = Y[i*LD + j + np];
       int32_t hl = Y[(i + np)*LD + j], hh = Y[(i + np)*LD + j + np];
       haar2x2(ll, lh, hl, hh);
-      X[cur ^ 1][(2*i)*LD + 2*j] = ll;
-      X[cur ^ 1][(2*i + 1)*LD + 2*j] = lh;
-      X[cur ^ 1][(2*i)*LD + 2*j + 1] = hl;
-      X[cur ^ 1][(2*i + 1)*LD + 2*j + 1] = hh;
+      dst[(2*i)*LD + 2*j] = ll;
+      dst[(2*i + 1)*LD + 2*j] = lh;
+      dst[(2*i)*LD + 2*j + 1] = hl;
+      dst[(2*i + 1)*LD + 2*j + 1] = hh;
     }
     cur ^= 1;
     __syncthreads();
   }
+  const int32_t *X = cur ? XH : XF;    // == XF: LN steps from the chosen parity end in the full tile
   for (int e = lane; e < SB*SB/4; e += 64) {
     const int r = e/(SB/4), c4 = e%(SB/4);
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int32_t p = X[cur][r*LD + 4*c4 + k] + 128;       // shift 0: OD_CLAMP255(c + 128)
+      int32_t p = X[r*LD + 4*c4 + k] + 128;            // shift 0: OD_CLAMP255(c + 128)
       p = p < 0 ? 0 : p > 255 ? 255 : p;
       v |= (uint32_t)p << (8*k);
     }

@@ -73,6 +73,11 @@ def test_load_stages_leave_in_one_batch(isa):
     # kernel, each with a head batch and one batch per plane tile; the first single-wave version had 60+
     loads, nb = batches('void k_decode_tail<true>(')
     assert loads >= 100 and nb <= 16, (loads, nb)
+    # lossless Haar planes: the superblock's loads in one batch
+    for k in ('void k_haar_forward_plane<32>(', 'void k_haar_forward_plane<16>(', 'void k_haar_inverse_plane<32>(',
+              'void k_haar_inverse_plane<16>('):
+        loads, nb = batches(k)
+        assert nb == 1, (k, loads, nb)
     # the K-order kernels read their chunk's gains in one batch (+ the histogram read)
     for k in ('k_pvq_order_count(', 'k_pvq_order_scatter('):
         loads, nb = batches(k)
