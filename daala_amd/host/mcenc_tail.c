@@ -2,7 +2,12 @@
  * The stage functions of od_mv_est (src/mcenc.c:6390) run as the reference wrote them
  * (*_cpu); the definitions here are what their call sites bind to:
  *   - every stage is timed (a handful of clock reads per frame) into the worker's statistics
- *     (od_hipenc_stats.mv_stage_s), which is where profiles/r04_mvest_stages.md comes from. */
+ *     (od_hipenc_stats.mv_stage_s), which is where profiles/r04*_mvest_stages*.md come from;
+ *   - od_mv_est_init_mvs walks levels >= 1 over the whole grid and od_mv_est_bma_sad answers from
+ *     device block-matching windows (first part of this file);
+ *   - od_mv_est_calc_sads is one fused OBMC + SAD device call per frame, and od_mv_est_sad answers
+ *     the top-level blocks of od_mv_est_init_dus from the same call (second part).
+ * The DP refinement (od_mv_est_refine, od_mv_subpel_refine) is the reference's code, timed only. */
 #include "../../include/daala_hip.h"
 void od_hipenc_mv_stage(int stage, double seconds);   /* hip_enc_glue.c */
 void od_hipenc_mv_check_fail(long n);
