@@ -530,6 +530,7 @@ int pvq_theta(od_coeff *out, od_coeff *x0, od_coeff *r0, int n, int q0, od_coeff
   /* ---- no-reference candidates (:452-481) */
   if (noref_search) {
     od_hip_search sc;
+    double xs[MAXN];              /* the vector sc searches: lives as long as sc (it keeps a pointer) */
     const int16_t *py;
     int ns;
     int base_slot;
@@ -612,10 +613,9 @@ int pvq_theta(od_coeff *out, od_coeff *x0, od_coeff *r0, int n, int q0, od_coeff
       }
       else {
         if (!searching) {
-          double x1[MAXN];
           int j;
-          for (j = 0; j < n; j++) x1[j] = x0[j]*qm[j]*OD_QM_SCALE_1;
-          od_hip_search_begin(&sc, x1, n);
+          for (j = 0; j < n; j++) xs[j] = x0[j]*qm[j]*OD_QM_SCALE_1;
+          od_hip_search_begin(&sc, xs, n);
           searching = 1;
           if (fed) T.st.lost_sync++;
         }
