@@ -848,6 +848,16 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     rb = (od_rollback_buffer *)malloc(sizeof(*rb));
     mine = (od_adapt_ctx *)malloc(sizeof(*mine));
     ref0 = (od_coeff *)malloc(sizeof(od_coeff)*n2*3);
+    if (rb == NULL || mine == NULL || ref0 == NULL) {
+      /* no memory for the comparison: the block is coded unchecked and counted as a failure */
+      free(ref0);
+      free(mine);
+      free(rb);
+      T.st.pvq_check_fail++;
+      set_block_context(enc, pli, bs, is_keyframe, bx, by);
+      return od_pvq_encode_cpu(enc, ref, in, out, q0, pli, bs, beta, robust, is_keyframe, q_scaling, bx, by,
+       qm, qm_inv);
+    }
     out1 = ref0 + n2;
     ref1 = out1 + n2;
     od_encode_checkpoint_cpu(enc, rb);
@@ -863,7 +873,7 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
     *mine = enc->state.adapt;
     ec_signature(&s1, &enc->ec);
     pre1 = (uint16_t *)malloc(sizeof(uint16_t)*(enc->ec.offs - offs0 + 1));
-    memcpy(pre1, enc->ec.precarry_buf + offs0, sizeof(uint16_t)*(enc->ec.offs - offs0));
+    if (pre1 != NULL) memcpy(pre1, enc->ec.precarry_buf + offs0, sizeof(uint16_t)*(enc->ec.offs - offs0));
     od_encode_rollback_cpu(enc, rb);
     memcpy(ref, ref0, sizeof(od_coeff)*n2);
     enc->state.sb_q_scaling[sbi] = sbq;
@@ -876,6 +886,7 @@ int od_hip_pvq_encode_host(daala_enc_ctx *enc, od_coeff *ref, od_coeff *in,
      || out1[0] != out[0] || memcmp(ref1, ref, sizeof(od_coeff)*n2) != 0
      || memcmp(mine, &enc->state.adapt, sizeof(*mine)) != 0
      || memcmp(&s1, &s2, sizeof(s1)) != 0
+     || pre1 == NULL
      || memcmp(pre1, enc->ec.precarry_buf + offs0, sizeof(uint16_t)*(s1.offs - offs0)) != 0) {
       T.st.pvq_check_fail++;
     }
