@@ -302,8 +302,14 @@ inline double host_gain_compand(double g, int q0, double beta) {
   return PVQ_COMPAND_SCALE*pow(g*(1./PVQ_COMPAND_SCALE), 1./beta)/q0;
 }
 
+// an integer switch from the environment, read once by its caller (static const)
+inline int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 inline bool pvq_sort_enabled() {
-  static const int on = getenv("OD_HIP_PVQ_SORT") ? atoi(getenv("OD_HIP_PVQ_SORT")) : 1;
+  static const int on = env_int("OD_HIP_PVQ_SORT", 1);
   return on != 0;
 }
 
@@ -1348,7 +1354,7 @@ int od_hip_inverse(od_hip_ctx *ctx, int slot0, int nslots) {
   if (int rc = check_slots(ctx, slot0, nslots)) return rc;
   // OD_HIP_INVERSE_IMPL=1: the two-kernel form through the int32 work plane (what the
   // decoder tail uses, where deringing needs that plane anyway); default: fused (no work plane)
-  static const int impl = getenv("OD_HIP_INVERSE_IMPL") ? atoi(getenv("OD_HIP_INVERSE_IMPL")) : 2;
+  static const int impl = env_int("OD_HIP_INVERSE_IMPL", 2);
   for (int p = 0; p < ctx->geo.nplanes; p++) {
     InvArgs a;
     a.d = ctx->d[p] + (size_t)slot0*ctx->psz[p];
@@ -1651,7 +1657,7 @@ int pvq_launch(od_hip_ctx *ctx, PvqCall &c, int nslots, bool gain_only) {
     hipStream_t ls = ctx->stream;
     if (side) {
       // OD_HIP_PVQ_ASSIGN=1: by kernel class (128 | 32 | 15+8) instead of round-robin
-      static const int by_class = getenv("OD_HIP_PVQ_ASSIGN") ? atoi(getenv("OD_HIP_PVQ_ASSIGN")) : 0;
+      static const int by_class = env_int("OD_HIP_PVQ_ASSIGN", 0);
       const int cls = sizes[si] == 128 ? 0 : sizes[si] == 32 ? 1 : 2;
       ls = ctx->aux[(by_class ? cls : ctx->aux_rr++) % ctx->naux];
       HIPCHK(hipStreamWaitEvent(ls, ctx->aux_dep, 0));
@@ -1677,7 +1683,7 @@ int pvq_launch(od_hip_ctx *ctx, PvqCall &c, int nslots, bool gain_only) {
 // and k_pvq_order builds the work lists - no transfer, no host stage.  OD_HIP_PVQ_DEV_COMPAND=0
 // sends those levels through the host stage as well (rounds 1-3; A/B).
 bool pvq_level_on_device(const od_hip_ctx *ctx, const double *beta, int nbands) {
-  static const int on = getenv("OD_HIP_PVQ_DEV_COMPAND") ? atoi(getenv("OD_HIP_PVQ_DEV_COMPAND")) : 1;
+  static const int on = env_int("OD_HIP_PVQ_DEV_COMPAND", 1);
   // strips (od_hip_set_strip) and unsorted lists keep the host stage, which writes identity lists
   if (!on || ctx->strip0 != 0 || ctx->strip1 != ctx->nvsb || !pvq_sort_enabled()) return false;
   for (int b = 0; b < nbands; b++) if (beta[b] != 1) return false;
