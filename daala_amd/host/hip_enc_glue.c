@@ -999,6 +999,7 @@ static daala_enc_ctx *worker_encoder(const od_hipenc *S) {
   }
   /* the motion search's per-block leaves (hip_mc_host.c) */
   enc->state.opt_vtbl.mc_blend_full = od_hipenc_mc_blend_full8;
+  enc->state.opt_vtbl.mc_blend_full_split = od_hipenc_mc_blend_full_split8;
   enc->state.opt_vtbl.mc_predict1fmv = od_hipenc_mc_predict1fmv8;
   return enc;
 }

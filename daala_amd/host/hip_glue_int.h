@@ -112,6 +112,8 @@ void od_hipenc_idct32x32(od_coeff *x, int xstride, const od_coeff *y, int ystrid
 /* hip_mc_host.c: od_state_opt_vtbl leaves of the motion search, host vector unit */
 void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned char *src[4],
  int log_xblk_sz, int log_yblk_sz);
+void od_hipenc_mc_blend_full_split8(unsigned char *dst, int dystride, const unsigned char *src[4],
+ int oc, int s, int log_xblk_sz, int log_yblk_sz);
 void od_hipenc_mc_predict1fmv8(od_state *state, unsigned char *dst, const unsigned char *src,
  int systride, int32_t mvx, int32_t mvy, int log_xblk_sz, int log_yblk_sz);
 void od_hipenc_mc_cache_flush(void);

@@ -146,6 +146,114 @@ void od_hipenc_mc_blend_full8(unsigned char *dst, int dystride, const unsigned c
   }
 }
 
+/* od_mc_blend_full_split8_c (src/mc.c:1104-1150): the blend of a block with one or two unsplit
+   edges.  The weight of source k at column i of row j is linear in i for a fixed j and the row's
+   start and step are linear in j (od_mc_setup_s_split, src/mc.c:1056-1102, followed by the
+   function's row updates): w_k(i, j) = s0_k + j dsdj_k + i (dsdi_k + j dd_k); the pixel is
+   ((a << L) + (s1 - a) w1 + (s2 - a) w2 + (s3 - a) w3 + round) >> L with a = source 0 and
+   L = log2(width) + log2(height) + 1.  Eight columns per vector in 32-bit lanes: a difference is
+   at most 255 and a weight at most 2 << (L - 1), so every product and the sum of the four terms
+   stay far inside 31 bits for the largest block (64x64: L = 13).  Blocks narrower than eight
+   columns go to the reference's function. */
+void od_hipenc_mc_blend_full_split8(unsigned char *dst, int dystride, const unsigned char *src[4],
+ int oc, int s, int log_xblk_sz, int log_yblk_sz) {
+  int w0[4];
+  int di[4];
+  int dj[4];
+  int dd[4];
+  int l2;
+  int L;
+  int xblk_sz;
+  int yblk_sz;
+  int j;
+  int k;
+  if (log_xblk_sz < 3) {
+    od_mc_blend_full_split8_c(dst, dystride, src, oc, s, log_xblk_sz, log_yblk_sz);
+    return;
+  }
+  l2 = log_xblk_sz + log_yblk_sz;
+  L = l2 + 1;
+  xblk_sz = 1 << log_xblk_sz;
+  yblk_sz = 1 << log_yblk_sz;
+  /* the bilinear weights of the four corners, doubled */
+  for (k = 0; k < 4; k++) w0[k] = di[k] = dj[k] = 0;
+  w0[0] = 2 << l2;
+  di[0] = -(2 << log_xblk_sz);
+  di[1] = 2 << log_xblk_sz;
+  dj[0] = -(2 << log_yblk_sz);
+  dj[3] = 2 << log_yblk_sz;
+  dd[0] = dd[2] = 2;
+  dd[1] = dd[3] = -2;
+  /* an unsplit edge next to corner oc: half of that neighbour's weight moves to oc */
+  for (k = 0; k < 2; k++) {
+    int c;
+    if (s & (1 << k)) continue;
+    c = (oc + (k == 0 ? 1 : 3)) & 3;
+    w0[c] >>= 1;
+    di[c] >>= 1;
+    dj[c] >>= 1;
+    dd[c] >>= 1;
+    w0[oc] += w0[c];
+    di[oc] += di[c];
+    dj[oc] += dj[c];
+    dd[oc] += dd[c];
+  }
+  {
+    const __m256i lane = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    const __m256i vround = _mm256_set1_epi32(1 << (L - 1));
+    const __m128i cL = _mm_cvtsi32_si128(L);
+    const unsigned char *s0;
+    const unsigned char *s1;
+    const unsigned char *s2;
+    const unsigned char *s3;
+    s0 = src[0];
+    s1 = src[1];
+    s2 = src[2];
+    s3 = src[3];
+    for (j = 0; j < yblk_sz; j++) {
+      __m256i w1;
+      __m256i w2;
+      __m256i w3;
+      __m256i st1;
+      __m256i st2;
+      __m256i st3;
+      int i;
+      w1 = _mm256_add_epi32(_mm256_set1_epi32(w0[1] + j*dj[1]), _mm256_mullo_epi32(lane, _mm256_set1_epi32(di[1] + j*dd[1])));
+      w2 = _mm256_add_epi32(_mm256_set1_epi32(w0[2] + j*dj[2]), _mm256_mullo_epi32(lane, _mm256_set1_epi32(di[2] + j*dd[2])));
+      w3 = _mm256_add_epi32(_mm256_set1_epi32(w0[3] + j*dj[3]), _mm256_mullo_epi32(lane, _mm256_set1_epi32(di[3] + j*dd[3])));
+      st1 = _mm256_set1_epi32(8*(di[1] + j*dd[1]));
+      st2 = _mm256_set1_epi32(8*(di[2] + j*dd[2]));
+      st3 = _mm256_set1_epi32(8*(di[3] + j*dd[3]));
+      for (i = 0; i < xblk_sz; i += 8) {
+        __m256i a;
+        __m256i v;
+        __m128i o;
+        a = _mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *)(s0 + i)));
+        v = _mm256_add_epi32(_mm256_sll_epi32(a, cL), vround);
+        v = _mm256_add_epi32(v, _mm256_mullo_epi32(
+         _mm256_sub_epi32(_mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *)(s1 + i))), a), w1));
+        v = _mm256_add_epi32(v, _mm256_mullo_epi32(
+         _mm256_sub_epi32(_mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *)(s2 + i))), a), w2));
+        v = _mm256_add_epi32(v, _mm256_mullo_epi32(
+         _mm256_sub_epi32(_mm256_cvtepu8_epi32(_mm_loadl_epi64((const __m128i *)(s3 + i))), a), w3));
+        v = _mm256_sra_epi32(v, cL);
+        /* the reference stores (unsigned char)value: the low byte, whatever the value */
+        v = _mm256_and_si256(v, _mm256_set1_epi32(255));
+        o = _mm_packs_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
+        _mm_storel_epi64((__m128i *)(dst + i), _mm_packus_epi16(o, o));
+        w1 = _mm256_add_epi32(w1, st1);
+        w2 = _mm256_add_epi32(w2, st2);
+        w3 = _mm256_add_epi32(w3, st3);
+      }
+      s0 += xblk_sz;
+      s1 += xblk_sz;
+      s2 += xblk_sz;
+      s3 += xblk_sz;
+      dst += dystride;
+    }
+  }
+}
+
 /* od_mc_predict1fmv8_c (src/mc.c:94-203): the 1/8-pel predictor, separable 6-tap filters
    (OD_SUBPEL_FILTER_SET, src/mc.c:69-80), horizontal pass into a 16-bit buffer with a two-row
    top and three-row bottom apron, then the vertical pass, one rounding at the end.  Eight
@@ -385,6 +493,8 @@ void od_hipenc_mc_leaves_test(int which, unsigned char *dst, int dystride, const
       od_hipenc_mc_predict1fmv8(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz);
       break;
     case 4: od_hipenc_mc_predict1fmv8(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
+    case 5: od_hipenc_mc_blend_full_split8(dst, dystride, src, mvx, mvy, log_xblk_sz, log_yblk_sz); break;   /* mvx: oc, mvy: s */
+    case 6: od_mc_blend_full_split8_c(dst, dystride, src, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
     default: od_mc_predict1fmv8_c(NULL, dst, s0, systride, mvx, mvy, log_xblk_sz, log_yblk_sz); break;
   }
 }

@@ -386,6 +386,14 @@ def test_motion_search_leaves_equal_reference():
         for which, o in ((0, got), (1, want)):
             f(which, pu8(o), ds, pu8(srcs[0]), pu8(srcs[1]), pu8(srcs[2]), pu8(srcs[3]), 0, 0, 0, lx, ly)
         assert np.array_equal(got, want), ('blend', trial, lx, ly)
+        # the blend with unsplit edges (od_mc_blend_full_split8_c, src/mc.c:1104): every corner and
+        # split state the motion search can ask for
+        oc, ss = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        got[:] = 0
+        want[:] = 0
+        for which, o in ((5, got), (6, want)):
+            f(which, pu8(o), ds, pu8(srcs[0]), pu8(srcs[1]), pu8(srcs[2]), pu8(srcs[3]), 0, oc, ss, lx, ly)
+        assert np.array_equal(got, want), ('split blend', trial, lx, ly, oc, ss)
     W, Hh, pad = 160, 144, 24
     for trial in range(900):
         lx, ly = int(rng.integers(2, 7)), int(rng.integers(2, 7))
