@@ -419,6 +419,40 @@ int od_hip_haar_blocks(int bs, int inverse, od_coeff *out, const od_coeff *in, i
   return 0;
 }
 
+namespace {
+// blocks of one size class form one launch (mc_kernels.hpp: McTiles); prediction blocks are
+// independent and may be reordered, so the list is bucketed by class first: at most three launches
+inline int mc_block_log(const McBlock &b) { return b.log_xblk_sz > b.log_yblk_sz ? b.log_xblk_sz : b.log_yblk_sz; }
+void mc_bucket_blocks(McBlock *dst, const od_hip_mc_block *src, int n) {
+  const McBlock *in = reinterpret_cast<const McBlock *>(src);
+  int at = 0;
+  for (int cls = 4; cls <= 6; cls++) {
+    for (int i = 0; i < n; i++) if (mc_size_class(mc_block_log(in[i])) == cls) dst[at++] = in[i];
+  }
+}
+void mc_launch_predict(const McArgs &a0, const McBlock *host_sorted, int n, hipStream_t st) {
+  mc_launch_runs(n, [&](int i) { return mc_block_log(host_sorted[i]); }, [&](int cls, int first, int cnt) {
+    McArgs a = a0;
+    a.blocks = a0.blocks + first;
+    a.nblocks = cnt;
+    if (cls == 4) hipLaunchKernelGGL(k_mc_predict_blocks<4>, dim3(cnt), dim3(MC_THREADS), 0, st, a);
+    else if (cls == 5) hipLaunchKernelGGL(k_mc_predict_blocks<5>, dim3(cnt), dim3(MC_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(k_mc_predict_blocks<6>, dim3(cnt), dim3(MC_THREADS), 0, st, a);
+  });
+}
+void mc_launch_sad(const McSadArgs &a0, const McSadItem *host_items, int n, hipStream_t st) {
+  mc_launch_runs(n, [&](int i) { return host_items[i].log_blk_sz; }, [&](int cls, int first, int cnt) {
+    McSadArgs a = a0;
+    a.items = a0.items + first;
+    a.sad = a0.sad + first;
+    a.nitems = cnt;
+    if (cls == 4) hipLaunchKernelGGL(k_mc_sad_items<4>, dim3(cnt), dim3(MC_SAD_THREADS), 0, st, a);
+    else if (cls == 5) hipLaunchKernelGGL(k_mc_sad_items<5>, dim3(cnt), dim3(MC_SAD_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(k_mc_sad_items<6>, dim3(cnt), dim3(MC_SAD_THREADS), 0, st, a);
+  });
+}
+}  // namespace
+
 // F3: OBMC prediction of a list of blocks (mc_kernels.hpp).
 int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int ref_stride, int ref_h,
                              int org_x, int org_y, const od_hip_mc_block *blocks, int nblocks,
@@ -446,7 +480,9 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
   if (int rc = g_out.reserve(dbytes)) return rc;
   for (int k = 0; k < nref; k++)
     HIPCHK(hipMemcpy((uint8_t *)g_in.p + plane*k, refs[k], plane, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g_aux0.p, blocks, (size_t)nblocks*sizeof(McBlock), hipMemcpyHostToDevice));
+  std::vector<McBlock> sorted((size_t)nblocks);
+  mc_bucket_blocks(sorted.data(), blocks, nblocks);
+  HIPCHK(hipMemcpy(g_aux0.p, sorted.data(), (size_t)nblocks*sizeof(McBlock), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_out.p, dst, dbytes, hipMemcpyHostToDevice));     // blocks need not cover the plane
   McArgs a;
   a.refs = (const uint8_t *)g_in.p;
@@ -459,7 +495,7 @@ int od_hip_mc_predict_blocks(int nref, const unsigned char *const refs[], int re
   a.nblocks = nblocks;
   a.dst = (uint8_t *)g_out.p;
   a.dst_stride = dst_stride;
-  hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(MC_THREADS), 0, 0, a);
+  mc_launch_predict(a, sorted.data(), nblocks, 0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(dst, g_out.p, dbytes, hipMemcpyDeviceToHost));
   return 0;
@@ -657,7 +693,7 @@ int mc_predict_impl(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nb
     m->blocks_cap = cap;
   }
   HIPCHK(hipStreamSynchronize(m->stream));          // the previous plane's list may still be read
-  memcpy(m->h_blocks, blocks, (size_t)nblocks*sizeof(McBlock));
+  mc_bucket_blocks(m->h_blocks, blocks, nblocks);
   HIPCHK(hipMemcpyAsync(m->d_blocks, m->h_blocks, (size_t)nblocks*sizeof(McBlock), hipMemcpyHostToDevice, m->stream));
   McArgs a;
   a.refs = P.d_refs;
@@ -670,7 +706,7 @@ int mc_predict_impl(od_hip_mc *m, int pli, const od_hip_mc_block *blocks, int nb
   a.nblocks = nblocks;
   a.dst = dev_dst ? dev_dst : P.d_dst;
   a.dst_stride = dst_w;
-  hipLaunchKernelGGL(k_mc_predict_blocks, dim3(nblocks), dim3(MC_THREADS), 0, m->stream, a);
+  mc_launch_predict(a, m->h_blocks, nblocks, m->stream);
   HIPCHK(hipGetLastError());
   if (dev_dst) return 0;
   HIPCHK(hipMemcpyAsync(P.h_dst, P.d_dst, dbytes, hipMemcpyDeviceToHost, m->stream));
@@ -875,7 +911,7 @@ int od_hip_mc_sad_items(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const o
   a.items = m->d_items;
   a.nitems = nitems;
   a.sad = m->d_sad;
-  hipLaunchKernelGGL(k_mc_sad_items, dim3(nitems), dim3(MC_SAD_THREADS), 0, m->stream, a);
+  mc_launch_sad(a, m->h_items, nitems, m->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(m->h_sad, m->d_sad, (size_t)nitems*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
@@ -960,7 +996,11 @@ int od_hip_mc_bma_windows(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const
     a.recs = m->d_recs + r0;
     a.nrec = min(CHUNK, nrec - r0);
     a.sad = m->d_win + (size_t)r0*W*W;
-    hipLaunchKernelGGL(k_mc_bma_windows, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+    int worst = 4;
+    for (int b = 0; b < a.nrec; b++) worst = max(worst, mc_size_class(recs[r0 + b].log_blk_sz));
+    if (worst == 4) hipLaunchKernelGGL(k_mc_bma_windows<4>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+    else if (worst == 5) hipLaunchKernelGGL(k_mc_bma_windows<5>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+    else hipLaunchKernelGGL(k_mc_bma_windows<6>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(m->h_win, m->d_win, nwin*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));

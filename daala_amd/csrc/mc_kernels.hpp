@@ -46,13 +46,32 @@ struct McPlaneRef {
   int org_x, org_y;       // picture origin inside a reference plane (the padding)
 };
 
-// The four single-vector predictions of a block (one per corner) into pred[k][...] (4096 bytes
+// LDS of a prediction kernel instantiated for blocks up to (1 << LM)^2 samples: the reference
+// window of one corner (rows -2 .. n+2, columns -2 .. n+2), the horizontal pass' 16-bit rows, and
+// NP prediction tiles.  Sized by the LARGEST block a launch holds (the host launches runs of
+// blocks of one size class): the 64x64 layout is 30 KB per workgroup - five single-wave
+// workgroups per CU - the 16x16 one 2 KB.
+template <int LM, int NP>
+struct McTiles {
+  static constexpr int N = 1 << LM;
+  static constexpr int SS = N + 8;                   // window stride (N + 5 used)
+  uint8_t stage[(N + 5)*SS];
+  int16_t buff[(N + 5)*N];
+  uint8_t pred[NP*N*N];
+};
+
+// The four single-vector predictions of a block (one per corner) into T.pred[k][...] (N*N bytes
 // apart), NT threads cooperating; corners that share reference and vector with an earlier corner
 // are not predicted again: alias[k] names the tile that holds corner k's prediction.
-template <int NT>
+// A corner's reference window is staged in LDS ONCE (clamped byte loads, a row of the window per
+// row of lanes) and both filter passes read LDS: the first form fetched every tap of every sample
+// from global memory through two clamps - six loads and twenty-four min/max per output sample
+// of the horizontal pass.
+template <int NT, int LM, int NP>
 __device__ __forceinline__ void mc_predict_corners(const McPlaneRef &R, int bx, int by, int lx, int ly,
                                                    const int32_t *ref, const int32_t *cmvx, const int32_t *cmvy,
-                                                   int16_t *buff, uint8_t *pred, int *alias, int lane) {
+                                                   McTiles<LM, NP> &T, int *alias, int lane) {
+  constexpr int PN = McTiles<LM, NP>::N*McTiles<LM, NP>::N, SS = McTiles<LM, NP>::SS;
   const int xblk = 1 << lx, yblk = 1 << ly, npix = xblk*yblk;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -67,7 +86,7 @@ __device__ __forceinline__ void mc_predict_corners(const McPlaneRef &R, int bx, 
     const int mvxf = mvx & 7, mvyf = mvy & 7;
     const uint8_t *plane = R.refs + (size_t)ref[k]*R.ref_plane;
     const int sx0 = R.org_x + bx + (mvx >> 3), sy0 = R.org_y + by + (mvy >> 3);
-    uint8_t *pk = pred + k*4096;
+    uint8_t *pk = T.pred + (NP == 1 ? 0 : k*PN);
     auto px = [&](int yy, int xx) -> int {
       // the reference relies on the padding of its reference frames; the clamp only keeps
       // a vector that points beyond it from reading outside the buffer
@@ -76,19 +95,28 @@ __device__ __forceinline__ void mc_predict_corners(const McPlaneRef &R, int bx, 
       return plane[(size_t)yy*R.ref_stride + xx];
     };
     if (mvxf || mvyf) {
+      // the window: rows -2 .. yblk + 2, columns -2 .. xblk + 2 of the displaced block
+      const int nrow = yblk + 5, ncol = xblk + 5;
+      const float ncol_1 = 1.0f/(float)ncol;
+      for (int e = lane; e < nrow*ncol; e += NT) {
+        const int r = (int)(((float)e + 0.5f)*ncol_1);   // e/ncol, exact for these small integers
+        const int c = e - r*ncol;
+        T.stage[r*SS + c] = (uint8_t)px(sy0 + r - 2, sx0 + c - 2);
+      }
+      __syncthreads();
       // 1st stage: rows -2 .. yblk + 2 (src/mc.c:145-172)
-      const int nrow = yblk + 5;
       for (int e = lane; e < nrow*xblk; e += NT) {
-        const int j = (e >> lx) - 2, i = e & (xblk - 1);
+        const int r = e >> lx, i = e & (xblk - 1);
+        const uint8_t *w = T.stage + r*SS + i;          // columns i - 2 .. i + 3 of the window row
         int v;
         if (mvxf) {
           int sum = 0;
 #pragma unroll
-          for (int t = 0; t < 6; t++) sum += px(sy0 + j, sx0 + i + t - 2)*MC_SUBPEL[mvxf][t];
+          for (int t = 0; t < 6; t++) sum += w[t]*MC_SUBPEL[mvxf][t];
           v = sum - (128 << 7);
         }
-        else v = (px(sy0 + j, sx0 + i) << 7) - (128 << 7);
-        buff[e] = (int16_t)v;
+        else v = (w[2] << 7) - (128 << 7);
+        T.buff[e] = (int16_t)v;
       }
       __syncthreads();
       // 2nd stage (src/mc.c:174-198)
@@ -98,10 +126,10 @@ __device__ __forceinline__ void mc_predict_corners(const McPlaneRef &R, int bx, 
         if (mvyf) {
           int sum = 0;
 #pragma unroll
-          for (int t = 0; t < 6; t++) sum += buff[(j + t)*xblk + i]*MC_SUBPEL[mvyf][t];
+          for (int t = 0; t < 6; t++) sum += T.buff[(j + t)*xblk + i]*MC_SUBPEL[mvyf][t];
           v = (sum + (1 << 13) + (128 << 14)) >> 14;
         }
-        else v = (buff[(j + 2)*xblk + i] + (1 << 6) + (128 << 7)) >> 7;
+        else v = (T.buff[(j + 2)*xblk + i] + (1 << 6) + (128 << 7)) >> 7;
         pk[e] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
       }
       __syncthreads();
@@ -168,9 +196,11 @@ struct McBlend {
 };
 
 #define MC_THREADS 128
+// LM: log2 of the largest block side of the launch (4, 5 or 6; the host launches runs of one class)
+template <int LM>
 __global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
-  __shared__ int16_t buff[(64 + 5)*64];
-  __shared__ uint8_t pred[4*4096];
+  __shared__ McTiles<LM, 4> T;
+  constexpr int PN = McTiles<LM, 4>::N*McTiles<LM, 4>::N;
   const int lane = threadIdx.x;
   const int bidx = blockIdx.x;
   if (bidx >= a.nblocks) return;
@@ -185,9 +215,9 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_predict_blocks(McArgs a) {
   R.org_x = a.org_x;
   R.org_y = a.org_y;
   int alias[4];
-  mc_predict_corners<MC_THREADS>(R, blk.x, blk.y, lx, ly, blk.ref, blk.mvx, blk.mvy, buff, pred, alias, lane);
-  const uint8_t *p0 = pred + alias[0]*4096, *p1 = pred + alias[1]*4096, *p2 = pred + alias[2]*4096,
-                *p3 = pred + alias[3]*4096;
+  mc_predict_corners<MC_THREADS, LM, 4>(R, blk.x, blk.y, lx, ly, blk.ref, blk.mvx, blk.mvy, T, alias, lane);
+  const uint8_t *p0 = T.pred + alias[0]*PN, *p1 = T.pred + alias[1]*PN, *p2 = T.pred + alias[2]*PN,
+                *p3 = T.pred + alias[3]*PN;
   uint8_t *d = a.dst + (size_t)blk.y*a.dst_stride + blk.x;
   McBlend W;
   W.setup(lx, ly, blk.oc, blk.s);
@@ -237,9 +267,10 @@ __device__ __forceinline__ int mc_div_pow2_re(int x, int shift) {
 }
 
 #define MC_SAD_THREADS 64
+template <int LM>
 __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_sad_items(McSadArgs a) {
-  __shared__ int16_t buff[(64 + 5)*64];
-  __shared__ uint8_t pred[4*4096];
+  __shared__ McTiles<LM, 4> T;
+  constexpr int PN = McTiles<LM, 4>::N*McTiles<LM, 4>::N;
   const int lane = threadIdx.x;
   const int idx = blockIdx.x;
   if (idx >= a.nitems) return;
@@ -257,9 +288,9 @@ __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_sad_items(McSadArgs a) {
       cmvy[k] = mc_div_pow2_re(it.mvy[k], P.ydec);
     }
     int alias[4];
-    mc_predict_corners<MC_SAD_THREADS>(P.R, bx, by, lx, ly, it.ref, cmvx, cmvy, buff, pred, alias, lane);
-    const uint8_t *p0 = pred + alias[0]*4096, *p1 = pred + alias[1]*4096, *p2 = pred + alias[2]*4096,
-                  *p3 = pred + alias[3]*4096;
+    mc_predict_corners<MC_SAD_THREADS, LM, 4>(P.R, bx, by, lx, ly, it.ref, cmvx, cmvy, T, alias, lane);
+    const uint8_t *p0 = T.pred + alias[0]*PN, *p1 = T.pred + alias[1]*PN, *p2 = T.pred + alias[2]*PN,
+                  *p3 = T.pred + alias[3]*PN;
     McBlend W;
     W.setup(lx, ly, it.oc, it.s);
     const int w = min(xblk, P.clip_w - bx), h = min(yblk, P.clip_h - by);
@@ -336,9 +367,10 @@ struct McBmaArgs {
   int32_t *sad;           // [nrec][(2R + 1)^2]; -1: outside the limits, not evaluated
 };
 
+template <int LM>
 __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_bma_windows(McBmaArgs a) {
-  __shared__ int16_t buff[(64 + 5)*64];
-  __shared__ uint8_t pred[4096];
+  __shared__ McTiles<LM, 1> T;
+  const uint8_t *pred = T.pred;
   const int lane = threadIdx.x;
   const int W = 2*a.radius + 1;
   const int rec = blockIdx.y, o = blockIdx.x;
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_bma_windows(McBmaArgs a) 
       cmvy[k] = mvy*(1 << (2 - P.ydec));
     }
     int alias[4];
-    mc_predict_corners<MC_SAD_THREADS>(P.R, bx, by, lx, ly, ref4, cmvx, cmvy, buff, pred, alias, lane);   // one tile
+    mc_predict_corners<MC_SAD_THREADS, LM, 1>(P.R, bx, by, lx, ly, ref4, cmvx, cmvy, T, alias, lane);   // one tile
     // od_enc_sad: the block clipped against [0, clip_w) x [0, clip_h)
     int acc = 0;
     for (int e = lane; e < npix; e += MC_SAD_THREADS) {
@@ -380,4 +412,27 @@ __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_bma_windows(McBmaArgs a) 
     __syncthreads();
   }
   if (lane == 0) *out = total;
+}
+
+// host side: a launch handles blocks of one size class (LDS sized by the class: McTiles)
+static inline int mc_size_class(int log_sz) { return log_sz <= 4 ? 4 : log_sz == 5 ? 5 : 6; }
+
+// calls launch(cls, first, count) for maximal runs of equal class; lists that change class too
+// often go out as one launch of the largest class (correct for every size, only slower)
+template <typename GetLog, typename Launch>
+static inline void mc_launch_runs(int n, GetLog log_of, Launch launch) {
+  int runs = 0, worst = 4;
+  for (int i = 0, c = -1; i < n; i++) {
+    const int ci = mc_size_class(log_of(i));
+    worst = ci > worst ? ci : worst;
+    if (ci != c) { runs++; c = ci; }
+  }
+  if (runs > 32) { launch(worst, 0, n); return; }
+  for (int i = 0; i < n;) {
+    const int c = mc_size_class(log_of(i));
+    int j = i + 1;
+    while (j < n && mc_size_class(log_of(j)) == c) j++;
+    launch(c, i, j - i);
+    i = j;
+  }
 }
