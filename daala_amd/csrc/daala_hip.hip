@@ -998,9 +998,19 @@ int od_hip_mc_bma_windows(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const
     a.sad = m->d_win + (size_t)r0*W*W;
     int worst = 4;
     for (int b = 0; b < a.nrec; b++) worst = max(worst, mc_size_class(recs[r0 + b].log_blk_sz));
-    if (worst == 4) hipLaunchKernelGGL(k_mc_bma_windows<4>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
-    else if (worst == 5) hipLaunchKernelGGL(k_mc_bma_windows<5>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
-    else hipLaunchKernelGGL(k_mc_bma_windows<6>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+    // OD_HIP_BMA_V1=1: one wave per (vertex, offset), every offset filtered by itself (A/B);
+    // default: one wave per vertex, phase planes shared by the window's offsets (radius <= 4)
+    static const int v1 = env_int("OD_HIP_BMA_V1", 0);
+    if (v1 || radius > 4) {
+      if (worst == 4) hipLaunchKernelGGL(k_mc_bma_windows<4>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+      else if (worst == 5) hipLaunchKernelGGL(k_mc_bma_windows<5>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+      else hipLaunchKernelGGL(k_mc_bma_windows<6>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
+    }
+    else {
+      if (worst == 4) hipLaunchKernelGGL((k_mc_bma_windows_v2<4, 64>), dim3(a.nrec), dim3(64), 0, m->stream, a);
+      else if (worst == 5) hipLaunchKernelGGL((k_mc_bma_windows_v2<5, 256>), dim3(a.nrec), dim3(256), 0, m->stream, a);
+      else hipLaunchKernelGGL((k_mc_bma_windows_v2<6, 256>), dim3(a.nrec), dim3(256), 0, m->stream, a);
+    }
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(m->h_win, m->d_win, nwin*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));

@@ -414,6 +414,151 @@ __global__ __launch_bounds__(MC_SAD_THREADS) void k_mc_bma_windows(McBmaArgs a) 
   if (lane == 0) *out = total;
 }
 
+// The same windows, one WAVE PER VERTEX (k_mc_bma_windows above: one wave per vertex AND offset,
+// which filters the block anew for each of the (2R + 1)^2 offsets).  The offsets of a window share
+// very few sub-sample phases: a half-sample vector is mvx*4 eighths of a luma sample - phase 0 or
+// 4 - and mvx*2 eighths of a 4:2:0 chroma sample - phase 0, 2, 4 or 6; their integer parts span
+// R + 1 (luma) or R/2 + 2 (chroma) positions.  So per plane: the reference window is staged once,
+// every horizontal phase is filtered once over the whole region (od_mc_predict1fmv8_c's first
+// stage, src/mc.c:145-172), every (horizontal, vertical) phase pair once (second stage, :174-198
+// - with phase 0 the two stages reduce to the copy the reference takes for whole-sample vectors),
+// and each offset's SAD (od_enc_sad: the block clipped against the picture) reads its phase
+// plane at its integer displacement.  Same numbers, about a tenth of the arithmetic.
+template <int LM>
+struct McBmaTiles {
+  static constexpr int N = 1 << LM;
+  static constexpr int WMAX = 6;                       // integer displacements of a window (R <= 4)
+  static constexpr int PW = N + WMAX - 1;              // phase plane side
+  static constexpr int SW = PW + 5, SS = SW + 3;       // staged window: 2 samples left/above, 3 right/below
+  uint8_t stage[SW*SS];
+  int16_t hbuf[SW*PW];
+  uint8_t plane[PW*PW];
+  uint8_t srcb[N*N];                                   // the block of the frame being coded
+  int32_t tot[96];                                     // the window's SAD sums
+  int32_t part[96];                                    // ... of the plane in hand
+};
+
+// NT threads per vertex: one wave for blocks up to 16x16, four for the larger ones (a level of large
+// blocks has few vertices: one wave each would leave most of the chip idle)
+template <int LM, int NT>
+__global__ __launch_bounds__(NT) void k_mc_bma_windows_v2(McBmaArgs a) {
+  using TT = McBmaTiles<LM>;
+  __shared__ TT T;
+  const int lane = threadIdx.x;
+  const int R = a.radius, W = 2*R + 1, NO = W*W;
+  const int rec = blockIdx.x;
+  if (rec >= a.nrec) return;
+  const McBmaRec r = a.recs[rec];
+  for (int o = lane; o < NO; o += NT) T.tot[o] = 0;
+  for (int pli = 0; pli < a.nplanes; pli++) {
+    const McSadPlane &P = a.pl[pli];
+    const int lx = r.log_blk_sz - P.xdec, ly = r.log_blk_sz - P.ydec;
+    const int bx = r.bx >> P.xdec, by = r.by >> P.ydec;          // arithmetic: positions are multiples of 4
+    const int xblk = 1 << lx, yblk = 1 << ly, npix = xblk*yblk;
+    const int shx = 2 - P.xdec, shy = 2 - P.ydec;                // half samples -> eighths of this plane's samples
+    // integer displacements the window spans, and the region the phase planes cover
+    const int ix0 = ((r.cx - R)*(1 << shx)) >> 3, ix1 = ((r.cx + R)*(1 << shx)) >> 3;
+    const int iy0 = ((r.cy - R)*(1 << shy)) >> 3, iy1 = ((r.cy + R)*(1 << shy)) >> 3;
+    const int pw = xblk + ix1 - ix0, ph = yblk + iy1 - iy0;      // <= TT::PW
+    const int sw = pw + 5, sh = ph + 5;
+    const uint8_t *plane_ref = P.R.refs + (size_t)r.ref*P.R.ref_plane;
+    const int sx0 = P.R.org_x + bx + ix0 - 2, sy0 = P.R.org_y + by + iy0 - 2;
+    {
+      const float sw_1 = 1.0f/(float)sw;
+      for (int e = lane; e < sh*sw; e += NT) {
+        const int rr = (int)(((float)e + 0.5f)*sw_1), c = e - rr*sw;      // e/sw, exact for these small integers
+        int yy = sy0 + rr, xx = sx0 + c;
+        yy = yy < 0 ? 0 : yy >= P.R.ref_h ? P.R.ref_h - 1 : yy;
+        xx = xx < 0 ? 0 : xx >= P.R.ref_stride ? P.R.ref_stride - 1 : xx;
+        T.stage[rr*TT::SS + c] = plane_ref[(size_t)yy*P.R.ref_stride + xx];
+      }
+      // the block of the frame being coded; samples outside the picture never count (od_enc_sad)
+      for (int e = lane; e < npix; e += NT) {
+        const int j = e >> lx, i = e & (xblk - 1);
+        const int sx = bx + i, sy = by + j;
+        const bool in = sx >= 0 && sx < P.clip_w && sy >= 0 && sy < P.clip_h;
+        T.srcb[e] = in ? P.src[(size_t)sy*P.src_stride + sx] : 0;
+      }
+    }
+    __syncthreads();
+    for (int o = lane; o < NO; o += NT) T.part[o] = 0;       // this plane's sums (the chroma shift applies to the whole sum)
+    const int fstep = 1 << shx;                                  // 4 (luma: phases 0, 4) or 2 (phases 0, 2, 4, 6)
+    const float pw_1 = 1.0f/(float)pw;
+    for (int fx = 0; fx < 8; fx += fstep) {
+      // is any offset of the window at this horizontal phase?  (W >= 2 consecutive vectors: yes
+      // for luma; chroma windows of R >= 2 cover all four)
+      bool anyx = false;
+      for (int ox = -R; ox <= R; ox++) anyx = anyx || ((((r.cx + ox)*(1 << shx)) & 7) == fx);
+      if (!anyx) continue;
+      // first stage over rows 0 .. sh - 1, columns 0 .. pw - 1 of the region
+      for (int e = lane; e < sh*pw; e += NT) {
+        const int rr = (int)(((float)e + 0.5f)*pw_1), c = e - rr*pw;
+        const uint8_t *w = T.stage + rr*TT::SS + c;              // window columns c .. c + 5 = samples c - 2 .. c + 3
+        int v;
+        if (fx) {
+          int sum = 0;
+#pragma unroll
+          for (int t = 0; t < 6; t++) sum += w[t]*MC_SUBPEL[fx][t];
+          v = sum - (128 << 7);
+        }
+        else v = (w[2] << 7) - (128 << 7);
+        T.hbuf[rr*TT::PW + c] = (int16_t)v;
+      }
+      __syncthreads();
+      for (int fy = 0; fy < 8; fy += (1 << shy)) {
+        bool anyy = false;
+        for (int oy = -R; oy <= R; oy++) anyy = anyy || ((((r.cy + oy)*(1 << shy)) & 7) == fy);
+        if (!anyy) continue;
+        // second stage: region rows 0 .. ph - 1 from first-stage rows rr .. rr + 5
+        for (int e = lane; e < ph*pw; e += NT) {
+          const int rr = (int)(((float)e + 0.5f)*pw_1), c = e - rr*pw;
+          const int16_t *h = T.hbuf + rr*TT::PW + c;
+          int v;
+          if (fy) {
+            int sum = 0;
+#pragma unroll
+            for (int t = 0; t < 6; t++) sum += h[t*TT::PW]*MC_SUBPEL[fy][t];
+            v = (sum + (1 << 13) + (128 << 14)) >> 14;
+          }
+          else v = (h[2*TT::PW] + (1 << 6) + (128 << 7)) >> 7;
+          T.plane[rr*TT::PW + c] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+        __syncthreads();
+        // the offsets at this phase pair
+        for (int oy = -R; oy <= R; oy++) {
+          const int my = (r.cy + oy)*(1 << shy);
+          if ((my & 7) != fy) continue;
+          const int dy = (my >> 3) - iy0;
+          for (int ox = -R; ox <= R; ox++) {
+            const int mx = (r.cx + ox)*(1 << shx);
+            if ((mx & 7) != fx) continue;
+            const int dx = (mx >> 3) - ix0;
+            int acc = 0;
+            for (int e = lane; e < npix; e += NT) {
+              const int j = e >> lx, i = e & (xblk - 1);
+              const int sx = bx + i, sy = by + j;
+              if (sx >= 0 && sx < P.clip_w && sy >= 0 && sy < P.clip_h) {
+                acc += abs((int)T.plane[(dy + j)*TT::PW + dx + i] - (int)T.srcb[e]);
+              }
+            }
+#pragma unroll
+            for (int q = 32; q > 0; q >>= 1) acc += __shfl_xor(acc, q);
+            if ((lane & 63) == 0) atomicAdd(&T.part[(oy + R)*W + ox + R], acc);
+          }
+        }
+        __syncthreads();                                       // the plane is rewritten by the next phase pair
+      }
+    }
+    for (int o = lane; o < NO; o += NT) T.tot[o] += T.part[o] >> P.shift;
+    __syncthreads();                                           // stage / srcb / part are rewritten by the next plane
+  }
+  for (int o = lane; o < NO; o += NT) {
+    const int mvx = r.cx + o%W - R, mvy = r.cy + o/W - R;
+    const bool in = mvx >= r.xmin && mvx <= r.xmax && mvy >= r.ymin && mvy <= r.ymax;
+    a.sad[(size_t)rec*NO + o] = in ? T.tot[o] : -1;
+  }
+}
+
 // host side: a launch handles blocks of one size class (LDS sized by the class: McTiles)
 static inline int mc_size_class(int log_sz) { return log_sz <= 4 ? 4 : log_sz == 5 ? 5 : 6; }
 
