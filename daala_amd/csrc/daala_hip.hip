@@ -1000,7 +1000,7 @@ int od_hip_mc_bma_windows(od_hip_mc *m, int nplanes, int pic_w, int pic_h, const
     for (int b = 0; b < a.nrec; b++) worst = max(worst, mc_size_class(recs[r0 + b].log_blk_sz));
     // OD_HIP_BMA_V1=1: one wave per (vertex, offset), every offset filtered by itself (A/B);
     // default: one wave per vertex, phase planes shared by the window's offsets (radius <= 4)
-    static const int v1 = env_int("OD_HIP_BMA_V1", 0);
+    const int v1 = env_int("OD_HIP_BMA_V1", 0);           // read per call: the parity test runs both kernels in one process
     if (v1 || radius > 4) {
       if (worst == 4) hipLaunchKernelGGL(k_mc_bma_windows<4>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);
       else if (worst == 5) hipLaunchKernelGGL(k_mc_bma_windows<5>, dim3(W*W, a.nrec), dim3(MC_SAD_THREADS), 0, m->stream, a);

@@ -730,6 +730,15 @@ def test_mvest_bma_windows(hip):
         got = mc.bma_windows(cut, 2, pw, ph, nplanes)
         assert (want == -1).any() and (want[:, 12] >= 0).all()
         assert np.array_equal(got, want), (nplanes, np.argwhere(got != want)[:5])
+    # the one-wave-per-offset kernel (OD_HIP_BMA_V1=1, kept for A/B) gives the same windows
+    os.environ['OD_HIP_BMA_V1'] = '1'
+    try:
+        for nplanes in (3, 1):
+            want = mvest_oracle_bma_windows(o, g, cut, 2, nplanes)
+            assert np.array_equal(mc.bma_windows(cut, 2, pw, ph, nplanes), want), nplanes
+        assert np.array_equal(mc.bma_windows(recs, 0, pw, ph)[:, 0], g['bma_sad'])
+    finally:
+        del os.environ['OD_HIP_BMA_V1']
     # more records than one launch's grid takes (a 4K frame's finest level): launched in chunks
     small = cut[cut['log_blk_sz'] == cut['log_blk_sz'].min()]
     many = np.tile(small, 1 + 40000//len(small))[:40000]
